@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import torch
+    return torch.load(os.path.join(GOLDEN, "golden.pt"), weights_only=False)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import bd_oracle
+    bd_oracle.lib()
+    return bd_oracle

@@ -1,0 +1,113 @@
+"""Pin the CPU oracle (oracle/bd_oracle.c) to the golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import torch
+
+
+def test_f16_bf16_conversions_match_numpy_and_torch(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(0)
+    vals = np.concatenate([
+        rng.standard_normal(4000).astype(np.float32) * 10.0 ** rng.integers(-9, 6, 4000),
+        np.array([0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e6, -1e6, 5.96e-8, 2.98e-8, 2.9802322e-8,
+                  2.9802326e-8, 6.1e-5, 6.097e-5, 1.0009765625, 1.00048828125, 1.0014648, np.inf, -np.inf],
+                 dtype=np.float32)])
+    # every fp16 bit pattern round-trips and re-rounds exactly
+    allh = np.arange(65536, dtype=np.uint16)
+    f = allh.view(np.float16).astype(np.float32)
+    for h in range(0, 65536, 7):
+        got = L.bdo_f16_to_f32(h)
+        assert (np.isnan(got) and np.isnan(f[h])) or np.float32(got).tobytes() == f[h].tobytes(), h
+    for v in vals:
+        want = np.float32(v).astype(np.float16).view(np.uint16)
+        assert L.bdo_f32_to_f16(float(v)) == int(want), (v, hex(int(want)))
+        wantb = torch.tensor(float(v), dtype=torch.float32).bfloat16().view(torch.int16).item() & 0xFFFF
+        assert L.bdo_f32_to_bf16(float(v)) == wantb, v
+    # midpoints between consecutive fp16 values (ties-to-even)
+    for h in range(1, 0x7bff, 13):
+        a, b = f[h], f[h + 1]
+        mid = np.float32((np.float64(a) + np.float64(b)) / 2)
+        want = mid.astype(np.float16).view(np.uint16)
+        assert L.bdo_f32_to_f16(float(mid)) == int(want), h
+
+
+def test_g1_pack_unpack_bit_exact(oracle, golden):
+    for case in golden["g1_pack32"]:
+        p = oracle.pack(case["bits"])
+        assert p.dtype == torch.int32 and p.shape == case["packed"].shape
+        assert torch.equal(p, case["packed"])
+        assert torch.equal(oracle.unpack(case["packed"]), case["bits"])
+    assert golden["g1_pack32"][4]["packed"].eq(-1).all()                 # all-ones word wraps to -1
+    assert golden["g1_pack32"][5]["packed"][0, 0].item() == -2 ** 31    # bit 31 only
+    for nb, case in golden["g1_pack_nbits"].items():
+        p = oracle.pack(case["bits"], n_bits=nb)
+        assert p.dtype == case["packed"].dtype and torch.equal(p, case["packed"])
+        assert torch.equal(oracle.unpack(case["packed"], n_bits=nb), case["bits"])
+    t = golden["g1_pack_transposed"]
+    assert torch.equal(oracle.pack(t["bits_NK"].T), t["packed"])
+
+
+def test_g2_binarize(oracle, golden):
+    for key in ("g2_binarydiff", "g2_binarydiff_fp16"):
+        g = golden[key]
+        mask, coeff = oracle.binarize(g["base"], g["fine"])
+        assert torch.equal(mask, g["mask"])
+        assert abs(coeff.item() - g["coeff"].item()) <= 2e-7 * abs(g["coeff"].item()) + 1e-12
+    g = golden["g2_binarydiff"]
+    assert g["state_keys"] == ["coeff", "mask", "base"]
+    # exact-zero diffs became bit 1 (diff.py:14-15), i.e. k=7,n=3 and k=33,n=5
+    assert (g["mask"][0, 3].item() >> 7) & 1 == 1 and (g["mask"][1, 5].item() >> 1) & 1 == 1
+
+
+def test_g3_kernel_semantics_bit_exact(oracle, golden):
+    # tl.dot's fp32 accumulation ORDER is not part of the reference's contract (the interpreter sums
+    # 32-wide blocks with numpy).  Short reductions are bit-exact in every order; for K=512 an fp32
+    # reordering may flip the last fp16 bit of a handful of outputs, so: >= 99.9 % bit-equal and every
+    # element within 1 fp16 ulp, for both oracle accumulation modes.
+    for case in golden["g3_bmm_fp16"]:
+        K = case["a"].shape[-1]
+        for acc_mode in (0, 1):
+            c = oracle.delta_bmm(case["a"], case["packed"], round_mode=1, acc_mode=acc_mode)
+            if K <= 96:
+                assert torch.equal(c, case["c"]), (case["a"].shape, acc_mode)
+            else:
+                assert (c == case["c"]).float().mean().item() >= 0.999
+                ulp = (c.view(torch.int16).int() - case["c"].view(torch.int16).int()).abs().max().item()
+                assert ulp <= 1, ulp
+    g = golden["g3_mm_fp16"]
+    c = oracle.delta_bmm(g["a"][None], g["packed"][None], round_mode=1)[0]
+    assert torch.equal(c, g["c"])
+    g = golden["g3_bmm_fp16_big"]
+    c = oracle.delta_bmm(g["a"], g["packed"], round_mode=1)
+    assert torch.equal(c.view(torch.int16), g["c"].view(torch.int16))    # includes +-inf overflow
+
+
+def test_g5_forward_reference_chain(oracle, golden):
+    for tag in ("bf16", "fp16"):
+        g = golden[f"g5_forward_{tag}"]
+        y = oracle.binary_linear(g["x"], g["base"], g["mask"][None], g["coeff"].reshape(1, 1), round_mode=1)
+        same = (y == g["y"]).float().mean().item()
+        # the base GEMM's fp32 accumulation order inside torch is not pinned; allow rare 1-ulp flips
+        assert same >= 0.97, (tag, same)
+        assert torch.allclose(y.float(), g["y"].float(), rtol=2 ** -7 if tag == "bf16" else 2 ** -10, atol=1e-4)
+        # single-rounding mode is at least as close to the exact value as the reference chain
+        y0 = oracle.binary_linear(g["x"], g["base"], g["mask"][None], g["coeff"].reshape(1, 1), round_mode=0,
+                                  out_dtype=torch.float32)
+        e_ref = (g["y"].float() - y0).abs().mean()
+        e_one = (y0.to(g["x"].dtype).float() - y0).abs().mean()
+        assert e_one <= e_ref * 1.0001
+
+
+def test_g6_multitenant(oracle, golden):
+    g = golden["g6_multitenant_fp16"]
+    y = oracle.binary_linear(g["h"], g["w"], g["masks"], g["coeffs"].float().reshape(-1, 1), round_mode=1)
+    same = (y == g["y"]).float().mean().item()
+    assert same >= 0.97, same
+    assert torch.allclose(y.float(), g["y"].float(), rtol=2 ** -10, atol=1e-4)
+
+
+def test_g7_merge(oracle, golden):
+    for key in ("g7_merge_fp16", "g7_merge_bf16"):
+        g = golden[key]
+        w = oracle.merge_delta(g["w"].clone(), g["mask"], g["coeff"].item())
+        assert torch.equal(w.view(torch.int16), g["w_merged"].view(torch.int16))
