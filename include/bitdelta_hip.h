@@ -1,0 +1,97 @@
+/*
+ * bitdelta_hip.h -- C ABI of libbitdelta_hip.so: the MI355X (gfx950) implementation of BitDelta's
+ * 1-bit-delta Linear hot path.  Plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ * noted; `stream` is a hipStream_t passed as void* (NULL = default stream).  All entry points are
+ * re-entrant and stateless (the reference's serving threads call without locks, demo/demo_backend.py:261).
+ * Return value: 0 on success, a negative BD_E_* code otherwise (bd_error_string() names it); nothing throws.
+ *
+ * The reference has no FFI of its own: the interface this library replaces is the Python function surface
+ * of /root/reference/bitdelta/binary_gemm_kernel.py and bitdelta/diff.py (cited per function below).
+ * bitdelta_amd/_lib.py is the ctypes binding; INTEGRATION.md shows the stub a maintainer of the
+ * reference would add.
+ *
+ * dtype codes: 0 = fp16, 1 = bf16, 2 = fp32 (outputs only).  All strides are in ELEMENTS.
+ */
+#ifndef BITDELTA_HIP_H
+#define BITDELTA_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BD_F16 0
+#define BD_BF16 1
+#define BD_F32 2
+
+#define BD_OK 0
+#define BD_E_K_NOT_MULTIPLE (-1)   /* K % n_bits != 0  (reference assert, binary_gemm_kernel.py:13) */
+#define BD_E_BAD_NBITS (-2)        /* n_bits not in {8,16,32,64} (reference: UnboundLocalError, :23-30) */
+#define BD_E_BAD_GROUPS (-3)       /* G < 1 or N % G != 0 */
+#define BD_E_BAD_DTYPE (-4)
+#define BD_E_BAD_SHAPE (-5)        /* negative / overflowing dimension */
+#define BD_E_WORKSPACE (-6)        /* workspace missing or too small */
+#define BD_E_LAUNCH (-7)           /* hipLaunchKernel failed (hipGetLastError has the detail) */
+#define BD_E_NULL (-8)
+
+int bd_version(void);
+const char* bd_error_string(int code);
+
+/* pack: replaces pack(x, n_bits)  -- bitdelta/binary_gemm_kernel.py:6-32.
+ * bits: torch.bool bytes, logical shape [batch, K, N] with element strides (s_b, s_k, s_n) -- the reference packs a
+ * transposed view (bitdelta/diff.py:16).  out: contiguous [batch, K/n_bits, N] of uint8/int16/int32/int64. */
+int bd_pack(const void* bits, int64_t batch, int64_t K, int64_t N, int64_t s_b, int64_t s_k, int64_t s_n,
+            void* out, int n_bits, void* stream);
+
+/* unpack: replaces unpack(x, n_bits) -- bitdelta/binary_gemm_kernel.py:34-46.
+ * words: contiguous [batch, KW, N]; out_bits: contiguous torch.bool bytes [batch, KW*n_bits, N]. */
+int bd_unpack(const void* words, int64_t batch, int64_t KW, int64_t N, void* out_bits, int n_bits, void* stream);
+
+/* delta GEMM: replaces binary_matmul / binary_bmm -- bitdelta/binary_gemm_kernel.py:153-184, :297-335 (kernels :48-151,
+ * :186-295).   C[b] = A[b] . (2*unpack(P[b]) - 1)
+ *   A [B,M,K] dtype (k contiguous), P int32 [B or 1, K/32, N] contiguous (sPb = 0 broadcasts one mask: what
+ *   bitdelta/diff.py:38 materialises with mask.repeat), C [B,M,N] out_dtype (n contiguous).
+ *   round_mode 1 = the reference epilogue fp32 -> fp16 -> out (:143/:287 then :167/:314); 0 = one rounding fp32 -> out.
+ *   alpha != NULL: C = alpha[b, g(n)] * acc (accumulate = 0) or C = C_in + alpha[b, g(n)] * acc (accumulate = 1), fp32
+ *   math, one rounding -- folds `coeff *` and `+` of bitdelta/diff.py:39 / demo_backend.py:97-98 into the epilogue.
+ *   alpha: fp32 [B or 1, G], sAlb = its batch stride (0 = broadcast); G scale groups split N evenly.
+ *   ws / ws_bytes: scratch of at least bd_gemm_workspace_bytes(B, M, N, K) bytes (may be NULL when that is 0). */
+int bd_delta_bmm(const void* A, const int32_t* P, void* C, int B, int M, int N, int K,
+                 int64_t sAb, int64_t sAm, int64_t sPb, int64_t sCb, int64_t sCm,
+                 int dtype, int out_dtype, int round_mode,
+                 const float* alpha, int64_t sAlb, int G, int accumulate,
+                 void* ws, int64_t ws_bytes, void* stream);
+
+/* fused 16-bit-base + 1-bit-delta Linear: replaces BinaryDiff.forward (bitdelta/diff.py:33-39) and
+ * DiffCompressModule.forward (demo/demo_backend.py:93-98) in ONE launch:
+ *   Y[b] = X[b] . W^T + alpha[b, g(n)] * (X[b] . S[b]),  fp32 accumulate, one rounding to out_dtype.
+ *   W [N,K] row-major, leading dimension ldw (BinaryDiff.base is its .T view, diff.py:18; nn.Linear.weight as is). */
+int bd_binary_linear(const void* X, const void* W, const int32_t* P, const float* alpha, void* Y,
+                     int B, int M, int N, int K,
+                     int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb, int64_t sAlb, int G,
+                     int64_t sYb, int64_t sYm, int dtype, int out_dtype,
+                     void* ws, int64_t ws_bytes, void* stream);
+
+/* bytes of scratch bd_delta_bmm / bd_binary_linear may need for this problem (split-k partials of the decode path) */
+int64_t bd_gemm_workspace_bytes(int B, int M, int N, int K);
+
+/* BinaryDiff.__init__ buffers in one pass -- bitdelta/diff.py:9-31: mask = pack((fine - base >= 0).T) int32 [K/32, N],
+ * coeff = mean|fine - base| (fp32, device scalar).  base, fine: [N,K] row-major, leading dimension ld. */
+int bd_binarize(const void* base, const void* fine, int64_t N, int64_t K, int64_t ld, int dtype,
+                int32_t* mask, float* coeff, void* ws, int64_t ws_bytes, void* stream);
+int64_t bd_binarize_workspace_bytes(int64_t N, int64_t K);
+
+/* load_diff's merge line -- bitdelta/diff.py:93-95: W[n,k] = round(W[n,k] + round(+-coeff)); coeff: device fp32 scalar. */
+int bd_merge_delta(void* W, int64_t ldw, const int32_t* P, const float* coeff, int64_t N, int64_t K, int dtype,
+                   void* stream);
+
+/* tuning / test hook: force a kernel family for bd_delta_bmm / bd_binary_linear.
+ * -1 auto (default); 0..3 MFMA tile configs (256x256, 128x256, 64x256, 32x256); 100 generic edge kernel; 200 decode GEMV.
+ * A forced variant whose preconditions fail returns BD_E_BAD_SHAPE instead of silently falling back. */
+int bd_set_gemm_variant(int variant);
+/* which family the LAST call on this thread dispatched to (same codes as above) */
+int bd_last_gemm_variant(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,295 @@
+// Native (no-Python) GPU harness: correctness spot checks + kernel timing for libbitdelta_hip.so and for
+// experimental tile configurations of bd_gemm_mfma.h.  Development / measurement tool: pytest (-m gpu) holds the
+// parity tests proper.  Build: see tests/native/Makefile.  Output: one JSON object per line on stdout.
+//
+//   bd_harness check            correctness over a shape grid, every kernel family (sampled exact reference)
+//   bd_harness perf             timing of the shipped dispatcher on the headline shapes
+//   bd_harness sweep            timing of experimental GemmCfg variants on 4096^3 (and 8192/16384 rows)
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../bitdelta_amd/csrc/bd_gemm_mfma.h"
+#include "../../include/bitdelta_hip.h"
+
+#define HIPCHECK(x)                                                                      \
+    do {                                                                                 \
+        hipError_t e_ = (x);                                                             \
+        if (e_ != hipSuccess) {                                                          \
+            fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(2);                                                                     \
+        }                                                                                \
+    } while (0)
+
+// ---------------- host-side 16-bit float helpers ----------------
+static inline float bf16_to_f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static inline uint16_t f_to_bf16(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
+static inline float f16_to_f(uint16_t h) { _Float16 x; memcpy(&x, &h, 2); return (float)x; }
+static inline uint16_t f_to_f16(float f) { _Float16 x = (_Float16)f; uint16_t h; memcpy(&h, &x, 2); return h; }
+static inline float h2f(uint16_t h, int dt) { return dt == BD_BF16 ? bf16_to_f(h) : f16_to_f(h); }
+static inline uint16_t f2h(float f, int dt) { return dt == BD_BF16 ? f_to_bf16(f) : f_to_f16(f); }
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static inline uint64_t rng() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
+static inline float urand() { return (float)((rng() >> 40) * (1.0 / 16777216.0)); }
+static inline float nrand() { float u1 = urand() + 1e-7f, u2 = urand(); return sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2); }
+
+struct Problem {
+    int B, M, N, K, dt, out_dt, fused, tenants;   // tenants: 1 = broadcast mask (sPb = 0), else B masks
+    std::vector<uint16_t> A, W;
+    std::vector<uint32_t> P;
+    std::vector<float> alpha;
+    void *dA = nullptr, *dW = nullptr, *dP = nullptr, *dAl = nullptr, *dC = nullptr, *dWs = nullptr;
+    int64_t ws_bytes = 0;
+    size_t c_elems() const { return (size_t)B * M * N; }
+};
+
+static void make_problem(Problem& q) {
+    const size_t na = (size_t)q.B * q.M * q.K, np = (size_t)(q.tenants == 1 ? 1 : q.B) * (q.K / 32) * q.N;
+    q.A.resize(na);
+    for (auto& v : q.A) v = f2h(nrand(), q.dt);
+    q.P.resize(np);
+    for (auto& v : q.P) v = (uint32_t)rng();
+    q.alpha.resize(q.B);
+    for (auto& v : q.alpha) v = 4e-4f * (0.75f + 0.5f * urand());
+    if (q.fused) {
+        q.W.resize((size_t)q.N * q.K);
+        for (auto& v : q.W) v = f2h(0.02f * nrand(), q.dt);
+    }
+    HIPCHECK(hipMalloc(&q.dA, na * 2));
+    HIPCHECK(hipMemcpy(q.dA, q.A.data(), na * 2, hipMemcpyHostToDevice));
+    HIPCHECK(hipMalloc(&q.dP, np * 4));
+    HIPCHECK(hipMemcpy(q.dP, q.P.data(), np * 4, hipMemcpyHostToDevice));
+    HIPCHECK(hipMalloc(&q.dAl, q.B * 4));
+    HIPCHECK(hipMemcpy(q.dAl, q.alpha.data(), q.B * 4, hipMemcpyHostToDevice));
+    if (q.fused) {
+        HIPCHECK(hipMalloc(&q.dW, q.W.size() * 2));
+        HIPCHECK(hipMemcpy(q.dW, q.W.data(), q.W.size() * 2, hipMemcpyHostToDevice));
+    }
+    HIPCHECK(hipMalloc(&q.dC, q.c_elems() * 4));
+    q.ws_bytes = bd_gemm_workspace_bytes(q.B, q.M, q.N, q.K);
+    if (q.ws_bytes) HIPCHECK(hipMalloc(&q.dWs, q.ws_bytes));
+}
+static void free_problem(Problem& q) {
+    hipFree(q.dA); hipFree(q.dP); hipFree(q.dAl); hipFree(q.dC);
+    if (q.dW) hipFree(q.dW);
+    if (q.dWs) hipFree(q.dWs);
+}
+
+static double ref_value(const Problem& q, int b, int m, int n) {
+    const uint16_t* a = &q.A[((size_t)b * q.M + m) * q.K];
+    const uint32_t* p = &q.P[(size_t)(q.tenants == 1 ? 0 : b) * (q.K / 32) * q.N];
+    double d = 0.0, base = 0.0;
+    for (int k = 0; k < q.K; ++k) {
+        const double x = h2f(a[k], q.dt);
+        d += ((p[(size_t)(k >> 5) * q.N + n] >> (k & 31)) & 1u) ? x : -x;
+        if (q.fused) base += x * (double)h2f(q.W[(size_t)n * q.K + k], q.dt);
+    }
+    return q.fused ? base + (double)q.alpha[b] * d : d;
+}
+
+// returns number of bad samples; fills max relative error (relative to the row-scale sqrt(K))
+static int check_output(const Problem& q, const void* hC, int nsamples, double* max_err, double* max_ulp) {
+    int bad = 0;
+    *max_err = 0; *max_ulp = 0;
+    const bool exhaustive = q.c_elems() <= (size_t)nsamples;
+    const size_t total = exhaustive ? q.c_elems() : (size_t)nsamples;
+    for (size_t s = 0; s < total; ++s) {
+        size_t idx = exhaustive ? s : (size_t)(rng() % q.c_elems());
+        if (!exhaustive && s < 64) {   // force the corners / edges into the sample
+            const int bb = (s & 1) ? q.B - 1 : 0, mm = (s & 2) ? q.M - 1 : (int)(s % q.M), nn = (s & 4) ? q.N - 1 : (int)((s * 7919) % q.N);
+            idx = ((size_t)bb * q.M + mm) * q.N + nn;
+        }
+        const int n = (int)(idx % q.N), m = (int)((idx / q.N) % q.M), b = (int)(idx / ((size_t)q.N * q.M));
+        const double r = ref_value(q, b, m, n);
+        double got, tol;
+        if (q.out_dt == BD_F32) {
+            got = ((const float*)hC)[idx];
+            tol = 2e-6 * (fabs(r) + sqrt((double)q.K));
+        } else {
+            got = h2f(((const uint16_t*)hC)[idx], q.out_dt);
+            int ex;
+            frexp(r, &ex);                                   // |r| in [2^(ex-1), 2^ex)
+            const double ulp = ldexp(1.0, ex - 1 - (q.out_dt == BD_BF16 ? 7 : 10));
+            tol = 0.5 * ulp + 4e-6 * (fabs(r) + sqrt((double)q.K)) + (q.out_dt == BD_F16 ? 6e-8 : 0);
+            if (ulp > 0) *max_ulp = fmax(*max_ulp, fabs(got - r) / ulp);
+        }
+        const double e = fabs(got - r);
+        *max_err = fmax(*max_err, e / (fabs(r) + sqrt((double)q.K)));
+        if (!(e <= tol)) {
+            if (bad < 5) fprintf(stderr, "  MISMATCH b=%d m=%d n=%d got=%.8g ref=%.8g tol=%.3g\n", b, m, n, got, r, tol);
+            ++bad;
+        }
+    }
+    return bad;
+}
+
+static int call_api(const Problem& q, hipStream_t st) {
+    const int64_t sPb = q.tenants == 1 ? 0 : (int64_t)(q.K / 32) * q.N;
+    if (q.fused)
+        return bd_binary_linear(q.dA, q.dW, (const int32_t*)q.dP, (const float*)q.dAl, q.dC, q.B, q.M, q.N, q.K,
+                                (int64_t)q.M * q.K, q.K, q.K, sPb, 1, 1, (int64_t)q.M * q.N, q.N, q.dt, q.out_dt, q.dWs,
+                                q.ws_bytes, st);
+    return bd_delta_bmm(q.dA, (const int32_t*)q.dP, q.dC, q.B, q.M, q.N, q.K, (int64_t)q.M * q.K, q.K, sPb,
+                        (int64_t)q.M * q.N, q.N, q.dt, q.out_dt, 0, nullptr, 0, 1, 0, q.dWs, q.ws_bytes, st);
+}
+
+template <class F>
+static double time_ms(F&& f, int warm, int iters) {
+    hipEvent_t e0, e1;
+    HIPCHECK(hipEventCreate(&e0));
+    HIPCHECK(hipEventCreate(&e1));
+    for (int i = 0; i < warm; ++i) f();
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) f();
+    HIPCHECK(hipEventRecord(e1, 0));
+    HIPCHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return ms / iters;
+}
+
+static const char* dtn(int dt) { return dt == BD_BF16 ? "bf16" : dt == BD_F16 ? "f16" : "f32"; }
+
+static int run_case(const char* tag, int B, int M, int N, int K, int dt, int out_dt, int fused, int tenants, int variant,
+                    int iters, int nsamples) {
+    Problem q{B, M, N, K, dt, out_dt, fused, tenants};
+    make_problem(q);
+    HIPCHECK(hipMemset(q.dC, 0xFF, q.c_elems() * 4));
+    bd_set_gemm_variant(variant);
+    int rc = call_api(q, 0);
+    hipError_t herr = hipDeviceSynchronize();
+    const int used = bd_last_gemm_variant();
+    int bad = -1;
+    double max_err = 0, max_ulp = 0, ms = 0;
+    if (rc == 0 && herr == hipSuccess) {
+        std::vector<uint8_t> hC(q.c_elems() * (out_dt == BD_F32 ? 4 : 2));
+        HIPCHECK(hipMemcpy(hC.data(), q.dC, hC.size(), hipMemcpyDeviceToHost));
+        bad = nsamples > 0 ? check_output(q, hC.data(), nsamples, &max_err, &max_ulp) : 0;
+        if (iters > 0) ms = time_ms([&] { call_api(q, 0); }, 3, iters);
+    }
+    const double flops = (fused ? 4.0 : 2.0) * B * M * (double)N * K;
+    const double bytes = 2.0 * B * M * K + (double)(tenants == 1 ? 1 : B) * K * N / 8 + (out_dt == BD_F32 ? 4.0 : 2.0) * B * M * N +
+                         (fused ? 2.0 * N * K : 0.0);
+    printf("{\"tag\":\"%s\",\"B\":%d,\"M\":%d,\"N\":%d,\"K\":%d,\"dt\":\"%s\",\"out\":\"%s\",\"fused\":%d,\"tenants\":%d,"
+           "\"variant\":%d,\"used\":%d,\"rc\":%d,\"hip\":\"%s\",\"bad\":%d,\"max_err\":%.3g,\"max_ulp\":%.3g,\"ms\":%.5f,"
+           "\"tflops\":%.2f,\"gbps\":%.1f}\n",
+           tag, B, M, N, K, dtn(dt), dtn(out_dt), fused, tenants, variant, used, rc, hipGetErrorString(herr), bad, max_err,
+           max_ulp, ms, ms > 0 ? flops / ms * 1e-9 : 0.0, ms > 0 ? bytes / ms * 1e-6 : 0.0);
+    fflush(stdout);
+    bd_set_gemm_variant(-1);
+    free_problem(q);
+    if (herr != hipSuccess) exit(3);   // device is in an undefined state after a fault
+    return (rc != 0 || bad != 0) ? 1 : 0;
+}
+
+// ---------------- experimental configs launched directly ----------------
+template <class Cfg>
+static void run_cfg(const char* name, int M, int N, int K, int iters, int nsamples) {
+    Problem q{1, M, N, K, Cfg::DT == bd::DT_BF16 ? BD_BF16 : BD_F16, Cfg::OUT_F32 ? BD_F32 : (Cfg::DT == bd::DT_BF16 ? BD_BF16 : BD_F16),
+              Cfg::FUSED ? 1 : 0, 1};
+    make_problem(q);
+    bd::GemmParams p{};
+    p.A = (const char*)q.dA; p.P = (const int32_t*)q.dP; p.C = (char*)q.dC; p.W = (const char*)q.dW; p.alpha = (const float*)q.dAl;
+    p.M = M; p.N = N; p.K = K;
+    p.tiles_m = (M + Cfg::BM - 1) / Cfg::BM; p.tiles_n = (N + Cfg::BN - 1) / Cfg::BN;
+    p.sAb = (long long)M * K; p.sPb = 0; p.sCb = (long long)M * N; p.sAm = K; p.sCm = N; p.ldw = K; p.sAlb = 0; p.gsz = N;
+    p.round_mode = 0; p.accumulate = 0;
+    HIPCHECK(hipFuncSetAttribute((const void*)bd::delta_gemm_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+    dim3 grid(p.tiles_m * p.tiles_n, 1);
+    auto launch = [&] { hipLaunchKernelGGL((bd::delta_gemm_kernel<Cfg>), grid, dim3(Cfg::NT), Cfg::LDS_BYTES, 0, p); };
+    HIPCHECK(hipMemset(q.dC, 0xFF, q.c_elems() * 4));
+    launch();
+    hipError_t herr = hipDeviceSynchronize();
+    int bad = -1; double max_err = 0, max_ulp = 0, ms = 0;
+    if (herr == hipSuccess) {
+        std::vector<uint8_t> hC(q.c_elems() * (Cfg::OUT_F32 ? 4 : 2));
+        HIPCHECK(hipMemcpy(hC.data(), q.dC, hC.size(), hipMemcpyDeviceToHost));
+        bad = check_output(q, hC.data(), nsamples, &max_err, &max_ulp);
+        ms = time_ms(launch, 5, iters);
+    }
+    const double flops = (Cfg::FUSED ? 4.0 : 2.0) * M * (double)N * K;
+    printf("{\"tag\":\"cfg\",\"name\":\"%s\",\"M\":%d,\"N\":%d,\"K\":%d,\"hip\":\"%s\",\"bad\":%d,\"max_err\":%.3g,\"max_ulp\":%.3g,"
+           "\"ms\":%.5f,\"tflops\":%.2f,\"lds\":%d}\n",
+           name, M, N, K, hipGetErrorString(herr), bad, max_err, max_ulp, ms, ms > 0 ? flops / ms * 1e-9 : 0.0, Cfg::LDS_BYTES);
+    fflush(stdout);
+    free_problem(q);
+    if (herr != hipSuccess) exit(3);
+}
+
+using namespace bd;
+#define CFG(name, ...) run_cfg<GemmCfg<__VA_ARGS__>>(name, M, N, K, iters, 2048)
+
+static void sweep(int M, int N, int K, int iters) {
+    //                      DT   BM   BN  WM WN NS fused f32 OPT
+    CFG("256x256_2x4_ns4", DT_BF16, 256, 256, 2, 4, 4, false, false, 0);
+    CFG("256x256_2x4_ns3", DT_BF16, 256, 256, 2, 4, 3, false, false, 0);
+    CFG("256x256_2x4_ns4_sgb", DT_BF16, 256, 256, 2, 4, 4, false, false, 1);
+    CFG("256x256_2x4_ns4_prio", DT_BF16, 256, 256, 2, 4, 4, false, false, 2);
+    CFG("256x256_2x4_ns4_sgb_prio", DT_BF16, 256, 256, 2, 4, 4, false, false, 3);
+    CFG("256x256_1x8_ns4", DT_BF16, 256, 256, 1, 8, 4, false, false, 0);
+    CFG("256x256_1x8_ns4_prio", DT_BF16, 256, 256, 1, 8, 4, false, false, 2);
+    CFG("256x256_4x2_ns4", DT_BF16, 256, 256, 4, 2, 4, false, false, 0);
+    CFG("256x128_2x2_ns4", DT_BF16, 256, 128, 2, 2, 4, false, false, 0);
+    CFG("128x256_1x4_ns4", DT_BF16, 128, 256, 1, 4, 4, false, false, 0);
+    CFG("128x128_2x2_ns4", DT_BF16, 128, 128, 2, 2, 4, false, false, 0);
+    CFG("256x256_2x4_ns4_f16", DT_F16, 256, 256, 2, 4, 4, false, false, 0);
+    CFG("256x256_2x4_fused", DT_BF16, 256, 256, 2, 4, 4, true, false, 0);
+    CFG("128x256_1x4_fused", DT_BF16, 128, 256, 1, 4, 4, true, false, 0);
+}
+
+int main(int argc, char** argv) {
+    const std::string mode = argc > 1 ? argv[1] : "check";
+    hipDeviceProp_t prop;
+    HIPCHECK(hipGetDeviceProperties(&prop, 0));
+    printf("{\"tag\":\"device\",\"name\":\"%s\",\"arch\":\"%s\",\"cus\":%d,\"clock_mhz\":%d,\"lds_per_block\":%zu}\n", prop.name,
+           prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000, prop.sharedMemPerBlock);
+    int fails = 0;
+    if (mode == "check") {
+        const int S = 4096;
+        // every kernel family, both dtypes, delta-only and fused, broadcast and per-tenant masks
+        for (int dt : {BD_BF16, BD_F16})
+            for (int fused : {0, 1}) {
+                for (int v : {0, 1, 2, 3, 100})
+                    fails += run_case("tile", 2, 200, 520, 256, dt, BD_F32, fused, 2, v, 0, S);
+                fails += run_case("tile_bcast", 3, 130, 300, 128, dt, dt, fused, 1, 0, 0, S);
+                fails += run_case("auto_big", 1, 512, 768, 1024, dt, dt, fused, 1, -1, 0, S);
+                fails += run_case("generic_k96", 2, 17, 40, 96, dt, BD_F32, fused, 2, -1, 0, S);
+                fails += run_case("gemv", 6, 1, 1000, 1024, dt, BD_F32, fused, 6, -1, 0, S);
+                fails += run_case("gemv_m2", 3, 2, 512, 512, dt, dt, fused, 3, -1, 0, S);
+                fails += run_case("gemv_b1", 1, 1, 4096, 4096, dt, dt, fused, 1, -1, 0, S);
+                fails += run_case("gemv_bcast16", 16, 1, 256, 2048, dt, BD_F32, fused, 1, -1, 0, S);
+            }
+        fails += run_case("edge_m1_tile", 1, 1, 256, 128, BD_BF16, BD_F32, 0, 1, 3, 0, S);
+        fails += run_case("edge_n_odd", 1, 70, 77, 64, BD_BF16, BD_BF16, 0, 1, -1, 0, S);
+        fails += run_case("edge_n_odd_t", 1, 70, 77, 64, BD_BF16, BD_BF16, 1, 1, 2, 0, S);
+        printf("{\"tag\":\"check_done\",\"fails\":%d}\n", fails);
+    } else if (mode == "perf") {
+        const int it = 20;
+        for (int M : {4096, 8192, 16384}) fails += run_case("delta_4096sq", 1, M, 4096, 4096, BD_BF16, BD_BF16, 0, 1, -1, it, 2048);
+        fails += run_case("fused_4096sq", 1, 4096, 4096, 4096, BD_BF16, BD_BF16, 1, 1, -1, it, 2048);
+        fails += run_case("fused_2048x4096", 1, 2048, 4096, 4096, BD_BF16, BD_BF16, 1, 1, -1, it, 2048);
+        fails += run_case("fused_gate", 1, 2048, 11008, 4096, BD_BF16, BD_BF16, 1, 1, -1, it, 2048);
+        fails += run_case("fused_down", 1, 2048, 4096, 11008, BD_BF16, BD_BF16, 1, 1, -1, it, 2048);
+        fails += run_case("c1_128", 1, 128, 4096, 4096, BD_BF16, BD_BF16, 1, 1, -1, it, 2048);
+        for (int T : {1, 6, 16}) {
+            fails += run_case("decode_delta", T, 1, 4096, 4096, BD_BF16, BD_BF16, 0, T, -1, 50, 2048);
+            fails += run_case("decode_fused", T, 1, 4096, 4096, BD_BF16, BD_BF16, 1, T, -1, 50, 2048);
+        }
+        fails += run_case("decode_fused_gate", 6, 1, 14336, 4096, BD_F16, BD_F16, 1, 6, -1, 50, 2048);
+        fails += run_case("decode_fused_down", 6, 1, 4096, 14336, BD_F16, BD_F16, 1, 6, -1, 50, 2048);
+        fails += run_case("decode_fused_kv", 6, 1, 1024, 4096, BD_F16, BD_F16, 1, 6, -1, 50, 2048);
+        fails += run_case("prefill64_t6", 6, 64, 4096, 4096, BD_F16, BD_F16, 1, 6, -1, it, 2048);
+    } else if (mode == "sweep") {
+        const int M = argc > 2 ? atoi(argv[2]) : 4096;
+        sweep(M, 4096, 4096, 20);
+    }
+    return fails ? 1 : 0;
+}
