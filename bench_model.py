@@ -1,0 +1,169 @@
+"""Synthetic-weight Llama/Mistral decoder used by bench.py (plain PyTorch plumbing around the HIP op).
+
+The hot path (the 7 projections of every layer) runs through bitdelta_amd.BinaryDiff / DiffCompressModule -> the
+fused HIP kernels.  Everything else (RMSNorm, RoPE, SDPA attention, SiLU, embedding, lm_head) is stock torch: it is
+the caller of the path, not the product.  Weights are random with the statistics SURVEY.md section 8(d) prescribes
+(W ~ N(0, 0.02^2) bf16, fine-tune = W + N(0, (5e-4)^2), alpha = mean|delta| ~ 4e-4); there is no network for real
+checkpoints.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from bitdelta_amd.diff import BinaryDiff
+from bitdelta_amd.serving import DiffCompressModule
+from bitdelta_amd.diff import binarize
+
+CONFIGS = {
+    # name: (hidden, intermediate, layers, heads, kv_heads, vocab)
+    "llama-2-7b": (4096, 11008, 32, 32, 32, 32000),
+    "mistral-7b": (4096, 14336, 32, 32, 8, 32000),
+    "llama-2-70b": (8192, 28672, 80, 64, 8, 32000),
+    "tiny": (256, 512, 2, 4, 4, 512),
+}
+
+
+def synth_pair(n_out, n_in, device, dtype, gen):
+    w = (torch.randn(n_out, n_in, device=device, generator=gen) * 0.02).to(dtype)
+    fine = (w.float() + torch.randn(n_out, n_in, device=device, generator=gen) * 5e-4).to(dtype)
+    return w, fine
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, dim, dtype, device, eps=1e-5):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim, dtype=dtype, device=device), requires_grad=False)
+        self.eps = eps
+
+    def forward(self, x):
+        v = x.float()
+        v = v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + self.eps)
+        return (v.to(x.dtype)) * self.weight
+
+
+def rope_tables(seq, dim, device, base=10000.0):
+    inv = 1.0 / (base ** (torch.arange(0, dim, 2, device=device, dtype=torch.float32) / dim))
+    t = torch.arange(seq, device=device, dtype=torch.float32)
+    f = torch.outer(t, inv)
+    emb = torch.cat([f, f], dim=-1)
+    return emb.cos(), emb.sin()
+
+
+def apply_rope(x, cos, sin):
+    # x [B, H, S, D]
+    d = x.shape[-1] // 2
+    rot = torch.cat([-x[..., d:], x[..., :d]], dim=-1)
+    return (x.float() * cos + rot.float() * sin).to(x.dtype)
+
+
+class SingleTenantLinear(nn.Module):
+    """One BinaryDiff (base + 1 delta): training/eval form, reference bitdelta/diff.py:8-39."""
+
+    def __init__(self, n_out, n_in, device, dtype, gen):
+        super().__init__()
+        w, fine = synth_pair(n_out, n_in, device, dtype, gen)
+        self.lin = BinaryDiff(w, fine)
+        self.lin.coeff.requires_grad_(False)
+        self.flops_per_row = 4 * n_out * n_in
+
+    def forward(self, x):
+        return self.lin(x)
+
+
+class MultiTenantLinear(nn.Module):
+    """One base nn.Linear + T deltas, row i -> tenant i: serving form, reference demo/demo_backend.py:82-98."""
+
+    def __init__(self, n_out, n_in, device, dtype, gen, tenants):
+        super().__init__()
+        base = nn.Linear(n_in, n_out, bias=False, device=device, dtype=dtype)
+        masks, coeffs = [], []
+        with torch.no_grad():
+            base.weight.copy_((torch.randn(n_out, n_in, device=device, generator=gen) * 0.02).to(dtype))
+            for _ in range(tenants):
+                fine = (base.weight.float() + torch.randn(n_out, n_in, device=device, generator=gen) * 5e-4).to(dtype)
+                m, c = binarize(base.weight.data, fine)
+                masks.append(m)
+                coeffs.append(c)
+        base.weight.requires_grad_(False)
+        self.lin = DiffCompressModule(base, torch.stack(masks, 0).contiguous(), torch.stack(coeffs, 0).to(dtype))
+        self.flops_per_row = 4 * n_out * n_in
+
+    def forward(self, x):
+        return self.lin(x)
+
+
+class DecoderLayer(nn.Module):
+    def __init__(self, cfg, device, dtype, gen, tenants=0):
+        super().__init__()
+        hid, inter, _, heads, kvh, _ = cfg
+        self.heads, self.kvh, self.hd = heads, kvh, hid // heads
+        mk = (lambda o, i: MultiTenantLinear(o, i, device, dtype, gen, tenants)) if tenants else \
+             (lambda o, i: SingleTenantLinear(o, i, device, dtype, gen))
+        self.q_proj = mk(hid, hid)
+        self.k_proj = mk(kvh * self.hd, hid)
+        self.v_proj = mk(kvh * self.hd, hid)
+        self.o_proj = mk(hid, hid)
+        self.gate_proj = mk(inter, hid)
+        self.up_proj = mk(inter, hid)
+        self.down_proj = mk(hid, inter)
+        self.input_layernorm = RMSNorm(hid, dtype, device)
+        self.post_attention_layernorm = RMSNorm(hid, dtype, device)
+
+    def forward(self, x, cos, sin, kv=None):
+        B, S, _ = x.shape
+        h = self.input_layernorm(x)
+        q = self.q_proj(h).view(B, S, self.heads, self.hd).transpose(1, 2)
+        k = self.k_proj(h).view(B, S, self.kvh, self.hd).transpose(1, 2)
+        v = self.v_proj(h).view(B, S, self.kvh, self.hd).transpose(1, 2)
+        q, k = apply_rope(q, cos, sin), apply_rope(k, cos, sin)
+        if kv is not None:                      # decode: append to the cache
+            if kv[0] is not None:
+                k = torch.cat([kv[0], k], dim=2)
+                v = torch.cat([kv[1], v], dim=2)
+            kv[0], kv[1] = k, v
+        if self.kvh != self.heads:
+            rep = self.heads // self.kvh
+            k = k.repeat_interleave(rep, dim=1)
+            v = v.repeat_interleave(rep, dim=1)
+        a = F.scaled_dot_product_attention(q, k, v, is_causal=(S > 1))
+        a = a.transpose(1, 2).reshape(B, S, self.heads * self.hd)
+        x = x + self.o_proj(a)
+        h = self.post_attention_layernorm(x)
+        x = x + self.down_proj(F.silu(self.gate_proj(h)) * self.up_proj(h))
+        return x
+
+
+class Decoder(nn.Module):
+    def __init__(self, name, device, dtype=torch.bfloat16, tenants=0, layers=None, seed=0):
+        super().__init__()
+        cfg = CONFIGS[name]
+        hid, inter, nl, heads, kvh, vocab = cfg
+        nl = layers or nl
+        gen = torch.Generator(device=device)
+        gen.manual_seed(seed)
+        self.cfg, self.dtype, self.device_, self.tenants = cfg, dtype, device, tenants
+        self.embed = nn.Embedding(vocab, hid, device=device, dtype=dtype)
+        self.layers = nn.ModuleList([DecoderLayer(cfg, device, dtype, gen, tenants) for _ in range(nl)])
+        self.norm = RMSNorm(hid, dtype, device)
+        self.lm_head = nn.Linear(hid, vocab, bias=False, device=device, dtype=dtype)
+        for p in self.parameters():
+            p.requires_grad_(False)
+        self.hd = hid // heads
+
+    def linear_flops_per_token(self):
+        return sum(m.flops_per_row for m in self.modules() if hasattr(m, "flops_per_row"))
+
+    def linear_param_count(self):
+        return self.linear_flops_per_token() // 4
+
+    @torch.no_grad()
+    def forward(self, ids, pos0=0, cache=None):
+        B, S = ids.shape
+        cos, sin = rope_tables(pos0 + S, self.hd, ids.device)
+        cos, sin = cos[pos0:], sin[pos0:]
+        x = self.embed(ids)
+        for i, layer in enumerate(self.layers):
+            x = layer(x, cos, sin, None if cache is None else cache[i])
+        return self.lm_head(self.norm(x[:, -1:, :]))

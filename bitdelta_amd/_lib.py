@@ -1,0 +1,90 @@
+"""ctypes binding of libbitdelta_hip.so (include/bitdelta_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a tensor is not on a ROCm device the
+call raises.  Nothing here imports oracle/.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbitdelta_hip.so")
+
+BD_F16, BD_BF16, BD_F32 = 0, 1, 2
+DTYPE_CODE = {torch.float16: BD_F16, torch.bfloat16: BD_BF16, torch.float32: BD_F32}
+WORD_DTYPE = {8: torch.uint8, 16: torch.int16, 32: torch.int32, 64: torch.int64}
+
+_i64, _vp, _ci = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int
+
+# name -> (restype, argtypes); must list every symbol declared in include/bitdelta_hip.h (tests check this)
+SIGNATURES = {
+    "bd_version": (_ci, []),
+    "bd_error_string": (ctypes.c_char_p, [_ci]),
+    "bd_pack": (_ci, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _ci, _vp]),
+    "bd_unpack": (_ci, [_vp, _i64, _i64, _i64, _vp, _ci, _vp]),
+    "bd_delta_bmm": (_ci, [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _ci, _ci, _ci,
+                           _vp, _i64, _ci, _ci, _vp, _i64, _vp]),
+    "bd_binary_linear": (_ci, [_vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _ci,
+                               _i64, _i64, _ci, _ci, _vp, _i64, _vp]),
+    "bd_gemm_workspace_bytes": (_i64, [_ci, _ci, _ci, _ci]),
+    "bd_binarize": (_ci, [_vp, _vp, _i64, _i64, _i64, _ci, _vp, _vp, _vp, _i64, _vp]),
+    "bd_binarize_workspace_bytes": (_i64, [_i64, _i64]),
+    "bd_merge_delta": (_ci, [_vp, _i64, _vp, _vp, _i64, _i64, _ci, _vp]),
+    "bd_set_gemm_variant": (_ci, [_ci]),
+    "bd_last_gemm_variant": (_ci, []),
+}
+
+_lib = None
+
+
+class BitDeltaHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libbitdelta_hip.so (built by __graft_entry__.build() / bitdelta_amd/build.py).  Raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BitDeltaHipError(
+                f"{LIB_PATH} not found: build it with `python -m bitdelta_amd.build` (hipcc, gfx950). "
+                "bitdelta_amd has no CPU / PyTorch fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().bd_error_string(rc).decode()
+        if rc in (-1,):
+            raise AssertionError(f"{what}: {msg}")          # the reference raises AssertionError here
+        raise BitDeltaHipError(f"{what}: {msg} (code {rc})")
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if t.device.type != "cuda":
+            raise BitDeltaHipError(
+                "bitdelta_amd ops run on a ROCm device only (got a %s tensor); there is no CPU fallback" % t.device.type)
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def workspace(nbytes, device):
+    if nbytes <= 0:
+        return None, 0
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device), int(nbytes)

@@ -1,0 +1,174 @@
+"""MI355X drop-in for the reference's ``bitdelta/binary_gemm_kernel.py``.
+
+Same public names, signatures, asserts and result semantics:
+
+    pack(x, n_bits=32)                          reference :6-32
+    unpack(x, n_bits=32)                        reference :34-46
+    binary_matmul(a, b, n_bits=32, activation="")   reference :153-184 (kernel :48-151)
+    binary_bmm(a, b, n_bits=32, activation="")      reference :297-335 (kernel :186-295)
+
+Every function launches hand-written HIP (gfx950) through the C ABI in include/bitdelta_hip.h; there is no
+Triton, no torch-op composition and no CPU path.  Extra keyword-only arguments (``round_mode``, ``out_dtype``) expose
+what the reference hard-codes; their defaults reproduce the reference.
+"""
+import torch
+
+from . import _lib
+from ._lib import DTYPE_CODE, WORD_DTYPE, check, lib, ptr, require_gpu, stream_ptr, workspace
+
+__all__ = ["pack", "unpack", "binary_matmul", "binary_bmm", "delta_bmm", "binary_linear"]
+
+
+def pack(x, n_bits=32):
+    """
+    pack n_bits of x into a single integer
+
+    x: bool tensor (*, K, N)
+    return: int tensor (*, K // n_bits, N)
+    """
+    assert x.shape[-2] % n_bits == 0, "K must be divisible by n_bits"
+    if n_bits not in WORD_DTYPE:
+        # reference: `dtype` is never bound for other widths (binary_gemm_kernel.py:23-32)
+        raise UnboundLocalError("local variable 'dtype' referenced before assignment")
+    require_gpu(x)
+    if x.dtype != torch.bool:
+        x = x != 0
+    lead = tuple(x.shape[:-2])
+    K, N = x.shape[-2], x.shape[-1]
+    if x.dim() == 2:
+        x3 = x.unsqueeze(0)
+    elif x.dim() == 3:
+        x3 = x
+    else:
+        x3 = x.reshape(-1, K, N)
+    out = torch.empty((x3.shape[0], K // n_bits, N), dtype=WORD_DTYPE[n_bits], device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().bd_pack(ptr(x3), x3.shape[0], K, N, x3.stride(0), x3.stride(1), x3.stride(2), ptr(out), n_bits,
+                            stream_ptr()), "pack")
+    return out.view(*lead, K // n_bits, N)
+
+
+def unpack(x, n_bits=32):
+    """
+    unpack n_bits of x into a single integer
+
+    x: int tensor (*, K // n_bits, N)
+    return: bool tensor (*, K, N)
+    """
+    if n_bits not in WORD_DTYPE:
+        raise ValueError("n_bits must be 8, 16, 32 or 64")
+    require_gpu(x)
+    if x.dtype != WORD_DTYPE[n_bits]:
+        # the reference shifts whatever integer dtype it is given; only the low n_bits matter
+        x = x.to(WORD_DTYPE[n_bits])
+    lead = tuple(x.shape[:-2])
+    KW, N = x.shape[-2], x.shape[-1]
+    xc = x.contiguous().view(-1, KW, N)
+    out = torch.empty((xc.shape[0], KW * n_bits, N), dtype=torch.bool, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().bd_unpack(ptr(xc), xc.shape[0], KW, N, ptr(out), n_bits, stream_ptr()), "unpack")
+    return out.view(*lead, KW * n_bits, N)
+
+
+def delta_bmm(a, b, *, out=None, out_dtype=None, round_mode=1, alpha=None, accumulate=False, groups=1):
+    """C[i] = a[i] . (2*unpack(b[i]) - 1)  (+ optional fused ``alpha *`` / ``C +=`` epilogue).
+
+    a: (B, M, K) fp16/bf16, rows k-contiguous.  b: (B, K/32, N) or (1, K/32, N) int32 contiguous -- a leading 1
+    broadcasts ONE mask over the batch (what bitdelta/diff.py:38 materialises with ``mask.repeat``).
+    alpha: fp32 tensor of shape (B or 1, groups) or None.
+    """
+    require_gpu(a, b, alpha, out)
+    assert a.dim() == 3 and b.dim() == 3
+    B, M, K = a.shape
+    N = b.shape[2]
+    assert b.dtype == torch.int32 and b.is_contiguous()
+    assert b.shape[0] in (1, B) and b.shape[1] * 32 == K
+    assert a.dtype in (torch.float16, torch.bfloat16) and a.stride(2) == 1
+    out_dtype = out_dtype or a.dtype
+    if out is None:
+        assert not accumulate
+        out = torch.empty((B, M, N), device=a.device, dtype=out_dtype)
+    else:
+        assert out.shape == (B, M, N) and out.dtype == out_dtype and out.stride(2) == 1
+    sPb = 0 if (b.shape[0] == 1 and B > 1) else b.stride(0)
+    al_ptr, sAlb = ptr(None), 0
+    if alpha is not None:
+        alpha = alpha.detach()
+        if alpha.dtype != torch.float32 or not alpha.is_contiguous():
+            alpha = alpha.float().contiguous()
+        alpha = alpha.reshape(-1, groups)
+        assert alpha.shape[0] in (1, B)
+        al_ptr, sAlb = ptr(alpha), (0 if alpha.shape[0] == 1 else groups)
+    L = lib()
+    ws, ws_bytes = workspace(L.bd_gemm_workspace_bytes(B, M, N, K), a.device)
+    with torch.cuda.device(a.device):
+        check(L.bd_delta_bmm(ptr(a), ptr(b), ptr(out), B, M, N, K, a.stride(0), a.stride(1), sPb, out.stride(0),
+                             out.stride(1), DTYPE_CODE[a.dtype], DTYPE_CODE[out_dtype], int(round_mode), al_ptr, sAlb,
+                             groups, 1 if accumulate else 0, ptr(ws), ws_bytes, stream_ptr()), "delta_bmm")
+    return out
+
+
+def binary_linear(x, weight, mask, alpha, *, out_dtype=None, groups=1):
+    """Fused 16-bit base + 1-bit delta Linear:  y[i] = x[i] . weight^T + alpha[i] * (x[i] . S[i])  in ONE launch.
+
+    x: (B, M, K); weight: (N, K) rows k-contiguous; mask: (B or 1, K/32, N) int32; alpha: fp32 (B or 1, groups).
+    Replaces the four launches of BinaryDiff.forward (bitdelta/diff.py:38-39) / DiffCompressModule.forward
+    (demo/demo_backend.py:95-98).  fp32 accumulation, one rounding to ``out_dtype`` (default: x.dtype).
+    """
+    require_gpu(x, weight, mask, alpha)
+    assert x.dim() == 3 and mask.dim() == 3 and weight.dim() == 2
+    B, M, K = x.shape
+    N = weight.shape[0]
+    assert weight.shape[1] == K and weight.stride(1) == 1 and weight.dtype == x.dtype
+    assert mask.dtype == torch.int32 and mask.is_contiguous() and mask.shape[1] * 32 == K and mask.shape[2] == N
+    assert mask.shape[0] in (1, B) and x.stride(2) == 1
+    out_dtype = out_dtype or x.dtype
+    alpha = alpha.detach()
+    if alpha.dtype != torch.float32 or not alpha.is_contiguous():
+        alpha = alpha.float().contiguous()
+    alpha = alpha.reshape(-1, groups)
+    assert alpha.shape[0] in (1, B)
+    y = torch.empty((B, M, N), device=x.device, dtype=out_dtype)
+    sPb = 0 if (mask.shape[0] == 1 and B > 1) else mask.stride(0)
+    sAlb = 0 if alpha.shape[0] == 1 else groups
+    L = lib()
+    ws, ws_bytes = workspace(L.bd_gemm_workspace_bytes(B, M, N, K), x.device)
+    with torch.cuda.device(x.device):
+        check(L.bd_binary_linear(ptr(x), ptr(weight), ptr(mask), ptr(alpha), ptr(y), B, M, N, K, x.stride(0),
+                                 x.stride(1), weight.stride(0), sPb, sAlb, groups, y.stride(0), y.stride(1),
+                                 DTYPE_CODE[x.dtype], DTYPE_CODE[out_dtype], ptr(ws), ws_bytes, stream_ptr()),
+              "binary_linear")
+    return y
+
+
+def binary_matmul(a, b, n_bits=32, activation="", *, round_mode=1, out_dtype=None):
+    """
+        a: float tensor (M, K)
+        b: int tensor (K, N)
+        n_bits: int, number of bits that each element in b represents
+    """
+    # Check constraints (same as the reference, binary_gemm_kernel.py:159-162).
+    assert a.shape[1] == b.shape[0] * n_bits, "Incompatible dimensions"
+    assert a.is_contiguous(), "Matrix A must be contiguous"
+    assert b.is_contiguous(), "Matrix B must be contiguous"
+    assert n_bits == 32, "the packed operand must be int32 words (the reference's only exercised width)"
+    # `activation` is accepted and ignored, exactly like the reference (:73, :141-142)
+    return delta_bmm(a.unsqueeze(0), b.unsqueeze(0), round_mode=round_mode, out_dtype=out_dtype)[0]
+
+
+def binary_bmm(a, b, n_bits=32, activation="", *, round_mode=1, out_dtype=None):
+    """
+        a: float tensor (B, M, K)
+        b: int tensor (B, K, N)
+        n_bits: int, number of bits that each element in b represents
+    """
+    assert a.dim() == 3, "Matrix A must be 3D"
+    assert b.dim() == 3, "Matrix B must be 3D"
+    assert a.shape[2] == b.shape[1] * n_bits, "Incompatible dimensions"
+    assert a.shape[0] == b.shape[0], "Incompatible batch dimensions"
+    assert a.is_contiguous(), "Matrix A must be contiguous"
+    assert b.is_contiguous(), "Matrix B must be contiguous"
+    assert a.device == b.device, "A and B must be on the same device"
+    assert n_bits == 32, "the packed operand must be int32 words (the reference's only exercised width)"
+    # output: non-differentiable tensor of a.dtype, fp32 accumulate -> fp16 -> a.dtype (reference :287, :314)
+    return delta_bmm(a, b, round_mode=round_mode, out_dtype=out_dtype)

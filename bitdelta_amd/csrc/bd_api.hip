@@ -4,6 +4,7 @@
 #include "bd_bits.h"
 #include "bd_gemm_generic.h"
 #include "bd_gemm_mfma.h"
+#include "bd_gemm_pp.h"
 #include "bd_gemv.h"
 
 using namespace bd;
@@ -173,18 +174,22 @@ inline GemmParams make_params(const Problem& q, int BM, int BN) {
     return p;
 }
 
-template <class Cfg>
+template <class Cfg, bool PP> struct TileKernel { static auto get() { return delta_gemm_kernel<Cfg>; } };
+template <class Cfg> struct TileKernel<Cfg, true> { static auto get() { return delta_gemm_pp_kernel<Cfg>; } };
+
+// PP = ping-pong schedule (bd_gemm_pp.h): the 256x256 tile; the smaller tiles use the single-barrier kernel.
+template <class Cfg, bool PP = false>
 int launch_tile(const Problem& q) {
     const GemmParams p = make_params(q, Cfg::BM, Cfg::BN);
+    auto kern = TileKernel<Cfg, PP>::get();
     static bool attr_set = false;   // benign race: idempotent
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)delta_gemm_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                Cfg::LDS_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess)
             return BD_E_LAUNCH;
         attr_set = true;
     }
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)q.B);
-    hipLaunchKernelGGL((delta_gemm_kernel<Cfg>), grid, dim3(Cfg::NT), Cfg::LDS_BYTES, q.st, p);
+    hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, q.st, p);
     return launch_status();
 }
 
@@ -208,11 +213,12 @@ int dispatch3(const Problem& q) {
         else v = 3;
     } else {
         if (v == 200 && !gemv_ok(q)) return BD_E_BAD_SHAPE;
-        if (v >= 0 && v <= 3 && !fast_ok(q)) return BD_E_BAD_SHAPE;
+        if (v >= 0 && v <= 4 && !fast_ok(q)) return BD_E_BAD_SHAPE;
     }
     t_last_variant = v;
     switch (v) {
-        case 0: return launch_tile<GemmCfg<DT, 256, 256, 2, 4, 4, FUSED, OUT_F32>>(q);
+        case 0: return launch_tile<GemmCfg<DT, 256, 256, 2, 4, 4, FUSED, OUT_F32, 2>, true>(q);
+        case 4: return launch_tile<GemmCfg<DT, 256, 256, 2, 4, 4, FUSED, OUT_F32>>(q);   // single-barrier 256x256 (A/B reference)
         case 1: return launch_tile<GemmCfg<DT, 128, 256, 1, 4, 4, FUSED, OUT_F32>>(q);
         case 2: return launch_tile<GemmCfg<DT, 64, 256, 1, 4, 4, FUSED, OUT_F32>>(q);
         case 3: return launch_tile<GemmCfg<DT, 32, 256, 1, 4, 4, FUSED, OUT_F32>>(q);

@@ -43,6 +43,9 @@ struct GemmParams {
 
 // OPT bits (tuning switches, measured in DESIGN.md): 1 = sched_group_barrier MFMA/VALU/DS interleave of the delta
 // k-step, 2 = s_setprio(1) around the MFMA clusters.
+// Ablation bits (timing experiments only -- results are WRONG with any of them set): 4 = no LDS-DMA inside the k loop,
+// 8 = no sign expansion (constant fragment), 16 = no X-fragment ds_read inside the loop, 32 = no barrier,
+// 64 = no MFMA (fragments kept alive).
 template <int DT_, int BM_, int BN_, int WAVES_M_, int WAVES_N_, int NS_, bool FUSED_, bool OUT_F32_, int OPT_ = 0>
 struct GemmCfg {
     static constexpr int DT = DT_, BM = BM_, BN = BN_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, NS = NS_, OPT = OPT_;
@@ -63,6 +66,106 @@ struct GemmCfg {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     static_assert((NS - 2) * DPW_D <= 63, "vmcnt field");
 };
+
+// Epilogue shared by the tile kernels.  acc[i][j][4q+e] = D[n = n0 + wn*WN + 32j + 8q + 4h + e][m = m0 + wm*WM + 32i + l31]
+// (swapped-operand MFMA: 4 consecutive n per register quad).  Fast path: each wave transposes its tile through a private
+// LDS buffer (rows padded by 16 B: 2-way write conflicts at most) and stores whole 128-byte row segments -- 8 rows per
+// store instruction instead of 32..64 scattered 8/16-byte pieces (the scattered form was store-ISSUE-bound: ~12 us of an
+// 18 us fixed cost at 4096^2).  Slow path (N or ldc not a multiple of 8 elements, unaligned C): direct guarded stores.
+template <class Cfg>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[Cfg::TM][Cfg::TN], char* smem, int m0, int n0,
+                                              int wm, int wn, int b, int lane, int wave) {
+    constexpr int DT = Cfg::DT, WM = Cfg::WM, WN = Cfg::WN, TM = Cfg::TM, TN = Cfg::TN;
+    constexpr int ESZ = Cfg::OUT_F32 ? 4 : 2;
+    constexpr int ROWB = WN * ESZ + 16;                 // padded LDS row
+    constexpr int IPP = (TM * 32 * ROWB * Cfg::NW <= Cfg::LDS_BYTES) ? TM : (TM >= 2 && (TM / 2) * 32 * ROWB * Cfg::NW <= Cfg::LDS_BYTES ? TM / 2 : 1);
+    constexpr bool STAGE_OK = IPP * 32 * ROWB * Cfg::NW <= Cfg::LDS_BYTES;
+    const int h = lane >> 5, l31 = lane & 31;
+    const long long c_b = (long long)b * p.sCb;
+    const bool acc_mode = !Cfg::FUSED && p.accumulate;
+    const float* al = (acc_mode) ? p.alpha + (long long)b * p.sAlb : nullptr;
+    const bool fast = STAGE_OK && (p.N % 8 == 0) && (p.sCm % 8 == 0) && (p.sCb % 8 == 0) && (((uintptr_t)p.C & 15) == 0);
+
+    // value transform shared by both paths
+    auto xform = [&](float v, int n, long long off) -> float {
+        if (acc_mode) {
+            const float cin = Cfg::OUT_F32 ? ((const float*)p.C)[off] : half_bits_to_f32<DT>(((const unsigned short*)p.C)[off]);
+            return cin + al[n / p.gsz] * v;
+        }
+        if (!Cfg::FUSED && p.round_mode == 1) return round_through_f16(v);
+        return v;
+    };
+
+    if (fast) {
+        char* buf = smem + wave * (IPP * 32 * ROWB);
+        constexpr int SEG = WN * ESZ / 16;               // 16-byte pieces per row
+        constexpr int RPI = 64 / SEG;                    // rows covered by one store instruction
+#pragma unroll
+        for (int i0 = 0; i0 < TM; i0 += IPP) {
+#pragma unroll
+            for (int ii = 0; ii < IPP; ++ii) {
+                const int i = i0 + ii;
+                const int m = m0 + wm * WM + i * 32 + l31;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int nl = j * 32 + 8 * q + 4 * h;
+                        const int n = n0 + wn * WN + nl;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc[i][j][q * 4 + e];
+                            if (acc_mode || (!Cfg::FUSED && p.round_mode == 1)) {
+                                const bool ok = (m < p.M) && (n + e < p.N);
+                                v[e] = ok ? xform(v[e], n + e, c_b + (long long)m * p.sCm + n + e) : 0.f;
+                            }
+                        }
+                        char* dst = buf + (ii * 32 + l31) * ROWB + nl * ESZ;
+                        if constexpr (Cfg::OUT_F32) {
+                            *(f32x4_t*)dst = f32x4_t{v[0], v[1], v[2], v[3]};
+                        } else {
+                            const uint32_t h0 = f32_to_half_bits<DT>(v[0]), h1 = f32_to_half_bits<DT>(v[1]);
+                            const uint32_t h2 = f32_to_half_bits<DT>(v[2]), h3 = f32_to_half_bits<DT>(v[3]);
+                            *(u32x2_t*)dst = u32x2_t{h0 | (h1 << 16), h2 | (h3 << 16)};
+                        }
+                    }
+            }
+            // this wave's rows only: no block barrier needed, just LDS write->read ordering inside the wave
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int r0 = 0; r0 < IPP * 32; r0 += RPI) {
+                const int r = r0 + lane / SEG, sg = lane % SEG;
+                const int m = m0 + wm * WM + i0 * 32 + r;
+                const int n = n0 + wn * WN + sg * (16 / ESZ);
+                const u32x4_t val = *(const u32x4_t*)(buf + r * ROWB + sg * 16);
+                if (m < p.M && n < p.N)     // N % 8 == 0 -> a 16-byte piece is entirely in or out
+                    *(u32x4_t*)(p.C + (c_b + (long long)m * p.sCm + n) * ESZ) = val;
+            }
+            if (i0 + IPP < TM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WM + i * 32 + l31;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * WN + j * 32 + 8 * q + 4 * h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e >= p.N) continue;
+                    const long long off = c_b + (long long)m * p.sCm + n + e;
+                    const float v = xform(acc[i][j][q * 4 + e], n + e, off);
+                    if constexpr (Cfg::OUT_F32) ((float*)p.C)[off] = v;
+                    else ((unsigned short*)p.C)[off] = (unsigned short)f32_to_half_bits<DT>(v);
+                }
+            }
+    }
+}
 
 template <class Cfg>
 __global__ void __launch_bounds__(Cfg::NT) delta_gemm_kernel(const GemmParams p) {
@@ -143,9 +246,10 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_kernel(const GemmParams p)
 
         int slot_c = 0, slot_i = NS - 1;
         for (int kt = 0; kt < nk; ++kt) {
-            wait_vmcnt<(NS - 2) * Cfg::DPW_D>();       // this wave's pieces of tile kt have landed
-            __builtin_amdgcn_s_barrier();              // ... everyone's have; everyone is done reading tile kt-1
-            issue(min(kt + NS - 1, nk - 1), slot_i);   // refill the slot tile kt-1 used (tail re-reads the last tile: keeps the count fixed)
+            if constexpr (!(Cfg::OPT & 4)) wait_vmcnt<(NS - 2) * Cfg::DPW_D>();   // this wave's pieces of tile kt have landed
+            if constexpr (!(Cfg::OPT & 32)) __builtin_amdgcn_s_barrier();         // ... everyone's have; everyone is done reading tile kt-1
+            if constexpr (!(Cfg::OPT & 4))
+                issue(min(kt + NS - 1, nk - 1), slot_i);   // refill the slot tile kt-1 used (tail re-reads the last tile: keeps the count fixed)
 
             const char* st = smem + slot_c * STAGE_D;
             uint32_t rlo[TN], rhi[TN];
@@ -159,14 +263,34 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_kernel(const GemmParams p)
             for (int s = 0; s < 4; ++s) {
                 u32x4_t xf[TM], sf[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) xf[i] = *(const u32x4_t*)(st + a_rd[s] + i * 4096);
+                for (int i = 0; i < TM; ++i) {
+                    if constexpr (Cfg::OPT & 16) {
+                        xf[i] = u32x4_t{one2, one2 + (uint32_t)i, one2, one2};
+                        asm volatile("" : "+v"(xf[i]));
+                    } else {
+                        xf[i] = *(const u32x4_t*)(st + a_rd[s] + i * 4096);
+                    }
+                }
 #pragma unroll
-                for (int j = 0; j < TN; ++j) sf[j] = expand_signs8(s < 2 ? rlo[j] : rhi[j], (s & 1) * 4, one2);
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (Cfg::OPT & 8) {
+                        sf[j] = u32x4_t{rlo[j], rhi[j], one2, one2};
+                        asm volatile("" : "+v"(sf[j]));
+                    } else {
+                        sf[j] = expand_signs8(s < 2 ? rlo[j] : rhi[j], (s & 1) * 4, one2);
+                    }
+                }
                 if constexpr (Cfg::OPT & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) acc[i][j] = mfma32<DT>(sf[j], xf[i], acc[i][j]);
+                    for (int i = 0; i < TM; ++i) {
+                        if constexpr (Cfg::OPT & 64) {
+                            asm volatile("" ::"v"(sf[j]), "v"(xf[i]));
+                        } else {
+                            acc[i][j] = mfma32<DT>(sf[j], xf[i], acc[i][j]);
+                        }
+                    }
                 if constexpr (Cfg::OPT & 2) __builtin_amdgcn_s_setprio(0);
             }
             if constexpr (Cfg::OPT & 1) {
@@ -248,65 +372,8 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_kernel(const GemmParams p)
     }
 
     // =========================== epilogue ===========================
-    // acc[i][j][4q+e] = D[n = n0 + wn*WN + 32j + 8q + 4h + e][m = m0 + wm*WM + 32i + l31]
-    const long long c_b = (long long)b * p.sCb;
-    const bool vec_ok = (p.N % 4 == 0) && (p.sCm % 4 == 0) && (((uintptr_t)p.C & (Cfg::OUT_F32 ? 15 : 7)) == 0) &&
-                        (p.sCb % 4 == 0);
-    const bool acc_mode = !Cfg::FUSED && p.accumulate;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * WM + i * 32 + l31;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn * WN + j * 32 + 8 * q + 4 * h;
-                if (n >= p.N) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
-                const long long off = c_b + (long long)m * p.sCm + n;
-                if (acc_mode) {
-                    const float* al = p.alpha + (long long)b * p.sAlb;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (n + e < p.N) {
-                            const float a = al[(n + e) / p.gsz];
-                            const float cin = Cfg::OUT_F32
-                                                  ? ((const float*)p.C)[off + e]
-                                                  : half_bits_to_f32<DT>(((const unsigned short*)p.C)[off + e]);
-                            v[e] = cin + a * v[e];
-                        }
-                    }
-                } else if (!Cfg::FUSED && p.round_mode == 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = round_through_f16(v[e]);
-                }
-                if constexpr (Cfg::OUT_F32) {
-                    float* cp = (float*)p.C + off;
-                    if (vec_ok) {
-                        *(f32x4_t*)cp = f32x4_t{v[0], v[1], v[2], v[3]};
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (n + e < p.N) cp[e] = v[e];
-                    }
-                } else {
-                    unsigned short* cp = (unsigned short*)p.C + off;
-                    uint32_t hb[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) hb[e] = f32_to_half_bits<DT>(v[e]);
-                    if (vec_ok) {
-                        *(u32x2_t*)cp = u32x2_t{hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16)};
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (n + e < p.N) cp[e] = (unsigned short)hb[e];
-                    }
-                }
-            }
-    }
+    __builtin_amdgcn_s_barrier();      // every wave is out of the rings: LDS is reused as the C staging buffer
+    gemm_epilogue<Cfg>(p, acc, smem, m0, n0, wm, wn, b, lane, wave);
 }
 
 }  // namespace bd

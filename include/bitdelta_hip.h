@@ -85,7 +85,8 @@ int bd_merge_delta(void* W, int64_t ldw, const int32_t* P, const float* coeff, i
                    void* stream);
 
 /* tuning / test hook: force a kernel family for bd_delta_bmm / bd_binary_linear.
- * -1 auto (default); 0..3 MFMA tile configs (256x256, 128x256, 64x256, 32x256); 100 generic edge kernel; 200 decode GEMV.
+ * -1 auto (default); 0..3 MFMA tile configs (256x256 ping-pong, 128x256, 64x256, 32x256); 4 = 256x256 single-barrier schedule;
+ * 100 generic edge kernel; 200 decode GEMV.
  * A forced variant whose preconditions fail returns BD_E_BAD_SHAPE instead of silently falling back. */
 int bd_set_gemm_variant(int variant);
 /* which family the LAST call on this thread dispatched to (same codes as above) */

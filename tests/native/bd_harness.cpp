@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../bitdelta_amd/csrc/bd_gemm_mfma.h"
+#include "../../bitdelta_amd/csrc/bd_gemm_pp.h"
 #include "../../include/bitdelta_hip.h"
 
 #define HIPCHECK(x)                                                                      \
@@ -191,8 +192,12 @@ static int run_case(const char* tag, int B, int M, int N, int K, int dt, int out
 }
 
 // ---------------- experimental configs launched directly ----------------
-template <class Cfg>
+template <class Cfg, bool PP> struct KernSel { static auto get() { return bd::delta_gemm_kernel<Cfg>; } };
+template <class Cfg> struct KernSel<Cfg, true> { static auto get() { return bd::delta_gemm_pp_kernel<Cfg>; } };
+
+template <class Cfg, bool PP = false>
 static void run_cfg(const char* name, int M, int N, int K, int iters, int nsamples) {
+    auto kern = KernSel<Cfg, PP>::get();
     Problem q{1, M, N, K, Cfg::DT == bd::DT_BF16 ? BD_BF16 : BD_F16, Cfg::OUT_F32 ? BD_F32 : (Cfg::DT == bd::DT_BF16 ? BD_BF16 : BD_F16),
               Cfg::FUSED ? 1 : 0, 1};
     make_problem(q);
@@ -202,9 +207,9 @@ static void run_cfg(const char* name, int M, int N, int K, int iters, int nsampl
     p.tiles_m = (M + Cfg::BM - 1) / Cfg::BM; p.tiles_n = (N + Cfg::BN - 1) / Cfg::BN;
     p.sAb = (long long)M * K; p.sPb = 0; p.sCb = (long long)M * N; p.sAm = K; p.sCm = N; p.ldw = K; p.sAlb = 0; p.gsz = N;
     p.round_mode = 0; p.accumulate = 0;
-    HIPCHECK(hipFuncSetAttribute((const void*)bd::delta_gemm_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+    HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
     dim3 grid(p.tiles_m * p.tiles_n, 1);
-    auto launch = [&] { hipLaunchKernelGGL((bd::delta_gemm_kernel<Cfg>), grid, dim3(Cfg::NT), Cfg::LDS_BYTES, 0, p); };
+    auto launch = [&] { hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, 0, p); };
     HIPCHECK(hipMemset(q.dC, 0xFF, q.c_elems() * 4));
     launch();
     hipError_t herr = hipDeviceSynchronize();
@@ -212,7 +217,7 @@ static void run_cfg(const char* name, int M, int N, int K, int iters, int nsampl
     if (herr == hipSuccess) {
         std::vector<uint8_t> hC(q.c_elems() * (Cfg::OUT_F32 ? 4 : 2));
         HIPCHECK(hipMemcpy(hC.data(), q.dC, hC.size(), hipMemcpyDeviceToHost));
-        bad = check_output(q, hC.data(), nsamples, &max_err, &max_ulp);
+        bad = nsamples > 0 ? check_output(q, hC.data(), nsamples, &max_err, &max_ulp) : 0;
         ms = time_ms(launch, 5, iters);
     }
     const double flops = (Cfg::FUSED ? 4.0 : 2.0) * M * (double)N * K;
@@ -245,6 +250,43 @@ static void sweep(int M, int N, int K, int iters) {
     CFG("128x256_1x4_fused", DT_BF16, 128, 256, 1, 4, 4, true, false, 0);
 }
 
+#define CFGPP(name, ...) run_cfg<GemmCfg<__VA_ARGS__>, true>(name, M, N, K, iters, 4096)
+static void sweep_pp(int M, int N, int K, int iters) {
+    if (K < 256) {   // fixed-cost probe: launch + prologue + epilogue with (almost) no main loop
+        CFGPP("pp_256x256_ns4", DT_BF16, 256, 256, 2, 4, 4, false, false, 0);
+        CFGPP("pp_256x256_ns3_f32out", DT_BF16, 256, 256, 2, 4, 3, false, true, 0);
+        return;
+    }
+    CFG("v1_256x256_2x4_ns4", DT_BF16, 256, 256, 2, 4, 4, false, false, 0);
+    CFGPP("pp_256x256_ns3", DT_BF16, 256, 256, 2, 4, 3, false, false, 0);
+    CFGPP("pp_256x256_ns4", DT_BF16, 256, 256, 2, 4, 4, false, false, 0);
+    CFGPP("pp_ns4_dma_in_load", DT_BF16, 256, 256, 2, 4, 4, false, false, 1);
+    CFGPP("pp_ns4_noprio", DT_BF16, 256, 256, 2, 4, 4, false, false, 2);
+    CFGPP("pp_ns4_dma_in_load_noprio", DT_BF16, 256, 256, 2, 4, 4, false, false, 3);
+    CFGPP("pp_256x256_ns3_f16", DT_F16, 256, 256, 2, 4, 3, false, false, 0);
+    CFGPP("pp_256x256_ns3_f32out", DT_BF16, 256, 256, 2, 4, 3, false, true, 0);
+    CFG("v1_256x256_fused", DT_BF16, 256, 256, 2, 4, 4, true, false, 0);
+    CFGPP("pp_256x256_ns3_fused", DT_BF16, 256, 256, 2, 4, 3, true, false, 0);
+    CFGPP("pp_256x256_ns4_fused", DT_BF16, 256, 256, 2, 4, 4, true, false, 0);
+}
+
+static void ablate(int M, int N, int K, int iters) {
+    // timing only: outputs are wrong by construction (nsamples = 0 skips the check)
+#define ABL(name, opt) run_cfg<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, opt>>(name, M, N, K, iters, 0)
+    ABL("base", 0);
+    ABL("no_dma", 4);
+    ABL("no_expand", 8);
+    ABL("no_dsread", 16);
+    ABL("no_barrier_no_dma", 36);
+    ABL("no_mfma", 64);
+    ABL("no_dma_no_expand", 12);
+    ABL("no_dma_no_dsread", 20);
+    ABL("no_dma_no_expand_no_dsread", 28);
+    ABL("mfma_only", 60);
+    ABL("no_mfma_no_dma", 68);
+#undef ABL
+}
+
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "check";
     hipDeviceProp_t prop;
@@ -257,7 +299,7 @@ int main(int argc, char** argv) {
         // every kernel family, both dtypes, delta-only and fused, broadcast and per-tenant masks
         for (int dt : {BD_BF16, BD_F16})
             for (int fused : {0, 1}) {
-                for (int v : {0, 1, 2, 3, 100})
+                for (int v : {0, 1, 2, 3, 4, 100})
                     fails += run_case("tile", 2, 200, 520, 256, dt, BD_F32, fused, 2, v, 0, S);
                 fails += run_case("tile_bcast", 3, 130, 300, 128, dt, dt, fused, 1, 0, 0, S);
                 fails += run_case("auto_big", 1, 512, 768, 1024, dt, dt, fused, 1, -1, 0, S);
@@ -287,6 +329,24 @@ int main(int argc, char** argv) {
         fails += run_case("decode_fused_down", 6, 1, 4096, 14336, BD_F16, BD_F16, 1, 6, -1, 50, 2048);
         fails += run_case("decode_fused_kv", 6, 1, 1024, 4096, BD_F16, BD_F16, 1, 6, -1, 50, 2048);
         fails += run_case("prefill64_t6", 6, 64, 4096, 4096, BD_F16, BD_F16, 1, 6, -1, it, 2048);
+    } else if (mode == "pp") {
+        const int M = argc > 2 ? atoi(argv[2]) : 4096;
+        sweep_pp(M, 4096, argc > 3 ? atoi(argv[3]) : 4096, 20);
+    } else if (mode == "ablate") {
+        ablate(4096, 4096, 4096, 20);
+    } else if (mode == "fixed") {
+        // fixed-cost anatomy at K = 64 (one k-tile): full / no C stores / empty kernel, timed by rocprofv3 kernel-trace
+        run_cfg<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 2>, true>("full", 4096, 4096, 64, 10, 0);
+        run_cfg<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 2 + 128>, true>("no_store", 4096, 4096, 64, 10, 0);
+        run_cfg<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 2 + 256>, true>("empty", 4096, 4096, 64, 10, 0);
+        run_cfg<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 2 + 128>, true>("no_store_k4096", 4096, 4096, 4096, 10, 0);
+    } else if (mode == "one_pp") {
+        const int M = argc > 2 ? atoi(argv[2]) : 4096, K = argc > 3 ? atoi(argv[3]) : 4096;
+        run_cfg<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 2>, true>("pp_ns4_noprio", M, 4096, K, 10, 256);
+    } else if (mode == "one") {
+        // a single configuration, a few launches: for rocprofv3 counter passes
+        const int M = argc > 2 ? atoi(argv[2]) : 4096;
+        run_cfg<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 0>>("256x256_2x4_ns4", M, 4096, 4096, 10, 256);
     } else if (mode == "sweep") {
         const int M = argc > 2 ? atoi(argv[2]) : 4096;
         sweep(M, 4096, 4096, 20);

@@ -1,0 +1,119 @@
+"""CPU-only checks of the boundary: the C-ABI library loads and exports every symbol include/bitdelta_hip.h declares,
+the Python mirror keeps the reference's names / signatures / error behaviour, the product never touches oracle/,
+and nothing computes without a GPU (no CPU fallback)."""
+import ast
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "bitdelta_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return re.findall(r"\b(bd_[a-z0-9_]+)\s*\(", txt)
+
+
+def test_library_exports_every_declared_symbol():
+    from bitdelta_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    L = _lib.lib()
+    names = header_functions()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/bitdelta_hip.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in bitdelta_amd/_lib.py"
+    assert set(_lib.SIGNATURES) == set(names)
+    assert L.bd_version() >= 1
+    assert L.bd_error_string(0) == b"ok" and b"divisible" in L.bd_error_string(-1)
+    # argument validation happens before any device work, so these are safe without a GPU
+    assert L.bd_pack(None, 1, 33, 4, 0, 4, 1, None, 32, None) == -1
+    assert L.bd_pack(None, 1, 24, 4, 0, 4, 1, None, 12, None) == -2
+    assert L.bd_pack(None, 0, 64, 4, 0, 4, 1, None, 32, None) == 0           # empty batch is a no-op
+    assert L.bd_gemm_workspace_bytes(6, 1, 4096, 4096) > 0 and L.bd_gemm_workspace_bytes(1, 2048, 4096, 4096) == 0
+    assert L.bd_binarize_workspace_bytes(4096, 4096) == 64 * 16 * 4
+
+
+def test_python_surface_matches_reference_names_and_signatures():
+    import bitdelta_amd.binary_gemm_kernel as k
+    import bitdelta_amd.diff as d
+    import bitdelta_amd.serving as s
+
+    def params(fn):
+        return [(p.name, p.default) for p in inspect.signature(fn).parameters.values()
+                if p.kind is not inspect.Parameter.KEYWORD_ONLY]
+    E = inspect.Parameter.empty
+    # reference: bitdelta/binary_gemm_kernel.py:6, :34, :153, :297
+    assert params(k.pack) == [("x", E), ("n_bits", 32)]
+    assert params(k.unpack) == [("x", E), ("n_bits", 32)]
+    assert params(k.binary_matmul) == [("a", E), ("b", E), ("n_bits", 32), ("activation", "")]
+    assert params(k.binary_bmm) == [("a", E), ("b", E), ("n_bits", 32), ("activation", "")]
+    # reference: bitdelta/diff.py:9, :41, :66, :81, :108
+    assert params(d.BinaryDiff.__init__)[1:] == [("base", E), ("finetune", E)]
+    assert params(d.compress_diff) == [("base_model", E), ("finetuned_model", E), ("finetuned_compressed_model", E)]
+    assert params(d.save_diff) == [("finetuned_compressed_model", E), ("save_dir", E)]
+    assert params(d.load_diff) == [("model", E), ("diff_dir", E)]
+    assert params(d.save_full_model) == [("base_model_name", E), ("finetuned_model_name", E), ("diff_dir", E),
+                                         ("save_dir", E), ("device", E)]
+    # reference: demo/demo_backend.py:62, :82, :107, :156, :170
+    assert params(s.DiffCompressModule.__init__)[1:] == [("module", E), ("mask_list", E), ("coeff_list", E)]
+    assert params(s.DataParallelModule.__init__)[1:] == [("module", E), ("weight_list", E)]
+    assert params(s.register_diff_compress) == [("model", E), ("checkpoint_list", E)]
+    for name in ("pack", "unpack", "binary_bmm"):                # `from bitdelta.diff import ...` re-exports these
+        assert hasattr(d, name)
+
+
+def test_reference_asserts_fire_before_any_device_work():
+    import bitdelta_amd as bd
+    a = torch.zeros(2, 4, 64, dtype=torch.float16)
+    b = torch.zeros(2, 2, 8, dtype=torch.int32)
+    with pytest.raises(AssertionError, match="3D"):
+        bd.binary_bmm(a[0], b)
+    with pytest.raises(AssertionError, match="Incompatible dimensions"):
+        bd.binary_bmm(a, b[:, :1])
+    with pytest.raises(AssertionError, match="batch"):
+        bd.binary_bmm(a, b[:1])
+    with pytest.raises(AssertionError, match="contiguous"):
+        bd.binary_bmm(a.transpose(1, 2).contiguous().transpose(1, 2), b)
+    with pytest.raises(AssertionError, match="divisible"):
+        bd.pack(torch.zeros(33, 4, dtype=torch.bool))
+    with pytest.raises(AssertionError, match="Incompatible"):
+        bd.binary_matmul(a[0], b[0, :1])
+
+
+def test_no_cpu_fallback():
+    """Valid CPU inputs must raise, not compute: the product path exists on the GPU only."""
+    import bitdelta_amd as bd
+    from bitdelta_amd._lib import BitDeltaHipError
+    with pytest.raises(BitDeltaHipError):
+        bd.pack(torch.zeros(32, 4, dtype=torch.bool))
+    with pytest.raises(BitDeltaHipError):
+        bd.unpack(torch.zeros(1, 4, dtype=torch.int32))
+    with pytest.raises(BitDeltaHipError):
+        bd.binary_bmm(torch.zeros(1, 4, 64, dtype=torch.float16), torch.zeros(1, 2, 8, dtype=torch.int32))
+    with pytest.raises(BitDeltaHipError):
+        bd.BinaryDiff(torch.zeros(8, 32, dtype=torch.bfloat16), torch.zeros(8, 32, dtype=torch.bfloat16))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "bitdelta_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            path = os.path.join(dirpath, f)
+            if f.endswith(".py"):
+                tree = ast.parse(open(path).read())
+                for node in ast.walk(tree):
+                    mods = []
+                    if isinstance(node, ast.Import):
+                        mods = [a.name for a in node.names]
+                    elif isinstance(node, ast.ImportFrom):
+                        mods = [node.module or ""]
+                    assert not any(m.split(".")[0] == "oracle" for m in mods), path
+            if f.endswith((".h", ".hip", ".cpp", ".py")):
+                assert "bd_oracle" not in open(path, errors="ignore").read(), path

@@ -1,0 +1,87 @@
+"""world_size-2 gloo tests (CPU) of the N>1 path: tenant partitioning / routing, mask sharding for tensor parallel
+(N-split needs no exchange, K-split partial sums all-reduce to the full result) and the bench timing contract."""
+import os
+import socket
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from bitdelta_amd import dist as bdd
+    from oracle import bd_oracle as o
+    r, w, _ = bdd.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(0)                                   # same problem on every rank
+    M, K, N = 5, 128, 64
+    x = torch.randn(1, M, K).bfloat16()
+    p = torch.randint(-2 ** 31, 2 ** 31 - 1, (1, K // 32, N), dtype=torch.int64).to(torch.int32)
+    full = o.delta_bmm(x, p, out_dtype=torch.float32, round_mode=0)
+    # K-split (row-parallel): partial sums + all-reduce == full
+    pk = bdd.shard_mask_rows(p, rank, world)
+    xk = x[..., rank * (K // world):(rank + 1) * (K // world)].contiguous()
+    part = o.delta_bmm(xk, pk, out_dtype=torch.float32, round_mode=0)
+    tot = bdd.all_reduce_partial(part.clone())
+    ok_k = torch.allclose(tot, full, rtol=1e-6, atol=1e-5)
+    # N-split (column-parallel): slices concatenate to the full result, no exchange
+    pn = bdd.shard_mask_columns(p, rank, world)
+    coln = o.delta_bmm(x, pn, out_dtype=torch.float32, round_mode=0)
+    gathered = [torch.empty_like(coln) for _ in range(world)]
+    dist.all_gather(gathered, coln)
+    ok_n = torch.equal(torch.cat(gathered, dim=-1), full)
+    # tenant partition: disjoint cover, routing consistent
+    mine = bdd.tenants_for_rank(7, rank, world)
+    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([len(mine)]))
+    ok_t = sum(int(s) for s in sizes) == 7 and all(bdd.route(t, 7, world) == rank for t in mine)
+    # timing contract: MAX over ranks
+    import time
+    dt = bdd.timed_region(lambda: time.sleep(0.02 * (rank + 1)), steps=2)
+    ok_time = dt >= 0.02 * world * 2 * 0.95
+    q.put((rank, ok_k, ok_n, ok_t, ok_time))
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_k, ok_n, ok_t, ok_time in res:
+        assert ok_k and ok_n and ok_t and ok_time, (rank, ok_k, ok_n, ok_t, ok_time)
+
+
+def test_partition_helpers_single_process():
+    from bitdelta_amd import dist as bdd
+    for n in (1, 6, 7, 32, 33):
+        for world in (1, 2, 4, 8):
+            cover = []
+            for r in range(world):
+                mine = bdd.tenants_for_rank(n, r, world)
+                cover += mine
+                assert all(bdd.route(t, n, world) == r for t in mine)
+            assert cover == list(range(n))
+    m = torch.arange(8 * 6, dtype=torch.int32).reshape(8, 6)
+    assert torch.equal(torch.cat([bdd.shard_mask_rows(m, r, 4) for r in range(4)], 0), m)
+    assert torch.equal(torch.cat([bdd.shard_mask_columns(m, r, 2) for r in range(2)], 1), m)

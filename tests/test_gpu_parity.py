@@ -1,0 +1,376 @@
+"""GPU parity tests (run on the MI355X box: `pytest -m gpu`).  Every check goes Python surface -> C ABI -> HIP kernel and is
+compared with the CPU oracle (oracle/bd_oracle.c, pinned to the reference by tests/test_oracle_golden.py) and/or with
+the golden vectors the reference itself produced (tests/golden/).
+
+Tolerances (BASELINE.json north star: 1e-3 relative on 16-bit, bit-exact on the sign pack/unpack):
+  * pack / unpack / binarize mask / merge:  bit-exact.
+  * fp32-output mode of every GEMM family:  rel-Frobenius and mean-rel <= 1e-5 (fp32 accumulation-order noise only).
+  * fp16 outputs: <= 1e-3 rel-Frobenius vs the oracle, and within 1 fp16 ulp per element.
+  * bf16 outputs: every element within 1 bf16 ulp of the rounded oracle (a flat 1e-3 is below bf16's own rounding
+    floor), >= 99 % bit-equal.
+"""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def bd():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    import bitdelta_amd
+    from bitdelta_amd import _lib
+    _lib.lib()          # fails loudly if the HIP library is missing: there is no fallback
+    return bitdelta_amd
+
+
+def dev(t):
+    return t.cuda()
+
+
+def ulp_diff(a, b):
+    """element-wise distance in units of the 16-bit format's ulp (via the monotonic integer mapping)."""
+    def key(t):
+        i = t.view(torch.int16).int()
+        return torch.where(i < 0, -(i & 0x7fff), i)
+    return (key(a) - key(b)).abs()
+
+
+def relerr(a, ref):
+    a, ref = a.double(), ref.double()
+    return ((a - ref).norm() / ref.norm()).item(), ((a - ref).abs().mean() / ref.abs().mean()).item()
+
+
+def rand_problem(B, M, K, N, dtype, tenants, seed=0, wscale=0.02):
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randn(B, M, K, generator=g).to(dtype)
+    p = torch.randint(-2 ** 31, 2 ** 31 - 1, (tenants, K // 32, N), generator=g, dtype=torch.int64).to(torch.int32)
+    w = (torch.randn(N, K, generator=g) * wscale).to(dtype)
+    alpha = (torch.rand(tenants, 1, generator=g) * 2e-4 + 3e-4).float()
+    return a, p, w, alpha
+
+
+# ------------------------------------------------------------------ pack / unpack
+def test_pack_unpack_golden_bit_exact(bd, golden):
+    for case in golden["g1_pack32"]:
+        p = bd.pack(dev(case["bits"]))
+        assert p.dtype == torch.int32 and torch.equal(p.cpu(), case["packed"])
+        assert torch.equal(bd.unpack(dev(case["packed"])).cpu(), case["bits"])
+    for nb, case in golden["g1_pack_nbits"].items():
+        p = bd.pack(dev(case["bits"]), n_bits=nb)
+        assert p.dtype == case["packed"].dtype and torch.equal(p.cpu(), case["packed"])
+        assert torch.equal(bd.unpack(dev(case["packed"]), n_bits=nb).cpu(), case["bits"])
+    t = golden["g1_pack_transposed"]
+    assert torch.equal(bd.pack(dev(t["bits_NK"]).T).cpu(), t["packed"])
+
+
+def test_pack_errors(bd):
+    with pytest.raises(AssertionError):
+        bd.pack(torch.zeros(33, 4, dtype=torch.bool, device="cuda"))
+    with pytest.raises(UnboundLocalError):
+        bd.pack(torch.zeros(24, 4, dtype=torch.bool, device="cuda"), n_bits=12)
+    e = bd.pack(torch.zeros(0, 5, dtype=torch.bool, device="cuda"))
+    assert e.shape == (0, 5)
+    e = bd.unpack(torch.zeros(2, 0, dtype=torch.int32, device="cuda"))
+    assert e.shape == (64, 0)
+
+
+def test_pack_unpack_full_size_roundtrip(bd, oracle):
+    # Llama-2-7B gate_proj sized mask [4096 -> 11008]: round trip + oracle spot rows + both layouts
+    torch.manual_seed(1)
+    bits = torch.rand(4096, 11008, device="cuda") > 0.5
+    p = bd.pack(bits)
+    assert p.shape == (128, 11008)
+    assert torch.equal(bd.unpack(p), bits)
+    assert torch.equal(p[:2].cpu(), oracle.pack(bits[:64].cpu()))
+    pt = bd.pack(bits.T.contiguous().T)          # k-major view, as BinaryDiff.__init__ packs
+    assert torch.equal(pt, p)
+    allones = bd.pack(torch.ones(64, 7, dtype=torch.bool, device="cuda"))
+    assert (allones == -1).all()
+
+
+# ------------------------------------------------------------------ BinaryDiff.__init__
+def test_binarize_golden(bd, golden, oracle):
+    from bitdelta_amd.diff import binarize
+    for key in ("g2_binarydiff", "g2_binarydiff_fp16"):
+        g = golden[key]
+        mask, coeff = binarize(dev(g["base"]), dev(g["fine"]))
+        assert torch.equal(mask.cpu(), g["mask"])
+        assert abs(coeff.item() - g["coeff"].item()) <= 2e-7 * g["coeff"].item()
+    # ragged edges + full size vs oracle / sampled
+    torch.manual_seed(2)
+    base = (torch.randn(200, 96) * 0.02).bfloat16()
+    fine = (base.float() + torch.randn(200, 96) * 5e-4).bfloat16()
+    fine[7, 5] = base[7, 5]
+    m, c = binarize(dev(base), dev(fine))
+    mo, co = oracle.binarize(base, fine)
+    assert torch.equal(m.cpu(), mo) and abs(c.item() - co.item()) <= 2e-7 * co.item()
+
+
+def test_binarydiff_module_surface(bd, golden):
+    g = golden["g2_binarydiff"]
+    m = bd.BinaryDiff(dev(g["base"]), dev(g["fine"]))
+    assert list(m.state_dict().keys()) == g["state_keys"] == ["coeff", "mask", "base"]
+    assert tuple(m.base.shape) == g["base_buf_shape"] and tuple(m.base.stride()) == g["base_buf_stride"]
+    assert isinstance(m.coeff, torch.nn.Parameter) and m.coeff.requires_grad and m.coeff.dtype == torch.float32
+    assert m.coeff.dim() == 0 and m.mask.dtype == torch.int32
+    assert torch.equal(m.mask.cpu(), g["mask"])
+
+
+# ------------------------------------------------------------------ delta GEMM
+def test_binary_bmm_golden_fp16(bd, golden):
+    for case in golden["g3_bmm_fp16"]:
+        c = bd.binary_bmm(dev(case["a"]), dev(case["packed"]))
+        assert c.dtype == torch.float16 and not c.requires_grad
+        d = ulp_diff(c.cpu(), case["c"])
+        assert d.max().item() <= 1
+        assert (d == 0).float().mean().item() >= 0.999
+    g = golden["g3_mm_fp16"]
+    c = bd.binary_matmul(dev(g["a"]), dev(g["packed"]))
+    assert ulp_diff(c.cpu(), g["c"]).max().item() <= 1
+    g = golden["g3_bmm_fp16_big"]     # fp16 epilogue overflow -> inf, like the reference
+    c = bd.binary_bmm(dev(g["a"]), dev(g["packed"]))
+    assert torch.equal(torch.isinf(c.cpu()), torch.isinf(g["c"]))
+    fin = ~torch.isinf(g["c"])
+    assert ulp_diff(c.cpu()[fin], g["c"][fin]).max().item() <= 1
+
+
+def test_binary_bmm_asserts(bd):
+    a = torch.zeros(2, 4, 64, dtype=torch.float16, device="cuda")
+    b = torch.zeros(2, 2, 8, dtype=torch.int32, device="cuda")
+    with pytest.raises(AssertionError):
+        bd.binary_bmm(a[0], b)                       # A must be 3D
+    with pytest.raises(AssertionError):
+        bd.binary_bmm(a, b[:, :1])                   # incompatible dimensions
+    with pytest.raises(AssertionError):
+        bd.binary_bmm(a, b[:1])                      # batch mismatch
+    with pytest.raises(AssertionError):
+        bd.binary_bmm(a.transpose(1, 2).contiguous().transpose(1, 2), b)   # A not contiguous
+    out = bd.binary_bmm(a, b, activation="leaky_relu")   # accepted and ignored, like the reference
+    assert out.shape == (2, 4, 8)
+
+
+SHAPES = [
+    # B, M, K, N, tenants, forced variant (None = auto)
+    (1, 1, 64, 32, 1, None), (2, 16, 64, 32, 2, None), (3, 17, 96, 40, 3, None),      # golden-sized / generic (K=96)
+    (16, 128, 512, 1024, 16, None),                                                    # notebook check shape (ipynb:519-531)
+    (1, 512, 512, 512, 1, None),                                                       # notebook 2-D check (ipynb:281-292)
+    (2, 200, 256, 520, 2, 0), (2, 200, 256, 520, 2, 1), (2, 200, 256, 520, 2, 2), (2, 200, 256, 520, 2, 3),
+    (2, 200, 256, 520, 2, 4), (2, 200, 256, 520, 2, 100),
+    (3, 130, 128, 300, 1, 0),                                                          # broadcast mask
+    (1, 70, 64, 77, 1, None),                                                          # odd N
+    (6, 1, 1024, 1000, 6, None), (3, 2, 512, 512, 3, None), (16, 1, 2048, 256, 1, None), (1, 1, 4096, 4096, 1, None),  # decode
+    (6, 64, 1024, 1024, 6, None),                                                      # demo prefill
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_delta_bmm_vs_oracle(bd, oracle, dtype, shape):
+    from bitdelta_amd import _lib
+    B, M, K, N, T, variant = shape
+    a, p, _, _ = rand_problem(B, M, K, N, dtype, T, seed=(B * 131 + M * 17 + K * 7 + N * 3 + T) & 0xffff)
+    L = _lib.lib()
+    L.bd_set_gemm_variant(-1 if variant is None else variant)
+    try:
+        c32 = bd.delta_bmm(dev(a), dev(p), out_dtype=torch.float32, round_mode=0)
+        c16 = bd.delta_bmm(dev(a), dev(p), round_mode=0)
+        c16r = bd.delta_bmm(dev(a), dev(p), round_mode=1)
+    finally:
+        L.bd_set_gemm_variant(-1)
+    ref32 = oracle.delta_bmm(a, p, out_dtype=torch.float32, round_mode=0)
+    fro, mrel = relerr(c32.cpu(), ref32)
+    assert fro <= 1e-5 and mrel <= 1e-5, (fro, mrel)
+    for got, mode in ((c16, 0), (c16r, 1)):
+        ref = oracle.delta_bmm(a, p, round_mode=mode)
+        d = ulp_diff(got.cpu(), ref)
+        assert d.max().item() <= 1, d.max().item()
+        assert (d == 0).float().mean().item() >= 0.99
+        if dtype == torch.float16:
+            assert relerr(got.cpu(), ref32)[0] <= 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_binary_linear_vs_oracle(bd, oracle, dtype, shape):
+    from bitdelta_amd import _lib
+    B, M, K, N, T, variant = shape
+    a, p, w, alpha = rand_problem(B, M, K, N, dtype, T, seed=(B * 131 + M * 17 + K * 7 + N * 3 + T + 7) & 0xffff)
+    L = _lib.lib()
+    L.bd_set_gemm_variant(-1 if variant is None else variant)
+    try:
+        y32 = bd.binary_linear(dev(a), dev(w), dev(p), dev(alpha), out_dtype=torch.float32)
+        y16 = bd.binary_linear(dev(a), dev(w), dev(p), dev(alpha))
+    finally:
+        L.bd_set_gemm_variant(-1)
+    ref32 = oracle.binary_linear(a, w, p, alpha, out_dtype=torch.float32, round_mode=0)
+    fro, mrel = relerr(y32.cpu(), ref32)
+    assert fro <= 1e-5 and mrel <= 2e-5, (fro, mrel)
+    ref16 = ref32.to(dtype)
+    d = ulp_diff(y16.cpu(), ref16)
+    assert d.max().item() <= 1
+    assert (d == 0).float().mean().item() >= 0.99
+    fro16 = relerr(y16.cpu(), ref32)[0]
+    assert fro16 <= (1e-3 if dtype == torch.float16 else 3e-3)
+    # not worse than the reference's own multi-rounding chain (SURVEY.md 7b iv)
+    ref_chain = oracle.binary_linear(a, w, p, alpha, round_mode=1)
+    assert fro16 <= relerr(ref_chain, ref32)[0] * 1.05 + 1e-7
+
+
+def test_delta_bmm_alpha_accumulate_and_groups(bd, oracle):
+    a, p, w, _ = rand_problem(2, 150, 256, 512, torch.bfloat16, 2, seed=11)
+    alpha = torch.tensor([[3e-4, 4e-4, 5e-4, 6e-4], [1e-3, 2e-3, 3e-3, 4e-3]])
+    base = (a.float() @ w.float().T).bfloat16()
+    out = dev(base.clone())
+    bd.delta_bmm(dev(a), dev(p), out=out, alpha=dev(alpha), accumulate=True, groups=4)
+    ref = oracle.delta_bmm(a, p, out_dtype=torch.float32, round_mode=0)
+    scale = alpha.repeat_interleave(128, dim=1)[:, None, :]
+    want = (base.float() + scale * ref).bfloat16()
+    assert ulp_diff(out.cpu(), want).max().item() <= 1
+    y = bd.binary_linear(dev(a), dev(w), dev(p), dev(alpha), groups=4, out_dtype=torch.float32)
+    yo = oracle.binary_linear(a, w, p, alpha, G=4, out_dtype=torch.float32)
+    assert relerr(y.cpu(), yo)[0] <= 1e-5
+    z = bd.delta_bmm(dev(a), dev(p), alpha=dev(alpha), groups=4, out_dtype=torch.float32)
+    assert relerr(z.cpu(), scale * ref)[0] <= 1e-5
+
+
+# ------------------------------------------------------------------ module forward / multi-tenant
+def test_binarydiff_forward_golden(bd, golden):
+    for tag in ("bf16", "fp16"):
+        g = golden[f"g5_forward_{tag}"]
+        mod = bd.BinaryDiff(dev(g["base"]), dev(g["fine"]))
+        assert torch.equal(mod.mask.cpu(), g["mask"])
+        with torch.no_grad():
+            y = mod(dev(g["x"]))
+        assert y.dtype == g["y"].dtype and y.shape == g["y"].shape
+        assert ulp_diff(y.cpu(), g["y"]).max().item() <= 2       # reference output carries 4 roundings, ours 1
+        assert relerr(y.cpu(), g["y"].float())[0] <= (6e-3 if tag == "bf16" else 1e-3)
+        # training form (grad enabled): same composition as the reference, grads as the reference defines them
+        mod.coeff.grad = None
+        xg = dev(g["x"]).clone().requires_grad_(True)
+        yt = mod(xg)
+        assert ulp_diff(yt.detach().cpu(), g["y"]).max().item() <= 1
+        yt.float().sum().backward()
+        assert mod.coeff.grad is not None and xg.grad is not None
+        wsum = g["base"].float().sum(0)                          # d/dx flows through `x @ base` only
+        assert torch.allclose(xg.grad[0, 0].float().cpu(), wsum, rtol=2e-2, atol=1e-3)
+
+
+def test_diffcompress_module_golden(bd, golden):
+    g = golden["g6_multitenant_fp16"]
+    lin = torch.nn.Linear(g["w"].shape[1], g["w"].shape[0], bias=False, dtype=torch.float16, device="cuda")
+    with torch.no_grad():
+        lin.weight.copy_(dev(g["w"]))
+    mod = bd.DiffCompressModule(lin, dev(g["masks"]), dev(g["coeffs"]))
+    with torch.no_grad():
+        y = mod(dev(g["h"]))
+    assert y.shape == g["y"].shape and y.dtype == torch.float16
+    assert ulp_diff(y.cpu(), g["y"]).max().item() <= 2
+    assert relerr(y.cpu(), g["y"].float())[0] <= 1e-3
+
+
+# ------------------------------------------------------------------ merge / diff.pt format
+def test_merge_delta_golden_bit_exact(bd, golden):
+    from bitdelta_amd.diff import merge_delta_
+    for key in ("g7_merge_fp16", "g7_merge_bf16"):
+        g = golden[key]
+        w = merge_delta_(dev(g["w"]).clone(), dev(g["mask"]), dev(g["coeff"]))
+        assert torch.equal(w.cpu().view(torch.int16), g["w_merged"].view(torch.int16))
+
+
+def test_merge_full_size_vs_oracle_rows(bd, oracle):
+    from bitdelta_amd.diff import merge_delta_
+    torch.manual_seed(3)
+    w = (torch.randn(1000, 4096) * 0.02).half()
+    mask = torch.randint(-2 ** 31, 2 ** 31 - 1, (128, 1000), dtype=torch.int64).to(torch.int32)
+    got = merge_delta_(dev(w).clone(), dev(mask), torch.tensor(4.2e-4, device="cuda"))
+    want = oracle.merge_delta(w.clone(), mask, 4.2e-4)
+    assert torch.equal(got.cpu().view(torch.int16), want.view(torch.int16))
+
+
+def test_diff_pt_format_and_load_diff(bd, tmp_path):
+    transformers = pytest.importorskip("transformers")
+    import copy
+    gm = torch.load(os.path.join(GOLDEN, "tiny_llama_merged.pt"), weights_only=False)
+    ref_diff = torch.load(os.path.join(GOLDEN, "tiny_llama_diff.pt"), weights_only=False)
+    cfg = transformers.LlamaConfig(**{k: v for k, v in gm["config"].items()
+                                      if k in ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers",
+                                               "num_attention_heads", "num_key_value_heads", "max_position_embeddings")})
+    base_m = transformers.LlamaForCausalLM(cfg).bfloat16()
+    base_m.load_state_dict(gm["base_state"])
+    fine_m = transformers.LlamaForCausalLM(cfg).bfloat16()
+    fine_m.load_state_dict(gm["fine_state"])
+    base_m, fine_m = base_m.cuda(), fine_m.cuda()
+    comp = copy.deepcopy(fine_m)
+    bd.compress_diff(base_m, fine_m, comp)
+    path = str(tmp_path / "diff.pt")
+    bd.save_diff(comp, path)
+    ours = torch.load(path, weights_only=False)
+    # same keys in the same order, same python types / dtypes / shapes, identical masks and (fp32) coeffs
+    assert list(ours.keys()) == gm["diff_keys"]
+    for k, v in ours.items():
+        assert (type(v).__name__, str(v.dtype), tuple(v.shape)) == gm["diff_types"][k], k
+        if k.endswith(".mask"):
+            assert torch.equal(v, ref_diff[k]), k
+        elif k.endswith(".coeff"):
+            assert abs(v.item() - ref_diff[k].item()) <= 2e-7 * ref_diff[k].item(), k
+        else:
+            assert torch.equal(v, ref_diff[k]), k
+    # our load_diff on the REFERENCE-written file reproduces the reference's merged fp16 weights bit for bit
+    eval_m = copy.deepcopy(base_m).half()
+    bd.load_diff(eval_m, os.path.join(GOLDEN, "tiny_llama_diff.pt"))
+    after = eval_m.state_dict()
+    for k, v in gm["after"].items():
+        assert torch.equal(after[k].cpu().view(torch.int16), v.view(torch.int16)), k
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE configs)
+def test_full_size_linearity_and_sign_flip(bd):
+    # 4096x4096 layer, M = 4096 rows: size-independent properties instead of an O(MNK) CPU reference
+    torch.manual_seed(5)
+    K = N = 4096
+    M = 4096
+    x1 = torch.randn(1, M, K, device="cuda").bfloat16()
+    x2 = torch.randn(1, M, K, device="cuda").bfloat16()
+    p = torch.randint(-2 ** 31, 2 ** 31 - 1, (1, K // 32, N), device="cuda", dtype=torch.int64).to(torch.int32)
+    f = lambda x, pp: bd.delta_bmm(x, pp, out_dtype=torch.float32, round_mode=0)
+    y1, y2 = f(x1, p), f(x2, p)
+    ys = f((x1.float() * 2).bfloat16(), p)                           # exact scaling by 2
+    assert torch.equal(ys, y1 * 2)
+    yn = f(x1, ~p)                                                   # flipping every sign bit negates the result
+    assert torch.equal(yn, -y1)
+    xs = (x1.float() + x2.float())
+    exact = xs.bfloat16().float() == xs                              # rows where the bf16 sum is exact
+    rows = exact.all(dim=-1)[0]
+    if rows.any():
+        y12 = f(xs.bfloat16(), p)
+        assert torch.allclose(y12[0, rows], (y1 + y2)[0, rows], rtol=1e-5, atol=1e-2)
+    # a column whose signs are all +1 reproduces the row sums
+    p1 = p.clone()
+    p1[0, :, 123] = -1
+    ysum = f(x1, p1)[0, :, 123]
+    assert torch.allclose(ysum, x1[0].float().sum(-1), rtol=1e-5, atol=1e-2)
+    # spot rows against torch fp32 math on the device (independent of the oracle)
+    s = (bd.unpack(p[0]).float() * 2 - 1)
+    ref = x1[0, :64].float() @ s
+    assert relerr(y1[0, :64], ref)[0] <= 1e-5
+
+
+def test_full_size_fused_spot_rows(bd):
+    torch.manual_seed(6)
+    K, N, M = 4096, 11008, 2048                                      # Llama-2-7B gate_proj at prefill 2048
+    x = torch.randn(1, M, K, device="cuda").bfloat16()
+    w = (torch.randn(N, K, device="cuda") * 0.02).bfloat16()
+    fine = (w.float() + torch.randn(N, K, device="cuda") * 5e-4).bfloat16()
+    mod = bd.BinaryDiff(w, fine)
+    with torch.no_grad():
+        y = mod(x)
+    rows = torch.tensor([0, 1, 255, 256, 1023, 2047], device="cuda")
+    s = (bd.unpack(mod.mask).float() * 2 - 1)
+    ref = x[0, rows].float() @ w.float().T + mod.coeff.detach() * (x[0, rows].float() @ s)
+    d = ulp_diff(y[0, rows], ref.bfloat16())
+    assert d.max().item() <= 1 and (d == 0).float().mean().item() >= 0.98
