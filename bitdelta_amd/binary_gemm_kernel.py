@@ -41,6 +41,8 @@ def pack(x, n_bits=32):
         x3 = x
     else:
         x3 = x.reshape(-1, K, N)
+    if x.numel() == 0:
+        return torch.empty((*lead, K // n_bits, N), dtype=WORD_DTYPE[n_bits], device=x.device)
     out = torch.empty((x3.shape[0], K // n_bits, N), dtype=WORD_DTYPE[n_bits], device=x.device)
     with torch.cuda.device(x.device):
         check(lib().bd_pack(ptr(x3), x3.shape[0], K, N, x3.stride(0), x3.stride(1), x3.stride(2), ptr(out), n_bits,
@@ -63,6 +65,8 @@ def unpack(x, n_bits=32):
         x = x.to(WORD_DTYPE[n_bits])
     lead = tuple(x.shape[:-2])
     KW, N = x.shape[-2], x.shape[-1]
+    if x.numel() == 0:
+        return torch.empty((*lead, KW * n_bits, N), dtype=torch.bool, device=x.device)
     xc = x.contiguous().view(-1, KW, N)
     out = torch.empty((xc.shape[0], KW * n_bits, N), dtype=torch.bool, device=x.device)
     with torch.cuda.device(x.device):

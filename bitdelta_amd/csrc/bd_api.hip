@@ -201,24 +201,46 @@ int launch_generic(const Problem& q) {
     return launch_status();
 }
 
+inline int num_cus() {
+    static int cus = 0;   // benign race: idempotent
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        cus = n;
+    }
+    return cus;
+}
+
+// 256x256 vs 256x128 ping-pong tile: rounds of CU-wide tile waves x measured relative cost of one tile
+// (256x128 does half the work of a 256x256 tile at ~0.85x its MFMA rate; DESIGN.md "tile choice").
+inline int choose_big_tile(const Problem& q) {
+    const long long cus = num_cus();
+    const long long tm = (q.M + 255) / 256;
+    const long long t0 = tm * ((q.N + 255) / 256) * q.B, t5 = tm * ((q.N + 127) / 128) * q.B;
+    const double c0 = (double)((t0 + cus - 1) / cus) * 1.0, c5 = (double)((t5 + cus - 1) / cus) * (0.5 / 0.85);
+    return c5 < c0 ? 5 : 0;
+}
+
 template <int DT, bool FUSED, bool OUT_F32>
 int dispatch3(const Problem& q) {
     int v = g_forced_variant;
     if (v < 0) {
         if (gemv_ok(q)) v = 200;
         else if (!fast_ok(q)) v = 100;
-        else if (q.M > 128) v = 0;
+        else if (q.M > 128) v = choose_big_tile(q);
         else if (q.M > 64) v = 1;
         else if (q.M > 32) v = 2;
         else v = 3;
     } else {
         if (v == 200 && !gemv_ok(q)) return BD_E_BAD_SHAPE;
-        if (v >= 0 && v <= 4 && !fast_ok(q)) return BD_E_BAD_SHAPE;
+        if (v >= 0 && v <= 5 && !fast_ok(q)) return BD_E_BAD_SHAPE;
     }
     t_last_variant = v;
     switch (v) {
         case 0: return launch_tile<GemmCfg<DT, 256, 256, 2, 4, 4, FUSED, OUT_F32, 2>, true>(q);
         case 4: return launch_tile<GemmCfg<DT, 256, 256, 2, 4, 4, FUSED, OUT_F32>>(q);   // single-barrier 256x256 (A/B reference)
+        case 5: return launch_tile<GemmCfg<DT, 256, 128, 2, 4, 4, FUSED, OUT_F32, 2>, true>(q);
         case 1: return launch_tile<GemmCfg<DT, 128, 256, 1, 4, 4, FUSED, OUT_F32>>(q);
         case 2: return launch_tile<GemmCfg<DT, 64, 256, 1, 4, 4, FUSED, OUT_F32>>(q);
         case 3: return launch_tile<GemmCfg<DT, 32, 256, 1, 4, 4, FUSED, OUT_F32>>(q);

@@ -58,10 +58,13 @@ struct GemmCfg {
     static constexpr int NSB = 2;                        // base loop ring depth
     static constexpr int A_PW = BM / 8 / NW;             // 1-KiB X pieces per wave per k-tile
     static constexpr int W_PW = BN / 8 / NW;             // 1-KiB W pieces per wave per k-tile
-    static constexpr int BW_PW = (BN / 32) / NW;         // 256-B sign-word pieces per wave per k-tile
+    static constexpr int BW_PIECES = BN / 32;            // 256-B sign-word pieces per k-tile ([2 x BN] words)
+    static constexpr int BW_PW = BW_PIECES >= NW ? BW_PIECES / NW : 1;   // per wave; narrow tiles: every wave still issues one
+                                                         // (waves >= BW_PIECES re-fetch a piece) so the vmcnt count is uniform
     static constexpr int DPW_D = A_PW + BW_PW, DPW_B = A_PW + W_PW;
     static constexpr int LDS_BYTES = (FUSED && NSB * STAGE_B > NS * STAGE_D) ? NSB * STAGE_B : NS * STAGE_D;
-    static_assert(BM % (8 * NW) == 0 && BN % (32 * NW) == 0 && BN % (8 * NW) == 0, "tile/wave mismatch");
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/wave mismatch");
+    static_assert(BW_PIECES % NW == 0 || NW % BW_PIECES == 0, "sign-word pieces vs waves");
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     static_assert((NS - 2) * DPW_D <= 63, "vmcnt field");
@@ -208,7 +211,7 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_kernel(const GemmParams p)
     }
 #pragma unroll
     for (int i = 0; i < BW_PW; ++i) {
-        const int idx = wave * BW_PW + i;
+        const int idx = (wave * BW_PW + i) % Cfg::BW_PIECES;
         const int hh = idx / (BN / 64), seg = idx % (BN / 64);
         const int nn = min(n0 + seg * 64 + lane, p.N - 1) - n0;     // clamp columns past N
         bw_voff[i] = (uint32_t)hh * (uint32_t)p.N * 4u + (uint32_t)nn * 4u;

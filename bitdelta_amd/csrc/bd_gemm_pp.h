@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_pp_kernel(const GemmParams
     }
 #pragma unroll
     for (int i = 0; i < BW_PW; ++i) {
-        const int idx = wave * BW_PW + i;
+        const int idx = (wave * BW_PW + i) % Cfg::BW_PIECES;
         const int hh = idx / (BN / 64), seg = idx % (BN / 64);
         const int nn = min(n0 + seg * 64 + lane, p.N - 1) - n0;
         bw_voff[i] = (uint32_t)hh * (uint32_t)p.N * 4u + (uint32_t)nn * 4u;

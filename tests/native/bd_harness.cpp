@@ -263,6 +263,8 @@ static void sweep_pp(int M, int N, int K, int iters) {
     CFGPP("pp_ns4_dma_in_load", DT_BF16, 256, 256, 2, 4, 4, false, false, 1);
     CFGPP("pp_ns4_noprio", DT_BF16, 256, 256, 2, 4, 4, false, false, 2);
     CFGPP("pp_ns4_dma_in_load_noprio", DT_BF16, 256, 256, 2, 4, 4, false, false, 3);
+    CFGPP("pp_256x128_ns4", DT_BF16, 256, 128, 2, 4, 4, false, false, 2);
+    CFGPP("pp_256x128_ns4_fused", DT_BF16, 256, 128, 2, 4, 4, true, false, 2);
     CFGPP("pp_256x256_ns3_f16", DT_F16, 256, 256, 2, 4, 3, false, false, 0);
     CFGPP("pp_256x256_ns3_f32out", DT_BF16, 256, 256, 2, 4, 3, false, true, 0);
     CFG("v1_256x256_fused", DT_BF16, 256, 256, 2, 4, 4, true, false, 0);
@@ -299,7 +301,7 @@ int main(int argc, char** argv) {
         // every kernel family, both dtypes, delta-only and fused, broadcast and per-tenant masks
         for (int dt : {BD_BF16, BD_F16})
             for (int fused : {0, 1}) {
-                for (int v : {0, 1, 2, 3, 4, 100})
+                for (int v : {0, 1, 2, 3, 4, 5, 100})
                     fails += run_case("tile", 2, 200, 520, 256, dt, BD_F32, fused, 2, v, 0, S);
                 fails += run_case("tile_bcast", 3, 130, 300, 128, dt, dt, fused, 1, 0, 0, S);
                 fails += run_case("auto_big", 1, 512, 768, 1024, dt, dt, fused, 1, -1, 0, S);
