@@ -142,8 +142,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
                 const int m = m0 + wm * WM + i0 * 32 + r;
                 const int n = n0 + wn * WN + sg * (16 / ESZ);
                 const u32x4_t val = *(const u32x4_t*)(buf + r * ROWB + sg * 16);
-                if (m < p.M && n < p.N)     // N % 8 == 0 -> a 16-byte piece is entirely in or out
-                    *(u32x4_t*)(p.C + (c_b + (long long)m * p.sCm + n) * ESZ) = val;
+                if (m < p.M && n < p.N) {   // N % 8 == 0 -> a 16-byte piece is entirely in or out
+                    u32x4_t* dst = (u32x4_t*)(p.C + (c_b + (long long)m * p.sCm + n) * ESZ);
+                    if constexpr (Cfg::OPT & 1024) *dst = val;                 // A/B: plain stores
+                    else __builtin_nontemporal_store(val, dst);                // C is written once and not re-read by this kernel
+                }
             }
             if (i0 + IPP < TM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }

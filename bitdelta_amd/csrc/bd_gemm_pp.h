@@ -3,29 +3,43 @@
 // Same math, operand roles, LDS image and k-permutation as bd_gemm_mfma.h (read that header first); what changes is
 // the time structure.  Profiling the one-barrier-per-k-tile kernel (profiles/r01_*): MFMA pipe 52 % busy, waves 30 % in
 // s_waitcnt/s_barrier, because the two waves that share a SIMD hit the barrier, the DMA issue and the LDS latency
-// at the same time.  Here the 8 waves form two groups (waves 0-3 / 4-7: one wave of each group per SIMD) that run the
-// same program ONE PHASE APART (group 1 executes one extra s_barrier up front, group 0 one at the end):
+// at the same time.  Here the 8 waves form two groups (waves 0-3 / 4-7: one wave of each group per SIMD).  Every wave runs the
+// same stream  L0 M0 L1 M1 | L0 M0 ...  per k-tile, where
+//   L = ds_read only: X fragments of two k-steps (L1 also: tile kt+1's sign words -> replicated chunks, and the s_waitcnt
+//       vmcnt for this wave's LDS-DMA pieces of tile kt+2);
+//   M = 2 k-steps x TM x TN v_mfma_f32_32x32x16; in their shadow (one dword = 2 VALU per MFMA) the +-1 expansion of the NEXT
+//       half's sign fragments and (M0) this wave's LDS-DMA pieces of tile kt+NS-1;
+// Shipped schedule: every wave rendezvous before every phase and group 1 runs one phase behind (strict alternation).
+// Experimental (OPT & 4): the groups differ ONLY in where they rendezvous: group 0 executes s_barrier before every L, group 1 before every M.
+// Between two consecutive barriers group 0 therefore runs "L then M" while group 1 runs "M then L": on each SIMD one wave owns
+// the matrix pipe while its partner hides LDS latency behind it, with ONE rendezvous per half-tile and an unsynchronised
+// (bubble-free) role swap in the middle.  History (profiles/r01_pp_timeline.txt, s_memtime stamps): a 4-barrier strict
+// alternation lost ~130 cycles of matrix pipe at each of its 4 hand-offs; expansion placed in the L phase made L longer than
+// the 512-cycle M phase; a 14-VALU make_reps chain behind M1's first MFMA cost 170 cycles.
 //
-//     phase          group 0                      group 1
-//     4kt            LOAD  half 0 of tile kt      MFMA  half 1 of tile kt-1
-//     4kt+1          MFMA  half 0                 LOAD  half 0 of tile kt
-//     4kt+2          LOAD  half 1                 MFMA  half 0
-//     4kt+3          MFMA  half 1                 LOAD  half 1
-//
-//   LOAD = issue this wave's LDS-DMA pieces of tile kt+NS-1 (half 0 only), ds_read the X fragments of two k-steps,
-//          read the sign words (half 0) and expand two steps' worth of +-1 fragments, wait for the tile after next.
-//   MFMA = 2 k-steps x TM x TN v_mfma_f32_32x32x16 back to back at raised priority.
-// Every phase ends in s_barrier, so on each SIMD one wave always owns the matrix pipe while its partner hides LDS
-// latency, VALU sign expansion and DMA issue behind it.
-//
-// LDS ring safety (NS slots, tile t in slot t % NS): the last read of tile kt-1 is group 1's LOAD of its half 1 in
-// phase 4kt-1; refills of that slot are issued in phases >= 4kt (after the barrier).  Tile kt is first read in phase
-// 4kt; every wave has executed s_waitcnt vmcnt((NS-2)*DPW) for its own pieces of tile kt in its LOAD-half-1 of tile
-// kt-1 (phase <= 4kt-1) and a barrier separates that from the first read.
+// LDS ring safety (NS >= 4 slots, tile t in slot t % NS; halves numbered n = 2kt+1, 2kt+2; barrier n = group 0's before L(n) =
+// group 1's before M(n)).  Reads of tile kt's slot end with L(2kt+2): group 1 finishes it before barrier 2kt+2, group 0 before
+// barrier 2kt+3.  The refill of that slot (tile kt+NS) is issued in M0 of tile kt+1 = M(2kt+3), which both groups enter after
+// barrier 2kt+3.  Tile kt+1 is first read (its words) in L(2kt+2), by group 1 right after barrier 2kt+1; every wave waits
+// vmcnt((NS-3)*DPW) for its pieces of tile kt+1 in L(2kt) = L1 of tile kt-1, which both groups finish before barrier 2kt+1.
 #pragma once
 #include "bd_gemm_mfma.h"
 
 namespace bd {
+
+#ifdef BD_TRACE
+// development aid (tests/native/bd_trace): shader-clock stamps of block 0, waves 0 and 4, k-tiles 16..23, 8 stamps per tile
+__device__ unsigned long long bd_trace_buf[2][8][8];
+#define BD_STAMP(id)                                                                                         \
+    do {                                                                                                     \
+        if (blockIdx.x == 0 && (wave & 3) == 0 && kt >= 16 && kt < 24) {                                     \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                      \
+            if (lane == 0) bd_trace_buf[wave >> 2][kt - 16][id] = t_;                                        \
+        }                                                                                                    \
+    } while (0)
+#else
+#define BD_STAMP(id) do { } while (0)
+#endif
 
 template <class Cfg>
 __global__ void __launch_bounds__(Cfg::NT) delta_gemm_pp_kernel(const GemmParams p) {
@@ -113,6 +127,13 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_pp_kernel(const GemmParams
     auto nothing = [](int) {};
 
     // =========================== delta loop ===========================
+    // Per wave and k-tile kt (see the header for the two-group phase picture):
+    //   L0: ds_read X fragments of steps 0,1;  s_waitcnt for this wave's pieces of tile kt+1
+    //   M0: 2*TM*TN MFMAs (steps 0,1) with, in their shadow, the expansion of steps 2,3 signs (from the word's high half,
+    //       already in registers) and this wave's LDS-DMA pieces of tile kt+NS-1
+    //   L1: ds_read X fragments of steps 2,3 and the sign words of tile kt+1
+    //   M1: MFMAs of steps 2,3 with the expansion of tile kt+1's steps 0,1 signs in their shadow
+    // LOAD phases are ds_read-only (~300 cycles), so they hide entirely behind the partner's 512-cycle MFMA phase.
     {
         auto issue = [&](int kt, int slot) {
             const char* as = a_src + (long long)kt * 128;
@@ -123,87 +144,149 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_pp_kernel(const GemmParams
 #pragma unroll
             for (int i = 0; i < BW_PW; ++i) dma4(bw_voff[i], ps, base + bw_lds[i]);
         };
+        static_assert(NS >= 4, "ring depth (two tiles must be resident ahead of the reader)");  // NS = 3 is not enough here
 #pragma unroll
         for (int t = 0; t < NS - 1; ++t) issue(min(t, nk - 1), t);
-        wait_vmcnt<(NS - 2) * Cfg::DPW_D>();
-        phase_end();                              // tile 0 resident
-        if (grp == 1) phase_end();                // stagger: group 1 runs one phase behind
+        wait_vmcnt<(NS - 3) * Cfg::DPW_D>();      // tiles 0 and 1 resident (this wave's pieces) ...
+        phase_end();                              // ... and everybody's
 
+        // rep[j]: 16-bit chunk c of the inverted word in the low half and (c >> 1) in the high half, so ONE 32-bit shift by
+        // 15-2q moves sign 2q to bit 15 and sign 2q+1 to bit 31: v_lshlrev_b32 + v_and_or_b32 = 2 VALU per dword.
+        auto expand_dw = [&](u32x4_t (&fa)[TN], u32x4_t (&fb)[TN], const uint32_t (&rep)[TN], int idx) {
+            const int which = idx / (4 * TN), j = (idx / 4) % TN, d = idx % 4;
+            const int q = which * 4 + d;
+            const uint32_t r = ((rep[j] << (15 - 2 * q)) & 0x80008000u) | one2;
+            if (which == 0) fa[j][d] = r; else fb[j][d] = r;
+        };
+        auto make_reps = [&](uint32_t w, uint32_t& lo, uint32_t& hi) {      // w = inverted packed word
+            lo = (w & 0xffffu) | ((w << 15) & 0x7fff0000u);
+            hi = (w >> 16) | ((w >> 1) & 0x7fff0000u);
+        };
+        uint32_t rlo[TN], rhi[TN], wraw[TN];
+        u32x4_t s0a[TN], s0b[TN], s1a[TN], s1b[TN];       // s0*: steps 0,1   s1*: steps 2,3
+        {   // bootstrap: tile 0's words -> steps 0,1 fragments
+#pragma unroll
+            for (int j = 0; j < TN; ++j) make_reps(~*(const uint32_t*)(smem + bw_rd + j * 128), rlo[j], rhi[j]);
+#pragma unroll
+            for (int idx = 0; idx < 8 * TN; ++idx) expand_dw(s0a, s0b, rlo, idx);
+        }
+        // Rendezvous: group 0 executes it BEFORE each LOAD, group 1 BEFORE each MFMA phase -> one s_barrier per half-tile
+        // for every wave, and the two groups run  L M | L M ...  vs  M L | M L ...  between consecutive barriers.
+        auto sync_if = [&](bool on) {
+            if (on) {
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("" ::: "memory");
+            }
+        };
+        // Default: strict alternation -- EVERY wave rendezvous after EVERY phase, group 1 one phase behind (4 barriers per tile).
+        // OPT & 4: the asymmetric placement described above (2 barriers per tile).  Measured (profiles/r01_pp_timeline.txt):
+        // asymmetric is slower -- with L << M the groups drift into bursting together and both idle through the trailing L.
+        constexpr bool ASYM = (Cfg::OPT & 4) != 0;
+        const bool g0 = ASYM ? (grp == 0) : true, g1 = ASYM ? (grp != 0) : true;
+        if (!ASYM && grp == 1) phase_end();       // stagger: group 1 runs one phase behind
+
+        constexpr int NMF = 2 * TM * TN;          // MFMAs per phase
+        constexpr int XG = (Cfg::OPT & 64) ? 2 : ((Cfg::OPT & 512) ? 4 : 1);   // MFMAs per (MFMA..., expansion...) group
+        constexpr int NDW = 8 * TN;               // sign dwords to expand per phase
+        constexpr int NPIECE = A_PW + BW_PW;
+        constexpr int EVERY = NMF / (NPIECE + 1) > 0 ? NMF / (NPIECE + 1) : 1;
         int slot_c = 0, slot_i = NS - 1;
         for (int kt = 0; kt < nk; ++kt) {
             const char* st = smem + slot_c * STAGE_D;
-            u32x4_t xa[TM], xb[TM], sfa[TN], sfb[TN];
-            uint32_t rhi[TN];
-            // ---------------- LOAD half 0
-            const int kt_i = min(kt + NS - 1, nk - 1);
-            if constexpr (Cfg::OPT & 1) issue(kt_i, slot_i);
-            // Sign words FIRST and by inline asm with a hand-counted wait: hipcc waits lgkmcnt(0) before their first use
-            // (the 2*TM fragment reads issued behind them would then sit idle); lgkmcnt(2*TM) releases the expansion
-            // VALU as soon as the words are back, so it overlaps the fragment reads' LDS latency.
-            uint32_t wraw[TN];
+            const int slot_n = (slot_c + 1 == NS) ? 0 : slot_c + 1;
+            u32x4_t xa[TM], xb[TM];
+            // ---------------- L0
+            sync_if(g0);
+            BD_STAMP(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) xa[i] = *(const u32x4_t*)(st + a_rd[0] + i * 4096);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) xb[i] = *(const u32x4_t*)(st + a_rd[1] + i * 4096);
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): fragments in registers before the (possible) rendezvous
+            BD_STAMP(1);
+            sync_if(g1);
+            BD_STAMP(2);
+            // ---------------- M0: steps 0,1; in the shadow: expand steps 2,3 (from rhi) + this wave's DMA pieces
             {
-                const uint32_t waddr = lds0 + slot_c * STAGE_D + bw_rd;
+                const int kt_i = min(kt + NS - 1, nk - 1);
+                const char* as = a_src + (long long)kt_i * 128;
+                const char* ps = p_src + (long long)kt_i * 2 * p.N * 4;
+                const uint32_t base = lds0 + slot_i * STAGE_D;
+                if constexpr (!(Cfg::OPT & 2)) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int t = 0; t < NMF; ++t) {
+                    const int hsel = t / (TM * TN), j = (t % (TM * TN)) / TM, i = t % TM;
+                    acc[i][j] = hsel == 0 ? mfma32<DT>(s0a[j], xa[i], acc[i][j]) : mfma32<DT>(s0b[j], xb[i], acc[i][j]);
+                    if constexpr (!(Cfg::OPT & 32)) {       // 32 = timing probe without the expansion (WRONG results)
+                        if (t % XG == XG - 1) {
+#pragma unroll
+                            for (int e = (t + 1 - XG) * NDW / NMF; e < (t + 1) * NDW / NMF; ++e) expand_dw(s1a, s1b, rhi, e);
+                        }
+                    }
+                    {
+                        const int pc = t / EVERY;
+                        if (t % EVERY == EVERY - 1 && pc < NPIECE) {
+                            if (pc < A_PW) dma16(a_voff[pc < A_PW ? pc : 0], as, base + a_lds[pc < A_PW ? pc : 0]);
+                            else dma4(bw_voff[pc >= A_PW && pc - A_PW < BW_PW ? pc - A_PW : 0], ps,
+                                      base + bw_lds[pc >= A_PW && pc - A_PW < BW_PW ? pc - A_PW : 0]);
+                        }
+                    }
+                    if constexpr (!(Cfg::OPT & 1)) { if (t % XG == XG - 1) __builtin_amdgcn_sched_barrier(0); }   // keep the interleave as written
+                }
+                if constexpr (!(Cfg::OPT & 2)) __builtin_amdgcn_s_setprio(0);
+            }
+            BD_STAMP(3);
+            // ---------------- L1: steps 2,3 fragments + tile kt+1's sign words (-> replicated chunks for M1's expansion)
+            sync_if(g0);
+            BD_STAMP(4);
+            {
+                const uint32_t waddr = lds0 + slot_n * STAGE_D + bw_rd;     // tile kt+1's words (tail: a re-fetched copy)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(wraw[j]) : "v"(waddr), "n"(j * 128) : "memory");
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) xa[i] = *(const u32x4_t*)(st + a_rd[0] + i * 4096);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) xb[i] = *(const u32x4_t*)(st + a_rd[1] + i * 4096);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * TM) : "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const uint32_t w = ~wraw[j];
-                const uint32_t rlo = __builtin_amdgcn_perm(w, w, 0x01000100u);
-                rhi[j] = __builtin_amdgcn_perm(w, w, 0x03020302u);
-                sfa[j] = expand_signs8(rlo, 0, one2);
-                sfb[j] = expand_signs8(rlo, 4, one2);
-            }
-            phase_end();
-            // ---------------- MFMA half 0 (+ this wave's LDS-DMA pieces of tile kt+NS-1, one per few MFMAs)
-            {
-                const char* as = a_src + (long long)kt_i * 128;
-                const char* ps = p_src + (long long)kt_i * 2 * p.N * 4;
-                const uint32_t base = lds0 + slot_i * STAGE_D;
-                constexpr int NPIECE = A_PW + BW_PW, EVERY = (2 * TM * TN) / (NPIECE + 1) > 0 ? (2 * TM * TN) / (NPIECE + 1) : 1;
-                mfma_phase(sfa, sfb, xa, xb, [&](int t) {
-                    if constexpr (!(Cfg::OPT & 1)) {
-                        const int pc = t / EVERY;
-                        if (t % EVERY == EVERY - 1 && pc < NPIECE) {
-                            __builtin_amdgcn_sched_barrier(0);     // keep the MFMA / DMA interleave as written
-                            if (pc < A_PW) dma16(a_voff[pc < A_PW ? pc : 0], as, base + a_lds[pc < A_PW ? pc : 0]);
-                            else dma4(bw_voff[pc - A_PW < BW_PW ? (pc >= A_PW ? pc - A_PW : 0) : 0], ps,
-                                      base + bw_lds[pc - A_PW < BW_PW ? (pc >= A_PW ? pc - A_PW : 0) : 0]);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                });
-            }
-            phase_end();
-            // ---------------- LOAD half 1
-#pragma unroll
             for (int i = 0; i < TM; ++i) xa[i] = *(const u32x4_t*)(st + a_rd[2] + i * 4096);
 #pragma unroll
             for (int i = 0; i < TM; ++i) xb[i] = *(const u32x4_t*)(st + a_rd[3] + i * 4096);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * TM) : "memory");      // the words are back
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                sfa[j] = expand_signs8(rhi[j], 0, one2);
-                sfb[j] = expand_signs8(rhi[j], 4, one2);
+            for (int j = 0; j < TN; ++j) make_reps(~wraw[j], rlo[j], rhi[j]);      // rhi's old value died in M0
+            wait_vmcnt<(NS - 3) * Cfg::DPW_D>();  // own pieces of tile kt+2 landed (published by the next rendezvous)
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            BD_STAMP(5);
+            sync_if(g1);
+            BD_STAMP(6);
+            // ---------------- M1: steps 2,3; in the shadow: expand tile kt+1's steps 0,1 (from rlo)
+            {
+                if constexpr (!(Cfg::OPT & 2)) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int t = 0; t < NMF; ++t) {
+                    const int hsel = t / (TM * TN), j = (t % (TM * TN)) / TM, i = t % TM;
+                    acc[i][j] = hsel == 0 ? mfma32<DT>(s1a[j], xa[i], acc[i][j]) : mfma32<DT>(s1b[j], xb[i], acc[i][j]);
+                    if constexpr (!(Cfg::OPT & 32)) {
+                        if (t % XG == XG - 1) {
+#pragma unroll
+                            for (int e = (t + 1 - XG) * NDW / NMF; e < (t + 1) * NDW / NMF; ++e) expand_dw(s0a, s0b, rlo, e);
+                        }
+                    }
+                    if constexpr (!(Cfg::OPT & 1)) { if (t % XG == XG - 1) __builtin_amdgcn_sched_barrier(0); }
+                }
+                if constexpr (!(Cfg::OPT & 2)) __builtin_amdgcn_s_setprio(0);
             }
-            wait_vmcnt<(NS - 2) * Cfg::DPW_D>();  // this wave's pieces of tile kt+1 have landed
-            phase_end();
-            // ---------------- MFMA half 1
-            mfma_phase(sfa, sfb, xa, xb, nothing);
-            phase_end();
-            slot_c = (slot_c + 1 == NS) ? 0 : slot_c + 1;
+            BD_STAMP(7);
+            slot_c = slot_n;
             slot_i = (slot_i + 1 == NS) ? 0 : slot_i + 1;
         }
-        if (grp == 0) phase_end();                // re-align the groups (equal barrier counts)
+        if (!ASYM && grp == 0) phase_end();       // re-align the groups (equal barrier counts)
         wait_vmcnt<0>();
+        phase_end();
     }
 
     // =========================== fused: scale, then base loop (same ping-pong, X and W fragments from LDS) ============

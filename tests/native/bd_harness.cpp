@@ -16,6 +16,7 @@
 
 #include "../../bitdelta_amd/csrc/bd_gemm_mfma.h"
 #include "../../bitdelta_amd/csrc/bd_gemm_pp.h"
+#include "../../bitdelta_amd/csrc/bd_gemm_sp.h"
 #include "../../include/bitdelta_hip.h"
 
 #define HIPCHECK(x)                                                                      \
@@ -192,10 +193,11 @@ static int run_case(const char* tag, int B, int M, int N, int K, int dt, int out
 }
 
 // ---------------- experimental configs launched directly ----------------
-template <class Cfg, bool PP> struct KernSel { static auto get() { return bd::delta_gemm_kernel<Cfg>; } };
-template <class Cfg> struct KernSel<Cfg, true> { static auto get() { return bd::delta_gemm_pp_kernel<Cfg>; } };
+template <class Cfg, int PP> struct KernSel { static auto get() { return bd::delta_gemm_kernel<Cfg>; } };
+template <class Cfg> struct KernSel<Cfg, 1> { static auto get() { return bd::delta_gemm_pp_kernel<Cfg>; } };
+template <class Cfg> struct KernSel<Cfg, 2> { static auto get() { return bd::delta_gemm_sp_kernel<Cfg>; } };
 
-template <class Cfg, bool PP = false>
+template <class Cfg, int PP = 0>
 static void run_cfg(const char* name, int M, int N, int K, int iters, int nsamples) {
     auto kern = KernSel<Cfg, PP>::get();
     Problem q{1, M, N, K, Cfg::DT == bd::DT_BF16 ? BD_BF16 : BD_F16, Cfg::OUT_F32 ? BD_F32 : (Cfg::DT == bd::DT_BF16 ? BD_BF16 : BD_F16),
@@ -250,25 +252,47 @@ static void sweep(int M, int N, int K, int iters) {
     CFG("128x256_1x4_fused", DT_BF16, 128, 256, 1, 4, 4, true, false, 0);
 }
 
-#define CFGPP(name, ...) run_cfg<GemmCfg<__VA_ARGS__>, true>(name, M, N, K, iters, 4096)
+#define CFGPP(name, ...) run_cfg<GemmCfg<__VA_ARGS__>, 1>(name, M, N, K, iters, 4096)
+#define CFGSP(name, ...) run_cfg<GemmCfg<__VA_ARGS__>, 2>(name, M, N, K, iters, 4096)
+static void sweep_sp(int M, int N, int K, int iters) {
+    for (int rep = 0; rep < 2; ++rep) {      // interleaved A/B: two rounds in one process
+        CFGPP("pp_ns4_noprio", DT_BF16, 256, 256, 2, 4, 4, false, false, 2);
+        CFGPP("pp_ns4_prio", DT_BF16, 256, 256, 2, 4, 4, false, false, 0);
+        CFGPP("pp_ns4_xg2", DT_BF16, 256, 256, 2, 4, 4, false, false, 2 + 64);
+        CFGPP("pp_ns4_xg4", DT_BF16, 256, 256, 2, 4, 4, false, false, 2 + 512);
+        CFGPP("pp_ns4_asym", DT_BF16, 256, 256, 2, 4, 4, false, false, 6);
+        CFGPP("pp_256x128_noprio", DT_BF16, 256, 128, 2, 4, 4, false, false, 2);
+        CFGSP("sp_ns4", DT_BF16, 256, 256, 2, 4, 4, false, false, 0);
+        CFGSP("sp_ns3", DT_BF16, 256, 256, 2, 4, 3, false, false, 0);
+        CFGSP("sp_ns4_nopin", DT_BF16, 256, 256, 2, 4, 4, false, false, 1);
+        CFGSP("sp_ns4_prio", DT_BF16, 256, 256, 2, 4, 4, false, false, 2);
+        CFGSP("sp_1x8_ns4", DT_BF16, 256, 256, 1, 8, 4, false, false, 0);
+        CFGSP("sp_256x128_ns4", DT_BF16, 256, 128, 2, 4, 4, false, false, 0);
+        CFGSP("sp_128x256_1x4", DT_BF16, 128, 256, 1, 4, 4, false, false, 0);
+    }
+}
+
 static void sweep_pp(int M, int N, int K, int iters) {
     if (K < 256) {   // fixed-cost probe: launch + prologue + epilogue with (almost) no main loop
         CFGPP("pp_256x256_ns4", DT_BF16, 256, 256, 2, 4, 4, false, false, 0);
-        CFGPP("pp_256x256_ns3_f32out", DT_BF16, 256, 256, 2, 4, 3, false, true, 0);
+        CFGPP("pp_256x256_ns4_f32out", DT_BF16, 256, 256, 2, 4, 4, false, true, 0);
         return;
     }
     CFG("v1_256x256_2x4_ns4", DT_BF16, 256, 256, 2, 4, 4, false, false, 0);
-    CFGPP("pp_256x256_ns3", DT_BF16, 256, 256, 2, 4, 3, false, false, 0);
+    CFGPP("pp_256x256_ns5", DT_BF16, 256, 256, 2, 4, 4, false, false, 0);
     CFGPP("pp_256x256_ns4", DT_BF16, 256, 256, 2, 4, 4, false, false, 0);
-    CFGPP("pp_ns4_dma_in_load", DT_BF16, 256, 256, 2, 4, 4, false, false, 1);
+    CFGPP("pp_ns4_nopin", DT_BF16, 256, 256, 2, 4, 4, false, false, 1);
     CFGPP("pp_ns4_noprio", DT_BF16, 256, 256, 2, 4, 4, false, false, 2);
-    CFGPP("pp_ns4_dma_in_load_noprio", DT_BF16, 256, 256, 2, 4, 4, false, false, 3);
+    CFGPP("pp_ns4_tail4", DT_BF16, 256, 256, 2, 4, 4, false, false, 4);
+    CFGPP("pp_ns4_tail4_noprio", DT_BF16, 256, 256, 2, 4, 4, false, false, 6);
+    CFGPP("pp_ns4_tail8", DT_BF16, 256, 256, 2, 4, 4, false, false, 8);
+    CFGPP("pp_ns4_tail8_noprio", DT_BF16, 256, 256, 2, 4, 4, false, false, 10);
     CFGPP("pp_256x128_ns4", DT_BF16, 256, 128, 2, 4, 4, false, false, 2);
     CFGPP("pp_256x128_ns4_fused", DT_BF16, 256, 128, 2, 4, 4, true, false, 2);
-    CFGPP("pp_256x256_ns3_f16", DT_F16, 256, 256, 2, 4, 3, false, false, 0);
-    CFGPP("pp_256x256_ns3_f32out", DT_BF16, 256, 256, 2, 4, 3, false, true, 0);
+    CFGPP("pp_256x256_ns4_f16", DT_F16, 256, 256, 2, 4, 4, false, false, 0);
+    CFGPP("pp_256x256_ns4_f32out", DT_BF16, 256, 256, 2, 4, 4, false, true, 0);
     CFG("v1_256x256_fused", DT_BF16, 256, 256, 2, 4, 4, true, false, 0);
-    CFGPP("pp_256x256_ns3_fused", DT_BF16, 256, 256, 2, 4, 3, true, false, 0);
+    CFGPP("pp_256x256_ns4_fused2", DT_BF16, 256, 256, 2, 4, 4, true, false, 2);
     CFGPP("pp_256x256_ns4_fused", DT_BF16, 256, 256, 2, 4, 4, true, false, 0);
 }
 
@@ -331,20 +355,31 @@ int main(int argc, char** argv) {
         fails += run_case("decode_fused_down", 6, 1, 4096, 14336, BD_F16, BD_F16, 1, 6, -1, 50, 2048);
         fails += run_case("decode_fused_kv", 6, 1, 1024, 4096, BD_F16, BD_F16, 1, 6, -1, 50, 2048);
         fails += run_case("prefill64_t6", 6, 64, 4096, 4096, BD_F16, BD_F16, 1, 6, -1, it, 2048);
+    } else if (mode == "sp") {
+        sweep_sp(argc > 2 ? atoi(argv[2]) : 4096, 4096, argc > 3 ? atoi(argv[3]) : 4096, 30);
     } else if (mode == "pp") {
         const int M = argc > 2 ? atoi(argv[2]) : 4096;
         sweep_pp(M, 4096, argc > 3 ? atoi(argv[3]) : 4096, 20);
     } else if (mode == "ablate") {
         ablate(4096, 4096, 4096, 20);
+    } else if (mode == "ablate_pp") {
+#define ABLP(name, opt) run_cfg<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 2 + (opt)>, 1>(name, 4096, 4096, 4096, 30, 0)
+        ABLP("pp_base", 0);
+        ABLP("pp_base_nostore", 128);
+        ABLP("pp_base", 0);
+#undef ABLP
     } else if (mode == "fixed") {
         // fixed-cost anatomy at K = 64 (one k-tile): full / no C stores / empty kernel, timed by rocprofv3 kernel-trace
-        run_cfg<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 2>, true>("full", 4096, 4096, 64, 10, 0);
-        run_cfg<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 2 + 128>, true>("no_store", 4096, 4096, 64, 10, 0);
-        run_cfg<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 2 + 256>, true>("empty", 4096, 4096, 64, 10, 0);
-        run_cfg<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 2 + 128>, true>("no_store_k4096", 4096, 4096, 4096, 10, 0);
+        run_cfg<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 2>, 1>("full", 4096, 4096, 64, 10, 0);
+        run_cfg<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 2 + 1024>, 1>("full_plain_store", 4096, 4096, 64, 10, 0);
+        run_cfg<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 2>, 1>("k4096_nt", 4096, 4096, 4096, 10, 64);
+        run_cfg<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 2 + 1024>, 1>("k4096_plain", 4096, 4096, 4096, 10, 64);
+        run_cfg<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 2 + 128>, 1>("no_store", 4096, 4096, 64, 10, 0);
+        run_cfg<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 2 + 256>, 1>("empty", 4096, 4096, 64, 10, 0);
+        run_cfg<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 2 + 128>, 1>("no_store_k4096", 4096, 4096, 4096, 10, 0);
     } else if (mode == "one_pp") {
         const int M = argc > 2 ? atoi(argv[2]) : 4096, K = argc > 3 ? atoi(argv[3]) : 4096;
-        run_cfg<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 2>, true>("pp_ns4_noprio", M, 4096, K, 10, 256);
+        run_cfg<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 2>, 1>("pp_ns4_noprio", M, 4096, K, 10, 256);
     } else if (mode == "one") {
         // a single configuration, a few launches: for rocprofv3 counter passes
         const int M = argc > 2 ? atoi(argv[2]) : 4096;
