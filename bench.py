@@ -53,14 +53,17 @@ class LaunchTimer:
             y = orig(x, weight, mask, alpha, **kw)
             e1.record()
             B, M, K = x.shape
-            timer.records.append((e0, e1, 4.0 * B * M * K * weight.shape[0], M))
+            N = weight.shape[0]
+            nbytes = 2.0 * B * M * K + 2.0 * N * K + mask.shape[0] * K * N / 8.0 + 4.0 * mask.shape[0] + 2.0 * B * M * N
+            timer.records.append((e0, e1, 4.0 * B * M * K * N, nbytes))
             return y
         k.binary_linear = d.binary_linear = s.binary_linear = timed
 
     def summary(self):
         ms = sum(a.elapsed_time(b) for a, b, _, _ in self.records)
         fl = sum(f for _, _, f, _ in self.records)
-        return len(self.records), ms, fl
+        by = sum(n for _, _, _, n in self.records)
+        return len(self.records), ms, fl, by
 
 
 def cpu_baseline(seq=128):
@@ -131,7 +134,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--model", default="llama-2-7b")
+    ap.add_argument("--workload", default="prefill", choices=["prefill", "mt-decode"],
+                    help="prefill = BASELINE configs[1] (default, the bench line the driver records); mt-decode = configs[2]: "
+                         "Mistral-7B base + T tenant deltas, batched decode steps (HBM-bound), reported for DESIGN.md")
+    ap.add_argument("--model", default=None)
+    ap.add_argument("--tenants", type=int, default=6)
+    ap.add_argument("--kv-len", type=int, default=512)
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result is then marked invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -150,11 +158,31 @@ def main():
 
     timer = LaunchTimer()
     timer.install()
-    model = Decoder(args.model, dev, layers=args.layers, seed=1234 + rank)
-    ids = torch.randint(0, model.cfg[5], (1, args.seq), device=dev)
+    decode = args.workload == "mt-decode"
+    args.model = args.model or ("mistral-7b" if decode else "llama-2-7b")
+    if decode:
+        T = len(bdd.tenants_for_rank(args.tenants * world, rank, world))      # tenants are partitioned across ranks
+        model = Decoder(args.model, dev, dtype=torch.float16, tenants=T, layers=args.layers, seed=1234 + rank)
+        cache = model.new_cache(T, args.kv_len + args.steps + args.warmup + 8)
+        model(torch.randint(0, model.cfg[5], (T, args.kv_len), device=dev), pos0=0, cache=cache)     # prefill the cache
+        tok = torch.randint(0, model.cfg[5], (T, 1), device=dev)
+        pos = [args.kv_len]
 
-    def step():
-        return model(ids)
+        def step():
+            out = model(tok, pos0=pos[0], cache=cache)
+            pos[0] += 1
+            return out
+
+        def step_fixed():           # same work at a fixed position (static shapes): what the hipGraph replays
+            for c in cache:
+                c[2] = args.kv_len
+            return model(tok, pos0=args.kv_len, cache=cache)
+    else:
+        model = Decoder(args.model, dev, layers=args.layers, seed=1234 + rank)
+        ids = torch.randint(0, model.cfg[5], (1, args.seq), device=dev)
+
+        def step():
+            return model(ids)
 
     for _ in range(args.warmup):
         step()
@@ -162,11 +190,56 @@ def main():
     dt = bdd.timed_region(step, args.steps, device_sync=torch.cuda.synchronize)
     timer.enabled = False
     torch.cuda.synchronize()
-    n_launch, k_ms, k_flops = timer.summary()
+    n_launch, k_ms, k_flops, k_bytes = timer.summary()
 
-    tokens = args.seq * args.steps * world
+    tokens = (args.tenants if decode else args.seq) * args.steps * world
     value = tokens / dt
+    graph_ms = None
+    if decode:
+        # launch-bound loop -> hipGraph: capture one decode step (448 kernel launches + glue) and replay it
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    step_fixed()
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step_fixed()
+            for _ in range(3):
+                g.replay()
+            graph_s = bdd.timed_region(g.replay, args.steps, device_sync=torch.cuda.synchronize)
+            graph_ms = graph_s / args.steps * 1e3
+        except Exception as e:          # report, never hide
+            graph_ms = f"capture failed: {type(e).__name__}: {e}"
     if rank != 0:
+        return
+    if decode:
+        gbs = k_bytes / k_ms * 1e-6 if k_ms > 0 else 0.0
+        out = {
+            "metric": "multi-tenant batched decode tokens/s (BASELINE.json configs[2]: Mistral-7B base + T 1-bit deltas)",
+            "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{args.model} base + {args.tenants} tenant deltas per GPU, decode step at kv length "
+                                   f"{args.kv_len}, one token per tenant; {len(model.layers)} layers x 7 fused DiffCompressModule "
+                                   "projections", "tenants_per_gpu": args.tenants, "parallelism": f"tenants partitioned over {world} rank(s), base replicated, no collective",
+                       "valid": args.layers is None},
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                         "traffic": None, "kernel": "bd::gemv_kernel (+ gemv_reduce_kernel) via bd_binary_linear",
+                         "launches": n_launch, "kernel_ms_total": k_ms, "algorithmic_bytes_total": k_bytes,
+                         "share_of_step_time": (k_ms / 1e3) / dt if dt > 0 else None},
+            "eager_ms_per_step": dt / args.steps * 1e3,
+            "hipgraph_ms_per_step": graph_ms,
+        }
+        if isinstance(graph_ms, float):        # the graph replay is the serving-relevant number: value reports it
+            out["value"] = args.tenants * world / (graph_ms * 1e-3)
+            out["ms_per_step"] = graph_ms
+            lin_bytes = k_bytes / args.steps
+            out["roofline"]["step_linear_bytes"] = lin_bytes
+            out["roofline"]["whole_step_gbs_if_only_linears"] = lin_bytes / (graph_ms * 1e-3) * 1e-9
+        print(json.dumps(out))
         return
     mb = delta_gemm_microbench(dev)
     achieved = k_flops / k_ms * 1e-9 if k_ms > 0 else 0.0
@@ -182,7 +255,7 @@ def main():
                    "valid": args.layers is None},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
-                     "kernel": "bd::delta_gemm_pp_kernel<bf16,256x256,fused> (x.W^T + alpha*(x.S), 4*M*N*K flop/launch)",
+                     "kernel": "bd::delta_gemm_pp_kernel<bf16, 256x128 | 256x256 tile, fused> (x.W^T + alpha*(x.S), 4*M*N*K flop/launch)",
                      "launches": n_launch, "kernel_ms_total": k_ms, "algorithmic_flops_total": k_flops,
                      "share_of_step_time": (k_ms / 1e3) / dt if dt > 0 else None},
         "delta_gemm": mb,

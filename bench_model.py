@@ -38,6 +38,8 @@ class RMSNorm(nn.Module):
         self.eps = eps
 
     def forward(self, x):
+        if hasattr(F, "rms_norm"):                       # fused kernel (torch >= 2.4); same fp32-internal math
+            return F.rms_norm(x, (x.shape[-1],), self.weight, self.eps)
         v = x.float()
         v = v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + self.eps)
         return (v.to(x.dtype)) * self.weight
@@ -52,10 +54,10 @@ def rope_tables(seq, dim, device, base=10000.0):
 
 
 def apply_rope(x, cos, sin):
-    # x [B, H, S, D]
+    # x [B, H, S, D]; cos/sin [S, D] already in x.dtype with the rotate-half sign folded into `sin`
     d = x.shape[-1] // 2
-    rot = torch.cat([-x[..., d:], x[..., :d]], dim=-1)
-    return (x.float() * cos + rot.float() * sin).to(x.dtype)
+    rot = torch.cat([x[..., d:], x[..., :d]], dim=-1)
+    return torch.addcmul(x * cos, rot, sin)
 
 
 class SingleTenantLinear(nn.Module):
@@ -118,16 +120,17 @@ class DecoderLayer(nn.Module):
         k = self.k_proj(h).view(B, S, self.kvh, self.hd).transpose(1, 2)
         v = self.v_proj(h).view(B, S, self.kvh, self.hd).transpose(1, 2)
         q, k = apply_rope(q, cos, sin), apply_rope(k, cos, sin)
-        if kv is not None:                      # decode: append to the cache
-            if kv[0] is not None:
-                k = torch.cat([kv[0], k], dim=2)
-                v = torch.cat([kv[1], v], dim=2)
-            kv[0], kv[1] = k, v
+        if kv is not None:                      # decode: write into the preallocated cache [B, kvh, Lmax, hd]
+            pos = kv[2]
+            kv[0][:, :, pos:pos + S] = k
+            kv[1][:, :, pos:pos + S] = v
+            kv[2] = pos + S
+            k, v = kv[0][:, :, :pos + S], kv[1][:, :, :pos + S]
         if self.kvh != self.heads:
             rep = self.heads // self.kvh
             k = k.repeat_interleave(rep, dim=1)
             v = v.repeat_interleave(rep, dim=1)
-        a = F.scaled_dot_product_attention(q, k, v, is_causal=(S > 1))
+        a = F.scaled_dot_product_attention(q, k, v, is_causal=(S > 1 and k.shape[2] == S))
         a = a.transpose(1, 2).reshape(B, S, self.heads * self.hd)
         x = x + self.o_proj(a)
         h = self.post_attention_layernorm(x)
@@ -152,6 +155,11 @@ class Decoder(nn.Module):
             p.requires_grad_(False)
         self.hd = hid // heads
 
+    def new_cache(self, batch, max_len):
+        _, _, _, heads, kvh, _ = self.cfg
+        mk = lambda: torch.zeros(batch, kvh, max_len, self.hd, device=self.device_, dtype=self.dtype)
+        return [[mk(), mk(), 0] for _ in self.layers]
+
     def linear_flops_per_token(self):
         return sum(m.flops_per_row for m in self.modules() if hasattr(m, "flops_per_row"))
 
@@ -161,8 +169,14 @@ class Decoder(nn.Module):
     @torch.no_grad()
     def forward(self, ids, pos0=0, cache=None):
         B, S = ids.shape
-        cos, sin = rope_tables(pos0 + S, self.hd, ids.device)
-        cos, sin = cos[pos0:], sin[pos0:]
+        key = (pos0 + S)
+        if getattr(self, "_rope_key", None) != key:      # tables are position-only: build once per length
+            cos, sin = rope_tables(pos0 + S, self.hd, ids.device)
+            d = self.hd // 2
+            sin = torch.cat([-sin[:, :d], sin[:, d:]], dim=-1)          # rotate-half sign folded in
+            self._rope = (cos.to(self.dtype), sin.to(self.dtype))
+            self._rope_key = key
+        cos, sin = self._rope[0][pos0:], self._rope[1][pos0:]
         x = self.embed(ids)
         for i, layer in enumerate(self.layers):
             x = layer(x, cos, sin, None if cache is None else cache[i])

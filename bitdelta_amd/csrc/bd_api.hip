@@ -117,11 +117,12 @@ inline bool gemv_ok(const Problem& q) {
 
 inline void gemv_split(const Problem& q, int& KS, int& kslice) {
     const int tiles_n = (q.N + 63) / 64;
-    int want = (1024 + tiles_n - 1) / tiles_n;            // ~4 blocks per CU
-    int maxks = q.K / 256;                                // at least 256 k per slice
+    int want = (512 + tiles_n - 1) / tiles_n;             // ~2 blocks per CU: fat blocks keep many loads in flight each
+    int maxks = q.K / 512;                                // at least 512 k per slice
     if (maxks < 1) maxks = 1;
     KS = want < 1 ? 1 : (want > maxks ? maxks : want);
     kslice = ((q.K + KS - 1) / KS + 127) / 128 * 128;
+    if (kslice > GEMV_KSLICE_MAX) kslice = GEMV_KSLICE_MAX;           // the activation slice lives in LDS
     KS = (q.K + kslice - 1) / kslice;
 }
 
@@ -154,11 +155,14 @@ int launch_gemv(const Problem& q) {
         const int64_t need = (int64_t)gp.KS * gp.R * q.N * 4;
         if (!q.ws || q.ws_bytes < need) return BD_E_WORKSPACE;
     }
-    const int R = gp.R;
+    const int R = gp.R;      // rows >= R are computed and discarded, so the buckets are kept fine-grained
     if (R <= 1) return launch_gemv_r<DT, 1>(q, gp);
     if (R <= 2) return launch_gemv_r<DT, 2>(q, gp);
+    if (R <= 3) return launch_gemv_r<DT, 3>(q, gp);
     if (R <= 4) return launch_gemv_r<DT, 4>(q, gp);
+    if (R <= 6) return launch_gemv_r<DT, 6>(q, gp);
     if (R <= 8) return launch_gemv_r<DT, 8>(q, gp);
+    if (R <= 12) return launch_gemv_r<DT, 12>(q, gp);
     return launch_gemv_r<DT, 16>(q, gp);
 }
 

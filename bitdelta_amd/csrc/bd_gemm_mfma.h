@@ -55,7 +55,7 @@ struct GemmCfg {
     static constexpr int A_BYTES = BM * 128, BW_BYTES = BN * 8, W_BYTES = BN * 128;
     static constexpr int STAGE_D = A_BYTES + BW_BYTES;   // delta loop ring slot
     static constexpr int STAGE_B = A_BYTES + W_BYTES;    // base loop ring slot
-    static constexpr int NSB = 2;                        // base loop ring depth
+    static constexpr int NSB = (3 * STAGE_B <= 160 * 1024) ? 3 : 2;   // base loop ring depth (3 slots fit for BN = 128)
     static constexpr int A_PW = BM / 8 / NW;             // 1-KiB X pieces per wave per k-tile
     static constexpr int W_PW = BN / 8 / NW;             // 1-KiB W pieces per wave per k-tile
     static constexpr int BW_PIECES = BN / 32;            // 256-B sign-word pieces per k-tile ([2 x BN] words)
@@ -354,13 +354,18 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_kernel(const GemmParams p)
 #pragma unroll
             for (int i = 0; i < W_PW; ++i) dma16(w_voff[i], ws, base + w_lds[i]);
         };
+        constexpr int NSB = Cfg::NSB;
         __builtin_amdgcn_s_barrier();   // all waves left the delta ring
-        issue_b(0, 0);
+#pragma unroll
+        for (int t = 0; t < NSB - 1; ++t) issue_b(min(t, nk - 1), t);
+        int sb_c = 0, sb_i = NSB - 1;
         for (int kt = 0; kt < nk; ++kt) {
-            wait_vmcnt<0>();
+            wait_vmcnt<(NSB - 2) * Cfg::DPW_B>();
             __builtin_amdgcn_s_barrier();
-            issue_b(min(kt + 1, nk - 1), (kt + 1) & 1);
-            const char* st = smem + (kt & 1) * STAGE_B;
+            issue_b(min(kt + NSB - 1, nk - 1), sb_i);
+            const char* st = smem + sb_c * STAGE_B;
+            sb_c = (sb_c + 1 == NSB) ? 0 : sb_c + 1;
+            sb_i = (sb_i + 1 == NSB) ? 0 : sb_i + 1;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 u32x4_t xf[TM], wf[TN];

@@ -327,16 +327,18 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_pp_kernel(const GemmParams
 #pragma unroll
             for (int i = 0; i < W_PW; ++i) dma16(w_voff[i], ws, base + w_lds[i]);
         };
+        constexpr int NSB = Cfg::NSB;
         phase_end();                              // all waves left the delta ring
-        issue_b(0, 0);
-        wait_vmcnt<0>();
+#pragma unroll
+        for (int t = 0; t < NSB - 1; ++t) issue_b(min(t, nk - 1), t);
+        wait_vmcnt<(NSB - 2) * Cfg::DPW_B>();
         phase_end();
         if (grp == 1) phase_end();
+        int sb_c = 0, sb_i = NSB - 1;
         for (int kt = 0; kt < nk; ++kt) {
-            const char* st = smem + (kt & 1) * STAGE_B;
+            const char* st = smem + sb_c * STAGE_B;
             u32x4_t xa[TM], xb[TM], wa[TN], wb[TN];
-            const int kt_i = min(kt + 1, nk - 1);
-            if constexpr (Cfg::OPT & 1) issue_b(kt_i, (kt + 1) & 1);
+            const int kt_i = min(kt + NSB - 1, nk - 1);
 #pragma unroll
             for (int i = 0; i < TM; ++i) xa[i] = *(const u32x4_t*)(st + a_rd[0] + i * 4096);
 #pragma unroll
@@ -349,10 +351,10 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_pp_kernel(const GemmParams
             {
                 const char* as = a_src + (long long)kt_i * 128;
                 const char* ws = w_src + (long long)kt_i * 128;
-                const uint32_t base = lds0 + ((kt + 1) & 1) * STAGE_B;
+                const uint32_t base = lds0 + sb_i * STAGE_B;
                 constexpr int NPIECE = A_PW + W_PW, EVERY = (2 * TM * TN) / NPIECE > 0 ? (2 * TM * TN) / NPIECE : 1;
                 mfma_phase(wa, wb, xa, xb, [&](int t) {
-                    if constexpr (!(Cfg::OPT & 1)) {
+                    {
                         const int pc = t / EVERY;
                         if (t % EVERY == EVERY - 1 && pc < NPIECE) {
                             __builtin_amdgcn_sched_barrier(0);
@@ -373,10 +375,12 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_pp_kernel(const GemmParams
             for (int i = 0; i < TM; ++i) xb[i] = *(const u32x4_t*)(st + a_rd[3] + i * 4096);
 #pragma unroll
             for (int j = 0; j < TN; ++j) wb[j] = *(const u32x4_t*)(st + w_rd[3] + j * 4096);
-            wait_vmcnt<0>();
+            wait_vmcnt<(NSB - 2) * Cfg::DPW_B>();   // own pieces of tile kt+1 landed
             phase_end();
             mfma_phase(wa, wb, xa, xb, nothing);
             phase_end();
+            sb_c = (sb_c + 1 == NSB) ? 0 : sb_c + 1;
+            sb_i = (sb_i + 1 == NSB) ? 0 : sb_i + 1;
         }
         if (grp == 0) phase_end();
         wait_vmcnt<0>();

@@ -59,10 +59,18 @@ template <int DT> __device__ __forceinline__ void store_out(const GemvParams& p,
     else ((unsigned short*)p.C)[off] = (unsigned short)f32_to_half_bits<DT>(v);
 }
 
+// words of RB k32-rows x RMAX activation rows are fetched as one batch (RB*R independent 256-byte loads per wave in flight)
+template <int RMAX> struct GemvBatch { static constexpr int RB = (32 / RMAX) < 1 ? 1 : ((32 / RMAX) > 8 ? 8 : (32 / RMAX)); };
+
+constexpr int GEMV_KSLICE_MAX = 1024;   // k per slice (activation slice staged in LDS: RMAX x 1024 x 2 B = 32 KB at most)
+
 template <int DT, int RMAX>
 __global__ void __launch_bounds__(256) gemv_kernel(const GemvParams p) {
+    constexpr int RB = GemvBatch<RMAX>::RB;
+    constexpr int XROW = GEMV_KSLICE_MAX * 2 + 16;          // padded LDS row of the activation slice (bytes)
     __shared__ float red[4][RMAX][64];    // delta partials per wave
     __shared__ float bs[RMAX][64];        // base GEMV tile
+    __shared__ __attribute__((aligned(16))) char xs_lds[RMAX * XROW];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n0 = blockIdx.x * 64, ks = blockIdx.y;
@@ -70,61 +78,119 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvParams p) {
     uint32_t one2;
     asm volatile("v_mov_b32 %0, %1" : "=v"(one2) : "n"(One2<DT>::v));
 
-    // ---------------- base part: D[n][r] += W[n][k] x[r][k], one 16-column group per wave ----------------
+    // ---------------- delta part, stage 1: put the first batch of sign words in flight before anything else ----------------
+    const int nc = min(n0 + lane, p.N - 1);
+    const int i_lo = (k_lo >> 5) + wave, i_hi = k_hi >> 5;          // this wave's word rows: i_lo, i_lo+4, ...
+    auto load_batch = [&](uint32_t (&w)[RB][RMAX], int ib) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const int i = min(ib + 4 * rb, (p.K >> 5) - 1);          // clamped rows are skipped at compute time
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) {
+                const int b = min(r, p.R - 1) / p.M;                  // rows >= R repeat the last row (results discarded)
+                w[rb][r] = __builtin_nontemporal_load(&p.P[(long long)b * p.sPb + (long long)i * p.N + nc]);
+            }
+        }
+    };
+    uint32_t wcur[RB][RMAX];
+    load_batch(wcur, i_lo);
+
+    // ---------------- activation slice -> LDS (once per block; rows >= R repeat the last row) ----------------
+    {
+        const int kn = k_hi - k_lo;                                   // multiple of 32
+        for (int idx = threadIdx.x; idx < RMAX * (kn >> 3); idx += 256) {
+            const int r = idx / (kn >> 3), c = idx - r * (kn >> 3);
+            const int rr = min(r, p.R - 1), b = rr / p.M, m = rr - b * p.M;
+            *(u32x4_t*)(xs_lds + r * XROW + c * 16) =
+                *(const u32x4_t*)(p.X + (long long)b * p.sXb + (long long)m * p.sXm + k_lo + c * 8);
+        }
+    }
+    __syncthreads();
+
+    // ---------------- base part: D[n][r] += W[n][k] x[r][k], one 16-column group per wave (weights streamed once) -------
+    auto base_part = [&]() {
     if (p.W) {
         const int li = lane & 15, g = lane >> 4;
         const int nw = min(n0 + wave * 16 + li, p.N - 1);
         const unsigned short* wr = p.W + (long long)nw * p.ldw + 8 * g;
-        const bool xvalid = li < p.R;
-        const int xb = xvalid ? li / p.M : 0, xm = xvalid ? li - xb * p.M : 0;    // idle lanes re-read row 0, then mask
-        const unsigned short* xr = p.X + (long long)xb * p.sXb + (long long)xm * p.sXm + 8 * g;
-        const uint32_t keep = xvalid ? 0xffffffffu : 0u;
-        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-        for (int k = k_lo; k < k_hi; k += 32) {
+        const char* xl = xs_lds + min(li, RMAX - 1) * XROW + 16 * g;  // MFMA column li <-> activation row li (rows >= RMAX unused)
+        const uint32_t keep = (li < p.R) ? 0xffffffffu : 0u;
+        f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        int k = k_lo;
+        for (; k + 256 <= k_hi; k += 256) {                          // 8 x (1 KiB of W per wave) in flight
+            u32x4_t wf[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wf[u] = __builtin_nontemporal_load((const u32x4_t*)(wr + k + 32 * u));
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                const u32x4_t x0 = *(const u32x4_t*)(xl + (k - k_lo + 32 * u) * 2) & u32x4_t{keep, keep, keep, keep};
+                const u32x4_t x1 = *(const u32x4_t*)(xl + (k - k_lo + 32 * u + 32) * 2) & u32x4_t{keep, keep, keep, keep};
+                acc0 = mfma16<DT>(wf[u], x0, acc0);
+                acc1 = mfma16<DT>(wf[u + 1], x1, acc1);
+            }
+        }
+        for (; k < k_hi; k += 32) {
             const u32x4_t wf = *(const u32x4_t*)(wr + k);
-            u32x4_t xf = *(const u32x4_t*)(xr + k);
-            xf = xf & u32x4_t{keep, keep, keep, keep};
-            acc = mfma16<DT>(wf, xf, acc);
+            const u32x4_t xf = *(const u32x4_t*)(xl + (k - k_lo) * 2) & u32x4_t{keep, keep, keep, keep};
+            acc0 = mfma16<DT>(wf, xf, acc0);
         }
         // lane holds r = li, n_local = 4g + reg
         if (li < RMAX) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bs[li][wave * 16 + 4 * g + e] = acc[e];
+            for (int e = 0; e < 4; ++e) bs[li][wave * 16 + 4 * g + e] = acc0[e] + acc1[e];
         }
     }
+    };
 
-    // ---------------- delta part: lane = column, waves interleave the slice's word rows ----------------
-    float dacc[RMAX];
+    // ---------------- delta part, stage 2: lane = column; signs -> +-1.0 pairs -> v_dot2c with the activation pairs --------
+    // Branch-free over the RMAX rows and 4 independent accumulators per row: the 16 dot2 of one word would otherwise be one
+    // dependent chain (measured: 5x the HBM time per tenant).  Activation pairs come from LDS as wave-uniform broadcasts.
+    float dacc[RMAX][4];
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) dacc[r] = 0.f;
-    const int nc = min(n0 + lane, p.N - 1);
-    for (int i = (k_lo >> 5) + wave; i < (k_hi >> 5); i += 4) {
+    for (int r = 0; r < RMAX; ++r)
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-            if (r < p.R) {
-                const int b = r / p.M, m = r - b * p.M;
-                const uint32_t w = ~p.P[(long long)b * p.sPb + (long long)i * p.N + nc];
-                const uint32_t* xs = (const uint32_t*)(p.X + (long long)b * p.sXb + (long long)m * p.sXm + 32 * i);
-                const uint32_t rlo = __builtin_amdgcn_perm(w, w, 0x01000100u), rhi = __builtin_amdgcn_perm(w, w, 0x03020302u);
-                float a = dacc[r];
+        for (int c = 0; c < 4; ++c) dacc[r][c] = 0.f;
+    // The base part is load-bound and the delta part VALU-bound; blocks alternate the order so that, CU-wide, one half's
+    // weight stream overlaps the other half's sign expansion (measured: the two phases otherwise simply add up).
+    const bool delta_first = ((blockIdx.x + blockIdx.y) & 1) != 0;
+    if (!delta_first) base_part();
+    for (int ib = i_lo; ib < i_hi; ib += 4 * RB) {
+        uint32_t wnext[RB][RMAX];
+        const bool more = ib + 4 * RB < i_hi;
+        if (more) load_batch(wnext, ib + 4 * RB);                    // next batch in flight under this batch's VALU work
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int qq = q & 7;
-                    u16x2_t v = __builtin_bit_cast(u16x2_t, q < 8 ? rlo : rhi);
-                    u16x2_t sh;
-                    sh.x = (unsigned short)(15 - 2 * qq);
-                    sh.y = (unsigned short)(14 - 2 * qq);
-                    v = v << sh;
-                    const uint32_t sd = (__builtin_bit_cast(uint32_t, v) & 0x80008000u) | one2;
-                    a = dot2acc<DT>(sd, xs[q], a);
+        for (int rb = 0; rb < RB; ++rb) {
+            const int i = ib + 4 * rb;
+            if (i < i_hi) {
+                const int koff = (32 * i - k_lo) * 2;
+#pragma unroll
+                for (int r = 0; r < RMAX; ++r) {
+                    const uint32_t w = ~wcur[rb][r];
+                    const uint32_t rlo = (w & 0xffffu) | ((w << 15) & 0x7fff0000u);     // chunk | (chunk>>1)<<16, see bd_gemm_pp.h
+                    const uint32_t rhi = (w >> 16) | ((w >> 1) & 0x7fff0000u);
+                    const u32x4_t* xv = (const u32x4_t*)(xs_lds + r * XROW + koff);  // 64 bytes = 16 pairs, same address in every lane
+                    u32x4_t x4[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) x4[c] = xv[c];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const uint32_t rep = q < 8 ? rlo : rhi;
+                        const uint32_t sd = ((rep << (15 - 2 * (q & 7))) & 0x80008000u) | one2;
+                        dacc[r][q & 3] = dot2acc<DT>(sd, x4[q >> 2][q & 3], dacc[r][q & 3]);
+                    }
                 }
-                dacc[r] = a;
             }
         }
-    }
+        if (more) {
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) red[wave][r][lane] = dacc[r];
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int r = 0; r < RMAX; ++r) wcur[rb][r] = wnext[rb][r];
+        }
+    }
+    if (delta_first) base_part();
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) red[wave][r][lane] = (dacc[r][0] + dacc[r][1]) + (dacc[r][2] + dacc[r][3]);
     __syncthreads();
 
     // ---------------- combine: wave w finishes rows r = w, w+4, ... ----------------
