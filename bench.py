@@ -243,6 +243,13 @@ def main():
         return
     mb = delta_gemm_microbench(dev)
     achieved = k_flops / k_ms * 1e-9 if k_ms > 0 else 0.0
+    traffic = None
+    try:    # PMC counters cannot be read from inside the process: the per-launch figure comes from the committed rocprofv3 passes
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        traffic = tj["fused_gemm"]["traffic_bytes_per_launch"]
+        mb["traffic_bytes_per_launch"] = tj["delta_gemm_4096"]["traffic_bytes_per_launch"]
+    except Exception:
+        pass
     out = {
         "metric": "W1A16 binary-delta GEMM TFLOP/s + tokens/s, Llama-2-7B+Vicuna delta, 1/2/4/8 MI355X "
                   "(value = end-to-end prefill tokens/s; delta_gemm.tflops = the GEMM figure)",
@@ -254,7 +261,10 @@ def main():
                    "seq_len": args.seq, "global_batch": world, "parallelism": f"dp{world} independent replicas, no collective",
                    "valid": args.layers is None},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+                     "traffic_note": "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes "
+                                     "(profiles/r01_traffic.json); algorithmic bytes per launch = algorithmic_bytes_total / launches",
+                     "algorithmic_bytes_total": k_bytes,
                      "kernel": "bd::delta_gemm_pp_kernel<bf16, 256x128 | 256x256 tile, fused> (x.W^T + alpha*(x.S), 4*M*N*K flop/launch)",
                      "launches": n_launch, "kernel_ms_total": k_ms, "algorithmic_flops_total": k_flops,
                      "share_of_step_time": (k_ms / 1e3) / dt if dt > 0 else None},

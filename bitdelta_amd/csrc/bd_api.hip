@@ -166,6 +166,17 @@ int launch_gemv(const Problem& q) {
     return launch_gemv_r<DT, 16>(q, gp);
 }
 
+inline int num_cus() {
+    static int cus = 0;   // benign race: idempotent
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        cus = n;
+    }
+    return cus;
+}
+
 inline GemmParams make_params(const Problem& q, int BM, int BN) {
     GemmParams p;
     p.A = (const char*)q.A; p.P = q.P; p.C = (char*)q.C; p.W = (const char*)q.W; p.alpha = q.alpha;
@@ -175,6 +186,9 @@ inline GemmParams make_params(const Problem& q, int BM, int BN) {
     p.sAm = (int)q.sAm; p.sCm = (int)q.sCm; p.ldw = (int)q.ldw;
     p.sAlb = (int)q.sAlb; p.gsz = q.N / q.G;
     p.round_mode = q.round_mode; p.accumulate = q.accumulate;
+    // m-fastest runs (an XCD owns a column slice of W) measured +5 % when the whole problem is one round of tiles and W is the
+    // larger operand, -4 % on multi-round shapes (profiles/r01_tile_order.txt): use it only in the first case.
+    p.m_fastest = (q.W != nullptr && (int64_t)q.N > (int64_t)q.M && (int64_t)p.tiles_m * p.tiles_n * q.B <= num_cus()) ? 1 : 0;
     return p;
 }
 
@@ -203,17 +217,6 @@ int launch_generic(const Problem& q) {
     dim3 grid((unsigned)((q.N + 63) / 64), (unsigned)((q.M + 63) / 64), (unsigned)q.B);
     hipLaunchKernelGGL((delta_gemm_generic_kernel<DT, FUSED, OUT_F32>), grid, dim3(256), 0, q.st, p);
     return launch_status();
-}
-
-inline int num_cus() {
-    static int cus = 0;   // benign race: idempotent
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
-        cus = n;
-    }
-    return cus;
 }
 
 // 256x256 vs 256x128 ping-pong tile: rounds of CU-wide tile waves x measured relative cost of one tile

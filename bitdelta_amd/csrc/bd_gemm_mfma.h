@@ -39,7 +39,17 @@ struct GemmParams {
     int sAlb, gsz;            // alpha batch stride (0 = broadcast), columns per scale group
     int round_mode;           // 1: fp32 -> fp16 -> out (reference epilogue); 0: fp32 -> out
     int accumulate;           // delta-only: C = C_in + alpha * acc  (adds the delta onto an existing base GEMM result)
+    int m_fastest;            // tile order inside an XCD's contiguous run: 0 = n fastest (X row panel shared in L2; right when
+                              // the other operand is the tiny packed mask), 1 = m fastest (the XCD owns a column slice of W;
+                              // right for the fused kernel when N*K > M*K: measured 6x algorithmic L2->fabric bytes otherwise)
 };
+
+__device__ __forceinline__ void tile_coords(const GemmParams& p, int wg, int& tile_m, int& tile_n) {
+    const int inner = p.m_fastest ? p.tiles_m : p.tiles_n;      // branch-free: keeps the values provably wave-uniform
+    const int q = wg / inner, r = wg - q * inner;
+    tile_m = __builtin_amdgcn_readfirstlane(p.m_fastest ? r : q);
+    tile_n = __builtin_amdgcn_readfirstlane(p.m_fastest ? q : r);
+}
 
 // OPT bits (tuning switches, measured in DESIGN.md): 1 = sched_group_barrier MFMA/VALU/DS interleave of the delta
 // k-step, 2 = s_setprio(1) around the MFMA clusters.
@@ -190,7 +200,8 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_kernel(const GemmParams p)
     // ---- tile mapping: XCD-aware, n fastest inside an XCD's run so neighbours share the X row panel in L2
     const int nwg = p.tiles_m * p.tiles_n;
     const int wg = xcd_remap(blockIdx.x, nwg);
-    const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
+    int tile_m, tile_n;
+    tile_coords(p, wg, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int b = blockIdx.y;
     const int nk = p.K >> 6;

@@ -31,7 +31,8 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_sp_kernel(const GemmParams
 
     const int nwg = p.tiles_m * p.tiles_n;
     const int wg = xcd_remap(blockIdx.x, nwg);
-    const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
+    int tile_m, tile_n;
+    tile_coords(p, wg, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int b = blockIdx.y;
     const int nk = p.K >> 6;
