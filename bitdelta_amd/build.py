@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "bd_api.hip")
 OUT = os.path.join(HERE, "lib", "libbitdelta_hip.so")
 DEPS = [os.path.join(HERE, "csrc", f) for f in
-        ("bd_api.hip", "bd_common.h", "bd_bits.h", "bd_gemm_mfma.h", "bd_gemm_pp.h", "bd_gemm_generic.h", "bd_gemv.h")] + \
+        ("bd_api.hip", "bd_common.h", "bd_bits.h", "bd_gemm_mfma.h", "bd_gemm_pp.h", "bd_gemm_pf.h", "bd_gemm_generic.h", "bd_gemv.h")] + \
        [os.path.join(os.path.dirname(HERE), "include", "bitdelta_hip.h")]
 
 

@@ -5,6 +5,7 @@
 #include "bd_gemm_generic.h"
 #include "bd_gemm_mfma.h"
 #include "bd_gemm_pp.h"
+#include "bd_gemm_pf.h"
 #include "bd_gemv.h"
 
 using namespace bd;
@@ -192,14 +193,16 @@ inline GemmParams make_params(const Problem& q, int BM, int BN) {
     return p;
 }
 
-template <class Cfg, bool PP> struct TileKernel { static auto get() { return delta_gemm_kernel<Cfg>; } };
-template <class Cfg> struct TileKernel<Cfg, true> { static auto get() { return delta_gemm_pp_kernel<Cfg>; } };
+template <class Cfg, int SCHED> struct TileKernel { static auto get() { return delta_gemm_kernel<Cfg>; } };
+template <class Cfg> struct TileKernel<Cfg, 1> { static auto get() { return delta_gemm_pp_kernel<Cfg>; } };
+template <class Cfg> struct TileKernel<Cfg, 2> { static auto get() { return delta_gemm_pf_kernel<Cfg>; } };
 
-// PP = ping-pong schedule (bd_gemm_pp.h): the 256x256 tile; the smaller tiles use the single-barrier kernel.
-template <class Cfg, bool PP = false>
+// SCHED 0 = single barrier per k-tile (bd_gemm_mfma.h; the small-M tiles), 1 = half-tile ping-pong (bd_gemm_pp.h),
+// 2 = full-tile ping-pong (bd_gemm_pf.h; the shipped schedule wherever its ring fits).
+template <class Cfg, int SCHED = 0>
 int launch_tile(const Problem& q) {
     const GemmParams p = make_params(q, Cfg::BM, Cfg::BN);
-    auto kern = TileKernel<Cfg, PP>::get();
+    auto kern = TileKernel<Cfg, SCHED>::get();
     static bool attr_set = false;   // benign race: idempotent
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess)
@@ -241,13 +244,17 @@ int dispatch3(const Problem& q) {
         else v = 3;
     } else {
         if (v == 200 && !gemv_ok(q)) return BD_E_BAD_SHAPE;
-        if (v >= 0 && v <= 5 && !fast_ok(q)) return BD_E_BAD_SHAPE;
+        if (v >= 0 && v <= 7 && !fast_ok(q)) return BD_E_BAD_SHAPE;
     }
     t_last_variant = v;
     switch (v) {
-        case 0: return launch_tile<GemmCfg<DT, 256, 256, 2, 4, 4, FUSED, OUT_F32, 2>, true>(q);
+        case 0:
+            if constexpr (FUSED) return launch_tile<GemmCfg<DT, 256, 256, 2, 4, 4, FUSED, OUT_F32, 2>, 1>(q);   // 2-slot base ring
+            else return launch_tile<GemmCfg<DT, 256, 256, 2, 4, 4, FUSED, OUT_F32, 0>, 2>(q);
+        case 6: return launch_tile<GemmCfg<DT, 256, 256, 2, 4, 4, FUSED, OUT_F32, 2>, 1>(q);      // half-tile ping-pong (A/B reference)
+        case 7: return launch_tile<GemmCfg<DT, 256, 128, 2, 4, 4, FUSED, OUT_F32, 2>, 1>(q);      // half-tile ping-pong 256x128 (A/B)
         case 4: return launch_tile<GemmCfg<DT, 256, 256, 2, 4, 4, FUSED, OUT_F32>>(q);   // single-barrier 256x256 (A/B reference)
-        case 5: return launch_tile<GemmCfg<DT, 256, 128, 2, 4, 4, FUSED, OUT_F32, 2>, true>(q);
+        case 5: return launch_tile<GemmCfg<DT, 256, 128, 2, 4, 4, FUSED, OUT_F32, 0>, 2>(q);
         case 1: return launch_tile<GemmCfg<DT, 128, 256, 1, 4, 4, FUSED, OUT_F32>>(q);
         case 2: return launch_tile<GemmCfg<DT, 64, 256, 1, 4, 4, FUSED, OUT_F32>>(q);
         case 3: return launch_tile<GemmCfg<DT, 32, 256, 1, 4, 4, FUSED, OUT_F32>>(q);

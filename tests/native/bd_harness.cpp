@@ -17,6 +17,7 @@
 #include "../../bitdelta_amd/csrc/bd_gemm_mfma.h"
 #include "../../bitdelta_amd/csrc/bd_gemm_pp.h"
 #include "../../bitdelta_amd/csrc/bd_gemm_sp.h"
+#include "../../bitdelta_amd/csrc/bd_gemm_pf.h"
 #include "../../include/bitdelta_hip.h"
 
 #define HIPCHECK(x)                                                                      \
@@ -196,6 +197,7 @@ static int run_case(const char* tag, int B, int M, int N, int K, int dt, int out
 template <class Cfg, int PP> struct KernSel { static auto get() { return bd::delta_gemm_kernel<Cfg>; } };
 template <class Cfg> struct KernSel<Cfg, 1> { static auto get() { return bd::delta_gemm_pp_kernel<Cfg>; } };
 template <class Cfg> struct KernSel<Cfg, 2> { static auto get() { return bd::delta_gemm_sp_kernel<Cfg>; } };
+template <class Cfg> struct KernSel<Cfg, 3> { static auto get() { return bd::delta_gemm_pf_kernel<Cfg>; } };
 
 template <class Cfg, int PP = 0>
 static void run_cfg(const char* name, int M, int N, int K, int iters, int nsamples) {
@@ -254,6 +256,17 @@ static void sweep(int M, int N, int K, int iters) {
 
 #define CFGPP(name, ...) run_cfg<GemmCfg<__VA_ARGS__>, 1>(name, M, N, K, iters, 4096)
 #define CFGSP(name, ...) run_cfg<GemmCfg<__VA_ARGS__>, 2>(name, M, N, K, iters, 4096)
+#define CFGPF(name, ...) run_cfg<GemmCfg<__VA_ARGS__>, 3>(name, M, N, K, iters, 4096)
+static void sweep_pf(int M, int N, int K, int iters) {
+    for (int rep = 0; rep < 3; ++rep) {      // interleaved A/B rounds in one process
+        CFGPP("pp_ns4_noprio", DT_BF16, 256, 256, 2, 4, 4, false, false, 2);
+        CFGPF("pf_ns4", DT_BF16, 256, 256, 2, 4, 4, false, false, 0);
+        CFGPF("pf_ns4_prio", DT_BF16, 256, 256, 2, 4, 4, false, false, 2);
+        CFGPF("pf_256x128", DT_BF16, 256, 128, 2, 4, 4, false, false, 0);
+        CFGPP("pp_256x128", DT_BF16, 256, 128, 2, 4, 4, false, false, 2);
+    }
+}
+
 static void sweep_sp(int M, int N, int K, int iters) {
     for (int rep = 0; rep < 2; ++rep) {      // interleaved A/B: two rounds in one process
         CFGPP("pp_ns4_noprio", DT_BF16, 256, 256, 2, 4, 4, false, false, 2);
@@ -313,6 +326,42 @@ static void ablate(int M, int N, int K, int iters) {
 #undef ABL
 }
 
+// HBM-bound bit-plane kernels: time + algorithmic bytes (spot-checked for self-consistency: unpack(pack(x)) == x, merge sign)
+static void bits_bench() {
+    const int64_t N = 11008, K = 4096;      // Llama-2-7B gate_proj sized
+    std::vector<uint8_t> hb((size_t)K * N);
+    for (auto& v : hb) v = (uint8_t)(rng() & 1);
+    uint8_t *dbits, *dbits2; uint32_t* dwords; uint16_t *dW, *dF; float *dcoeff, *dws;
+    HIPCHECK(hipMalloc(&dbits, (size_t)K * N)); HIPCHECK(hipMalloc(&dbits2, (size_t)K * N)); HIPCHECK(hipMalloc(&dwords, (size_t)K / 32 * N * 4));
+    HIPCHECK(hipMalloc(&dW, (size_t)N * K * 2)); HIPCHECK(hipMalloc(&dF, (size_t)N * K * 2)); HIPCHECK(hipMalloc(&dcoeff, 4));
+    const int64_t wsb = bd_binarize_workspace_bytes(N, K);
+    HIPCHECK(hipMalloc(&dws, wsb));
+    HIPCHECK(hipMemcpy(dbits, hb.data(), hb.size(), hipMemcpyHostToDevice));
+    std::vector<uint16_t> hw((size_t)N * K), hf((size_t)N * K);
+    for (size_t i = 0; i < hw.size(); ++i) { const float w = 0.02f * nrand(); hw[i] = f_to_bf16(w); hf[i] = f_to_bf16(bf16_to_f(hw[i]) + 5e-4f * nrand()); }
+    HIPCHECK(hipMemcpy(dW, hw.data(), hw.size() * 2, hipMemcpyHostToDevice)); HIPCHECK(hipMemcpy(dF, hf.data(), hf.size() * 2, hipMemcpyHostToDevice));
+    auto report = [&](const char* name, double ms, double bytes, int ok) {
+        printf("{\"tag\":\"bits\",\"name\":\"%s\",\"N\":%lld,\"K\":%lld,\"ms\":%.5f,\"gbps\":%.1f,\"frac_of_8TBs\":%.3f,\"ok\":%d}\n", name, (long long)N, (long long)K, ms,
+               bytes / ms * 1e-6, bytes / ms * 1e-6 / 8000.0, ok);
+        fflush(stdout);
+    };
+    double ms = time_ms([&] { bd_pack(dbits, 1, K, N, K * N, N, 1, dwords, 32, 0); }, 3, 20);
+    report("pack_rowmajor", ms, (double)K * N + (double)K * N / 8, 1);
+    ms = time_ms([&] { bd_unpack(dwords, 1, K / 32, N, dbits2, 32, 0); }, 3, 20);
+    std::vector<uint8_t> hb2((size_t)K * N);
+    HIPCHECK(hipMemcpy(hb2.data(), dbits2, hb2.size(), hipMemcpyDeviceToHost));
+    report("unpack", ms, (double)K * N + (double)K * N / 8, memcmp(hb.data(), hb2.data(), hb.size()) == 0);
+    // k-major view (what BinaryDiff.__init__ packs: bits stored [N,K], logical [K,N] with s_k = 1, s_n = K)
+    ms = time_ms([&] { bd_pack(dbits, 1, K, N, K * N, 1, K, dwords, 32, 0); }, 3, 20);
+    report("pack_kmajor", ms, (double)K * N + (double)K * N / 8, 1);
+    ms = time_ms([&] { bd_binarize(dW, dF, N, K, K, BD_BF16, (int32_t*)dwords, dcoeff, dws, wsb, 0); }, 3, 20);
+    float hc = 0; HIPCHECK(hipMemcpy(&hc, dcoeff, 4, hipMemcpyDeviceToHost));
+    report("binarize", ms, 4.0 * N * K + (double)K * N / 8, hc > 3.5e-4f && hc < 4.5e-4f);
+    ms = time_ms([&] { bd_merge_delta(dW, K, (const int32_t*)dwords, dcoeff, N, K, BD_BF16, 0); }, 3, 20);
+    report("merge_delta", ms, 4.0 * N * K + (double)K * N / 8, 1);
+    hipFree(dbits); hipFree(dbits2); hipFree(dwords); hipFree(dW); hipFree(dF); hipFree(dcoeff); hipFree(dws);
+}
+
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "check";
     hipDeviceProp_t prop;
@@ -325,7 +374,7 @@ int main(int argc, char** argv) {
         // every kernel family, both dtypes, delta-only and fused, broadcast and per-tenant masks
         for (int dt : {BD_BF16, BD_F16})
             for (int fused : {0, 1}) {
-                for (int v : {0, 1, 2, 3, 4, 5, 100})
+                for (int v : {0, 1, 2, 3, 4, 5, 6, 7, 100})
                     fails += run_case("tile", 2, 200, 520, 256, dt, BD_F32, fused, 2, v, 0, S);
                 fails += run_case("tile_bcast", 3, 130, 300, 128, dt, dt, fused, 1, 0, 0, S);
                 fails += run_case("auto_big", 1, 512, 768, 1024, dt, dt, fused, 1, -1, 0, S);
@@ -355,6 +404,21 @@ int main(int argc, char** argv) {
         fails += run_case("decode_fused_down", 6, 1, 4096, 14336, BD_F16, BD_F16, 1, 6, -1, 50, 2048);
         fails += run_case("decode_fused_kv", 6, 1, 1024, 4096, BD_F16, BD_F16, 1, 6, -1, 50, 2048);
         fails += run_case("prefill64_t6", 6, 64, 4096, 4096, BD_F16, BD_F16, 1, 6, -1, it, 2048);
+    } else if (mode == "bits") {
+        bits_bench();
+    } else if (mode == "pfab") {
+        // shipped (full-tile ping-pong) vs half-tile ping-pong through the dispatcher, model shapes, 3 interleaved rounds
+        for (int rep = 0; rep < 3; ++rep)
+            for (int v : {5, 7}) {
+                fails += run_case("fused_q", 1, 2048, 4096, 4096, BD_BF16, BD_BF16, 1, 1, v, 20, 1024);
+                fails += run_case("fused_gate", 1, 2048, 11008, 4096, BD_BF16, BD_BF16, 1, 1, v, 20, 1024);
+                fails += run_case("fused_down", 1, 2048, 4096, 11008, BD_BF16, BD_BF16, 1, 1, v, 20, 1024);
+                fails += run_case("delta_q", 1, 2048, 4096, 4096, BD_BF16, BD_BF16, 0, 1, v, 20, 1024);
+            }
+        for (int rep = 0; rep < 3; ++rep)
+            for (int v : {0, 6}) fails += run_case("delta_4096", 1, 4096, 4096, 4096, BD_BF16, BD_BF16, 0, 1, v, 20, 1024);
+    } else if (mode == "pf") {
+        sweep_pf(argc > 2 ? atoi(argv[2]) : 4096, 4096, argc > 3 ? atoi(argv[3]) : 4096, 30);
     } else if (mode == "sp") {
         sweep_sp(argc > 2 ? atoi(argv[2]) : 4096, 4096, argc > 3 ? atoi(argv[3]) : 4096, 30);
     } else if (mode == "pp") {

@@ -168,7 +168,7 @@ SHAPES = [
     (16, 128, 512, 1024, 16, None),                                                    # notebook check shape (ipynb:519-531)
     (1, 512, 512, 512, 1, None),                                                       # notebook 2-D check (ipynb:281-292)
     (2, 200, 256, 520, 2, 0), (2, 200, 256, 520, 2, 1), (2, 200, 256, 520, 2, 2), (2, 200, 256, 520, 2, 3),
-    (2, 200, 256, 520, 2, 4), (2, 200, 256, 520, 2, 5), (2, 200, 256, 520, 2, 100),
+    (2, 200, 256, 520, 2, 4), (2, 200, 256, 520, 2, 5), (2, 200, 256, 520, 2, 6), (2, 200, 256, 520, 2, 7), (2, 200, 256, 520, 2, 100),
     (3, 130, 128, 300, 1, 0),                                                          # broadcast mask
     (1, 70, 64, 77, 1, None),                                                          # odd N
     (6, 1, 1024, 1000, 6, None), (3, 2, 512, 512, 3, None), (16, 1, 2048, 256, 1, None), (1, 1, 4096, 4096, 1, None),  # decode
