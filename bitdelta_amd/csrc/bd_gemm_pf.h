@@ -8,6 +8,8 @@
 // S: 16*TN VGPRs) on top of the 128 accumulator registers (242 VGPRs at 256x256, no spills).
 // Measured in the same process as bd_gemm_pp.h (profiles/r01_pf_vs_pp.txt): +8..11 % at 256x256 and 256x128.
 // Fused mode: delta loop -> acc *= alpha -> base loop (X and W tiles by LDS-DMA, 3-slot ring) in the same schedule.
+// Rejected here as well (profiles/r01_pp_timeline.txt): handing the pipe over 2/4/8 MFMAs before the phase end -- fewer ticks in
+// the traced block but 17 % MORE GPU cycles overall (GRBM_GUI_ACTIVE 241 k vs 205 k) and 1110 vs 1240 TF.
 //
 // Ring safety (NS >= 4): reads of tile kt's slot happen in L(kt) (phase 2kt for group 0, 2kt+1 for group 1).  Its refill (tile
 // kt+NS) is issued in M(kt+1), phases >= 2kt+3.  Tile kt+1 is first read in L(kt+1) (phase 2kt+2); every wave waits
@@ -16,6 +18,20 @@
 #include "bd_gemm_mfma.h"
 
 namespace bd {
+
+#ifdef BD_TRACE
+__device__ unsigned long long bd_trace_pf[2][8][4];
+#define BD_PF_STAMP(id)                                                                                      \
+    do {                                                                                                     \
+        if (blockIdx.x == 0 && (wave & 3) == 0 && kt >= 16 && kt < 24) {                                     \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                      \
+            if (lane == 0) bd_trace_pf[wave >> 2][kt - 16][id] = t_;                                         \
+        }                                                                                                    \
+    } while (0)
+#else
+#define BD_PF_STAMP(id) do { } while (0)
+#endif
+
 
 template <class Cfg>
 __global__ void __launch_bounds__(Cfg::NT) delta_gemm_pf_kernel(const GemmParams p) {
@@ -110,6 +126,7 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_pf_kernel(const GemmParams
         const char* st = smem + slot_c * STAGE_D;
         u32x4_t xf[4][TM], sf[4][TN];
         // ---------------- L(kt)
+        BD_PF_STAMP(0);
         uint32_t wraw[TN];
         {
             const uint32_t waddr = lds0 + slot_c * STAGE_D + bw_rd;
@@ -138,7 +155,12 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_pf_kernel(const GemmParams
                 }
         }
         wait_vmcnt<(NS - 3) * Cfg::DPW_D>();      // own pieces of tile kt+1 landed
+#ifdef BD_TRACE
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+#endif
+        BD_PF_STAMP(1);
         phase_end();
+        BD_PF_STAMP(2);
         // ---------------- M(kt)
         {
             const int kt_i = min(kt + NS - 1, nk - 1);
@@ -161,6 +183,7 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_pf_kernel(const GemmParams
             }
             if constexpr (Cfg::OPT & 2) __builtin_amdgcn_s_setprio(0);
         }
+        BD_PF_STAMP(3);
         phase_end();
         slot_c = (slot_c + 1 == NS) ? 0 : slot_c + 1;
         slot_i = (slot_i + 1 == NS) ? 0 : slot_i + 1;

@@ -417,6 +417,11 @@ int main(int argc, char** argv) {
             }
         for (int rep = 0; rep < 3; ++rep)
             for (int v : {0, 6}) fails += run_case("delta_4096", 1, 4096, 4096, 4096, BD_BF16, BD_BF16, 0, 1, v, 20, 1024);
+    } else if (mode == "pf_pmc") {
+        const int M = 4096, N = 4096, K = 4096, iters = 10;
+        CFGPP("pp_ns4_noprio", DT_BF16, 256, 256, 2, 4, 4, false, false, 2);
+        CFGPF("pf_ns4", DT_BF16, 256, 256, 2, 4, 4, false, false, 0);
+        CFG("v1_256x256_2x4_ns4", DT_BF16, 256, 256, 2, 4, 4, false, false, 0);
     } else if (mode == "pf") {
         sweep_pf(argc > 2 ? atoi(argv[2]) : 4096, 4096, argc > 3 ? atoi(argv[3]) : 4096, 30);
     } else if (mode == "sp") {

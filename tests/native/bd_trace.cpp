@@ -6,6 +6,7 @@
 #include <string.h>
 #include <vector>
 #include "../../bitdelta_amd/csrc/bd_gemm_pp.h"
+#include "../../bitdelta_amd/csrc/bd_gemm_pf.h"
 using namespace bd;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("hip error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(2);} } while (0)
 template <class Cfg> void run(const char* name) {
@@ -38,7 +39,37 @@ template <class Cfg> void run(const char* name) {
         }
     hipFree(dA); hipFree(dP); hipFree(dC);
 }
+template <class Cfg> void run_pf(const char* name) {
+    const int M = 4096, N = 4096, K = 4096;
+    void *dA, *dP, *dC;
+    CK(hipMalloc(&dA, (size_t)M * K * 2)); CK(hipMalloc(&dP, (size_t)K / 32 * N * 4)); CK(hipMalloc(&dC, (size_t)M * N * 4));
+    std::vector<unsigned short> a((size_t)M * K); std::vector<unsigned> pw((size_t)K / 32 * N);
+    unsigned long long st = 88172645463325252ull;
+    auto rng = [&] { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+    for (auto& v : a) { float f = ((rng() >> 40) / 16777216.0f - 0.5f) * 4.f; unsigned u; memcpy(&u, &f, 4); v = u >> 16; }
+    for (auto& v : pw) v = (unsigned)rng();
+    CK(hipMemcpy(dA, a.data(), a.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dP, pw.data(), pw.size() * 4, hipMemcpyHostToDevice));
+    GemmParams p{};
+    p.A = (const char*)dA; p.P = (const int32_t*)dP; p.C = (char*)dC; p.M = M; p.N = N; p.K = K;
+    p.tiles_m = M / Cfg::BM; p.tiles_n = N / Cfg::BN; p.sAb = (long long)M * K; p.sCb = (long long)M * N; p.sAm = K; p.sCm = N; p.gsz = N;
+    auto kern = delta_gemm_pf_kernel<Cfg>;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+    for (int it = 0; it < 5; ++it) hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(Cfg::NT), Cfg::LDS_BYTES, 0, p);
+    CK(hipDeviceSynchronize());
+    unsigned long long t[2][8][4];
+    CK(hipMemcpyFromSymbol(t, HIP_SYMBOL(bd_trace_pf), sizeof(t)));
+    printf("== %s   (ticks; L = loads+expansion | wait+barrier | M = 32 MFMAs + DMA | barrier -> next L)\n", name);
+    for (int g = 0; g < 2; ++g)
+        for (int k = 2; k < 4; ++k) {
+            auto* s = t[g][k];
+            printf("grp%d kt%2d: L %5lld  b %5lld  M %5lld  b+ %5lld   tile %6lld\n", g, 16 + k, (long long)(s[1] - s[0]), (long long)(s[2] - s[1]),
+                   (long long)(s[3] - s[2]), (long long)(t[g][k + 1][0] - s[3]), (long long)(t[g][k + 1][0] - s[0]));
+        }
+    hipFree(dA); hipFree(dP); hipFree(dC);
+}
 int main() {
+    run_pf<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 0>>("full-tile ping-pong 256x256");
+    run_pf<GemmCfg<DT_BF16, 256, 128, 2, 4, 4, false, false, 0>>("full-tile ping-pong 256x128");
     run<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 2>>("strict, noprio, 1 MFMA : 2 VALU");
     run<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 2 + 64>>("strict, noprio, 2 MFMA : 4 VALU");
     run<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 2 + 512>>("strict, noprio, 4 MFMA : 8 VALU");
