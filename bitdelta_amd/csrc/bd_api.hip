@@ -11,6 +11,7 @@
 using namespace bd;
 
 static int g_forced_variant = -1;
+static int g_gemv_target_blocks = 512;
 static thread_local int t_last_variant = -1;
 
 extern "C" int bd_version(void) { return 1; }
@@ -116,14 +117,18 @@ inline bool gemv_ok(const Problem& q) {
     return ok;
 }
 
+inline int gemv_rmax(int R) { return R <= 1 ? 1 : R <= 2 ? 2 : R <= 3 ? 3 : R <= 4 ? 4 : R <= 6 ? 6 : R <= 8 ? 8 : R <= 12 ? 12 : 16; }
+
 inline void gemv_split(const Problem& q, int& KS, int& kslice) {
     const int tiles_n = (q.N + 63) / 64;
-    int want = (512 + tiles_n - 1) / tiles_n;             // ~2 blocks per CU: fat blocks keep many loads in flight each
+    int want = (g_gemv_target_blocks + tiles_n - 1) / tiles_n;   // fat blocks keep many loads in flight each
+    if (g_forced_variant > 200 && g_forced_variant <= 264) want = g_forced_variant - 200;     // test hook: 200 + KS
     int maxks = q.K / 512;                                // at least 512 k per slice
     if (maxks < 1) maxks = 1;
     KS = want < 1 ? 1 : (want > maxks ? maxks : want);
     kslice = ((q.K + KS - 1) / KS + 127) / 128 * 128;
-    if (kslice > GEMV_KSLICE_MAX) kslice = GEMV_KSLICE_MAX;           // the activation slice lives in LDS
+    const int smax = gemv_kslice_max(gemv_rmax(q.B * q.M));
+    if (kslice > smax) kslice = smax;                     // the activation slice lives in LDS
     KS = (q.K + kslice - 1) / kslice;
 }
 
@@ -235,6 +240,7 @@ inline int choose_big_tile(const Problem& q) {
 template <int DT, bool FUSED, bool OUT_F32>
 int dispatch3(const Problem& q) {
     int v = g_forced_variant;
+    if (v > 200 && v <= 264) v = 200;        // 200 + KS: decode kernel with a forced k-split (test hook)
     if (v < 0) {
         if (gemv_ok(q)) v = 200;
         else if (!fast_ok(q)) v = 100;
@@ -291,7 +297,9 @@ extern "C" int64_t bd_gemm_workspace_bytes(int B, int M, int N, int K) {
     q.B = B; q.M = M; q.N = N; q.K = K;
     int KS, kslice;
     gemv_split(q, KS, kslice);
-    return KS > 1 ? (int64_t)KS * B * M * N * 4 : 0;
+    int KSmax = K / 512 < 1 ? 1 : K / 512;               // upper bound over the auto rule and the forced-KS test hook
+    if (KS > KSmax) KSmax = KS;
+    return (int64_t)KSmax * B * M * N * 4;
 }
 
 extern "C" int bd_delta_bmm(const void* A, const int32_t* P, void* C, int B, int M, int N, int K, int64_t sAb, int64_t sAm,

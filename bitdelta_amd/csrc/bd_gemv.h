@@ -62,12 +62,14 @@ template <int DT> __device__ __forceinline__ void store_out(const GemvParams& p,
 // words of RB k32-rows x RMAX activation rows are fetched as one batch (RB*R independent 256-byte loads per wave in flight)
 template <int RMAX> struct GemvBatch { static constexpr int RB = (32 / RMAX) < 1 ? 1 : ((32 / RMAX) > 8 ? 8 : (32 / RMAX)); };
 
-constexpr int GEMV_KSLICE_MAX = 1024;   // k per slice (activation slice staged in LDS: RMAX x 1024 x 2 B = 32 KB at most)
+// k per slice: the block's activation slice is staged in LDS (RMAX rows x kslice x 2 B), static LDS budget 64 KB
+// (measured: 4096-k slices for <= 6 rows cut occupancy to 3 blocks/CU and were 15-20 % slower than 1024-k slices + more k-splits)
+constexpr int gemv_kslice_max(int /*rmax*/) { return 1024; }
 
 template <int DT, int RMAX>
 __global__ void __launch_bounds__(256) gemv_kernel(const GemvParams p) {
     constexpr int RB = GemvBatch<RMAX>::RB;
-    constexpr int XROW = GEMV_KSLICE_MAX * 2 + 16;          // padded LDS row of the activation slice (bytes)
+    constexpr int XROW = gemv_kslice_max(RMAX) * 2 + 16;    // padded LDS row of the activation slice (bytes)
     __shared__ float red[4][RMAX][64];    // delta partials per wave
     __shared__ float bs[RMAX][64];        // base GEMV tile
     __shared__ __attribute__((aligned(16))) char xs_lds[RMAX * XROW];

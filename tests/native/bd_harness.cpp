@@ -406,6 +406,15 @@ int main(int argc, char** argv) {
         fails += run_case("prefill64_t6", 6, 64, 4096, 4096, BD_F16, BD_F16, 1, 6, -1, it, 2048);
     } else if (mode == "bits") {
         bits_bench();
+    } else if (mode == "ks") {
+        for (int ks : {1, 2, 4, 8}) {
+            fails += run_case("gate_t6", 6, 1, 14336, 4096, BD_F16, BD_F16, 1, 6, 200 + ks, 50, 1024);
+            fails += run_case("q_t6", 6, 1, 4096, 4096, BD_F16, BD_F16, 1, 6, 200 + ks, 50, 1024);
+            fails += run_case("kv_t6", 6, 1, 1024, 4096, BD_F16, BD_F16, 1, 6, 200 + ks, 50, 1024);
+            fails += run_case("down_t6", 6, 1, 4096, 14336, BD_F16, BD_F16, 1, 6, 200 + ks, 50, 1024);
+        }
+        fails += run_case("down_t6", 6, 1, 4096, 14336, BD_F16, BD_F16, 1, 6, 200 + 14, 50, 1024);
+        fails += run_case("down_t6", 6, 1, 4096, 14336, BD_F16, BD_F16, 1, 6, 200 + 28, 50, 1024);
     } else if (mode == "pfab") {
         // shipped (full-tile ping-pong) vs half-tile ping-pong through the dispatcher, model shapes, 3 interleaved rounds
         for (int rep = 0; rep < 3; ++rep)

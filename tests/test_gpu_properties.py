@@ -1,0 +1,62 @@
+"""Property tests on the GPU (hypothesis): pack/unpack are inverse bijections on every shape the reference accepts, binarize agrees
+with pack(sign) + mean|diff|, the delta GEMM is linear in its activations and odd in its signs.  Small shapes, many cases."""
+import pytest
+import torch
+
+hypothesis = pytest.importorskip("hypothesis")
+from hypothesis import given, settings, strategies as st  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bd():
+    import bitdelta_amd
+    from bitdelta_amd import _lib
+    _lib.lib()
+    return bitdelta_amd
+
+
+@settings(max_examples=40, deadline=None)
+@given(lead=st.lists(st.integers(1, 3), max_size=2), kw=st.integers(1, 5), n=st.integers(1, 70),
+       n_bits=st.sampled_from([8, 16, 32, 64]), seed=st.integers(0, 2 ** 16))
+def test_pack_unpack_roundtrip(bd, lead, kw, n, n_bits, seed):
+    g = torch.Generator().manual_seed(seed)
+    bits = (torch.rand(*lead, kw * n_bits, n, generator=g) > 0.5).cuda()
+    p = bd.pack(bits, n_bits=n_bits)
+    assert p.shape == (*lead, kw, n)
+    assert torch.equal(bd.unpack(p, n_bits=n_bits), bits)
+    # word value = sum(bit << j) in two's complement (reference binary_gemm_kernel.py:16-19, :23-32)
+    b64 = bits.reshape(-1, kw, n_bits, n).to(torch.int64).cpu()
+    want = (b64 << torch.arange(n_bits)[None, None, :, None]).sum(-2).to(p.dtype).reshape(*lead, kw, n)
+    assert torch.equal(p.cpu(), want)
+
+
+@settings(max_examples=25, deadline=None)
+@given(n=st.integers(1, 130), kw=st.integers(1, 9), dtype=st.sampled_from([torch.bfloat16, torch.float16]), seed=st.integers(0, 2 ** 16))
+def test_binarize_matches_definition(bd, n, kw, dtype, seed):
+    from bitdelta_amd.diff import binarize
+    g = torch.Generator().manual_seed(seed)
+    base = (torch.randn(n, kw * 32, generator=g) * 0.02).to(dtype).cuda()
+    fine = (base.float() + torch.randn(n, kw * 32, generator=g).cuda() * 5e-4).to(dtype)
+    mask, coeff = binarize(base, fine)
+    diff = fine - base                                           # in the weights' dtype, like diff.py:11
+    assert torch.equal(mask, bd.pack((diff >= 0).T))             # zero -> bit 1 (diff.py:14-15)
+    assert abs(coeff.item() - diff.float().abs().mean().item()) <= 1e-6 * max(diff.float().abs().mean().item(), 1e-12) + 1e-12
+
+
+@settings(max_examples=20, deadline=None)
+@given(b=st.integers(1, 3), m=st.integers(1, 70), kw=st.integers(1, 6), n=st.integers(1, 90), seed=st.integers(0, 2 ** 16),
+       dtype=st.sampled_from([torch.bfloat16, torch.float16]))
+def test_delta_bmm_linear_and_odd(bd, b, m, kw, n, seed, dtype):
+    g = torch.Generator().manual_seed(seed)
+    K = kw * 32
+    x = torch.randn(b, m, K, generator=g).to(dtype).cuda()
+    p = torch.randint(-2 ** 31, 2 ** 31 - 1, (b, kw, n), generator=g, dtype=torch.int64).to(torch.int32).cuda()
+    f = lambda xx, pp: bd.delta_bmm(xx, pp, out_dtype=torch.float32, round_mode=0)
+    y = f(x, p)
+    s = bd.unpack(p).float() * 2 - 1
+    assert torch.allclose(y, torch.bmm(x.float(), s), rtol=1e-5, atol=1e-4 * K ** 0.5)
+    assert torch.allclose(f(x, ~p), -y, rtol=1e-5, atol=1e-5)
+    x2 = (x.float() * 2).to(dtype)
+    assert torch.equal(f(x2, p), 2 * y)
