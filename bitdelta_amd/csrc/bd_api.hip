@@ -256,7 +256,7 @@ int dispatch3(const Problem& q) {
     switch (v) {
         case 0:
             if constexpr (FUSED) return launch_tile<GemmCfg<DT, 256, 256, 2, 4, 4, FUSED, OUT_F32, 2>, 1>(q);   // 2-slot base ring
-            else return launch_tile<GemmCfg<DT, 256, 256, 2, 4, 4, FUSED, OUT_F32, 0>, 2>(q);
+            else return launch_tile<GemmCfg<DT, 256, 256, 2, 4, 4, FUSED, OUT_F32, 1>, 2>(q);    // full-tile ping-pong, LUT sign expansion
         case 6: return launch_tile<GemmCfg<DT, 256, 256, 2, 4, 4, FUSED, OUT_F32, 2>, 1>(q);      // half-tile ping-pong (A/B reference)
         case 7: return launch_tile<GemmCfg<DT, 256, 128, 2, 4, 4, FUSED, OUT_F32, 2>, 1>(q);      // half-tile ping-pong 256x128 (A/B)
         case 4: return launch_tile<GemmCfg<DT, 256, 256, 2, 4, 4, FUSED, OUT_F32>>(q);   // single-barrier 256x256 (A/B reference)

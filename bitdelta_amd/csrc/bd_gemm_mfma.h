@@ -72,7 +72,8 @@ struct GemmCfg {
     static constexpr int BW_PW = BW_PIECES >= NW ? BW_PIECES / NW : 1;   // per wave; narrow tiles: every wave still issues one
                                                          // (waves >= BW_PIECES re-fetch a piece) so the vmcnt count is uniform
     static constexpr int DPW_D = A_PW + BW_PW, DPW_B = A_PW + W_PW;
-    static constexpr int LDS_BYTES = (FUSED && NSB * STAGE_B > NS * STAGE_D) ? NSB * STAGE_B : NS * STAGE_D;
+    static constexpr int LUT_BYTES = 4096;               // bd_gemm_pf.h's sign-expansion table sits behind the delta ring
+    static constexpr int LDS_BYTES = (FUSED && NSB * STAGE_B > NS * STAGE_D + LUT_BYTES) ? NSB * STAGE_B : NS * STAGE_D + LUT_BYTES;
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/wave mismatch");
     static_assert(BW_PIECES % NW == 0 || NW % BW_PIECES == 0, "sign-word pieces vs waves");
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");

@@ -112,10 +112,25 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_pf_kernel(const GemmParams
 #pragma unroll
         for (int i = 0; i < BW_PW; ++i) dma4(bw_voff[i], ps, base + bw_lds[i]);
     };
+    // OPT & 1: sign expansion by table lookup -- LUT[byte] = the 8 (+-1.0) 16-bit values of that byte's signs (one ds_read_b128 per
+    // fragment, 2 VALU for the address) instead of 8 VALU per fragment.  4 KiB behind the ring; built once per block.
+    constexpr bool USE_LUT = (Cfg::OPT & 1) != 0;
+    constexpr int LUT_OFF = NS * STAGE_D;
+    if constexpr (USE_LUT) {
+        static_assert(!USE_LUT || (LUT_OFF + 4096 <= 160 * 1024), "LUT does not fit");
+        constexpr uint32_t POS = One2<DT>::v & 0xffffu, NEG = POS | 0x8000u;
+        for (int e = threadIdx.x; e < 256; e += Cfg::NT) {
+            u32x4_t v;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                v[d] = (((e >> (2 * d)) & 1) ? POS : NEG) | ((((e >> (2 * d + 1)) & 1) ? POS : NEG) << 16);
+            *(u32x4_t*)(smem + LUT_OFF + e * 16) = v;
+        }
+    }
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t) issue(min(t, nk - 1), t);
     wait_vmcnt<(NS - 2) * Cfg::DPW_D>();
-    phase_end();                                  // tile 0 resident
+    phase_end();                                  // tile 0 resident (and the LUT visible)
     if (grp == 1) phase_end();                    // stagger
 
     constexpr int NMF = 4 * TM * TN;
@@ -142,6 +157,15 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_pf_kernel(const GemmParams
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(4 * TM > 15 ? 15 : 4 * TM) : "memory");   // the words are back (counter field is 4 bits)
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (USE_LUT) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const uint32_t byte = (wraw[j] >> (8 * s)) & 0xffu;            // v_bfe_u32
+                    sf[s][j] = *(const u32x4_t*)(smem + LUT_OFF + byte * 16);      // v_lshl_add + ds_read_b128
+                }
+        } else
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const uint32_t w = ~wraw[j];

@@ -261,7 +261,8 @@ static void sweep_pf(int M, int N, int K, int iters) {
     for (int rep = 0; rep < 3; ++rep) {      // interleaved A/B rounds in one process
         CFGPP("pp_ns4_noprio", DT_BF16, 256, 256, 2, 4, 4, false, false, 2);
         CFGPF("pf_ns4", DT_BF16, 256, 256, 2, 4, 4, false, false, 0);
-        CFGPF("pf_ns4_prio", DT_BF16, 256, 256, 2, 4, 4, false, false, 2);
+        CFGPF("pf_ns4_lut", DT_BF16, 256, 256, 2, 4, 4, false, false, 1);
+        CFGPF("pf_256x128_lut", DT_BF16, 256, 128, 2, 4, 4, false, false, 1);
         CFGPF("pf_256x128", DT_BF16, 256, 128, 2, 4, 4, false, false, 0);
         CFGPP("pp_256x128", DT_BF16, 256, 128, 2, 4, 4, false, false, 2);
     }
@@ -430,6 +431,7 @@ int main(int argc, char** argv) {
         const int M = 4096, N = 4096, K = 4096, iters = 10;
         CFGPP("pp_ns4_noprio", DT_BF16, 256, 256, 2, 4, 4, false, false, 2);
         CFGPF("pf_ns4", DT_BF16, 256, 256, 2, 4, 4, false, false, 0);
+        CFGPF("pf_ns4_lut", DT_BF16, 256, 256, 2, 4, 4, false, false, 1);
         CFG("v1_256x256_2x4_ns4", DT_BF16, 256, 256, 2, 4, 4, false, false, 0);
     } else if (mode == "pf") {
         sweep_pf(argc > 2 ? atoi(argv[2]) : 4096, 4096, argc > 3 ? atoi(argv[3]) : 4096, 30);

@@ -69,7 +69,8 @@ template <class Cfg> void run_pf(const char* name) {
 }
 int main() {
     run_pf<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 0>>("full-tile ping-pong 256x256");
-    run_pf<GemmCfg<DT_BF16, 256, 128, 2, 4, 4, false, false, 0>>("full-tile ping-pong 256x128");
+    run_pf<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 1>>("full-tile ping-pong 256x256, LUT expansion");
+    return 0;
     run<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 2>>("strict, noprio, 1 MFMA : 2 VALU");
     run<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 2 + 64>>("strict, noprio, 2 MFMA : 4 VALU");
     run<GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 2 + 512>>("strict, noprio, 4 MFMA : 8 VALU");
