@@ -265,7 +265,7 @@ def main():
                      "traffic_note": "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes "
                                      "(profiles/r01_traffic.json); algorithmic bytes per launch = algorithmic_bytes_total / launches",
                      "algorithmic_bytes_total": k_bytes,
-                     "kernel": "bd::delta_gemm_pf_kernel<bf16, 256x128 tile, fused> (full-tile ping-pong; x.W^T + alpha*(x.S), 4*M*N*K flop/launch)",
+                     "kernel": "bd::delta_gemm_fx_kernel<bf16, 256x128 tile> (one-pass fused, two accumulator sets, full-tile ping-pong; x.W^T + alpha*(x.S), 4*M*N*K flop/launch)",
                      "launches": n_launch, "kernel_ms_total": k_ms, "algorithmic_flops_total": k_flops,
                      "share_of_step_time": (k_ms / 1e3) / dt if dt > 0 else None},
         "delta_gemm": mb,

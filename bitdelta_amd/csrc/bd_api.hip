@@ -6,6 +6,7 @@
 #include "bd_gemm_mfma.h"
 #include "bd_gemm_pp.h"
 #include "bd_gemm_pf.h"
+#include "bd_gemm_fx.h"
 #include "bd_gemv.h"
 
 using namespace bd;
@@ -201,9 +202,10 @@ inline GemmParams make_params(const Problem& q, int BM, int BN) {
 template <class Cfg, int SCHED> struct TileKernel { static auto get() { return delta_gemm_kernel<Cfg>; } };
 template <class Cfg> struct TileKernel<Cfg, 1> { static auto get() { return delta_gemm_pp_kernel<Cfg>; } };
 template <class Cfg> struct TileKernel<Cfg, 2> { static auto get() { return delta_gemm_pf_kernel<Cfg>; } };
+template <class Cfg> struct TileKernel<Cfg, 3> { static auto get() { return delta_gemm_fx_kernel<Cfg>; } };
 
 // SCHED 0 = single barrier per k-tile (bd_gemm_mfma.h; the small-M tiles), 1 = half-tile ping-pong (bd_gemm_pp.h),
-// 2 = full-tile ping-pong (bd_gemm_pf.h; the shipped schedule wherever its ring fits).
+// 2 = full-tile ping-pong (bd_gemm_pf.h; the shipped delta-only schedule), 3 = one-pass fused, two accumulator sets (bd_gemm_fx.h).
 template <class Cfg, int SCHED = 0>
 int launch_tile(const Problem& q) {
     const GemmParams p = make_params(q, Cfg::BM, Cfg::BN);
@@ -244,13 +246,14 @@ int dispatch3(const Problem& q) {
     if (v < 0) {
         if (gemv_ok(q)) v = 200;
         else if (!fast_ok(q)) v = 100;
-        else if (q.M > 128) v = choose_big_tile(q);
+        else if (q.M > 128) v = FUSED ? 8 : choose_big_tile(q);   // fused: one-pass 256x128 kernel (profiles/r01_fx_vs_two_loop.txt)
         else if (q.M > 64) v = 1;
         else if (q.M > 32) v = 2;
         else v = 3;
     } else {
         if (v == 200 && !gemv_ok(q)) return BD_E_BAD_SHAPE;
-        if (v >= 0 && v <= 7 && !fast_ok(q)) return BD_E_BAD_SHAPE;
+        if (v >= 0 && v <= 8 && !fast_ok(q)) return BD_E_BAD_SHAPE;
+        if (v == 8 && !FUSED) return BD_E_BAD_SHAPE;
     }
     t_last_variant = v;
     switch (v) {
@@ -261,6 +264,9 @@ int dispatch3(const Problem& q) {
         case 7: return launch_tile<GemmCfg<DT, 256, 128, 2, 4, 4, FUSED, OUT_F32, 2>, 1>(q);      // half-tile ping-pong 256x128 (A/B)
         case 4: return launch_tile<GemmCfg<DT, 256, 256, 2, 4, 4, FUSED, OUT_F32>>(q);   // single-barrier 256x256 (A/B reference)
         case 5: return launch_tile<GemmCfg<DT, 256, 128, 2, 4, 4, FUSED, OUT_F32, 0>, 2>(q);
+        case 8:
+            if constexpr (FUSED) return launch_tile<FxCfg<DT, 256, 128, 3, OUT_F32, 1>, 3>(q);
+            else return BD_E_BAD_SHAPE;
         case 1: return launch_tile<GemmCfg<DT, 128, 256, 1, 4, 4, FUSED, OUT_F32>>(q);
         case 2: return launch_tile<GemmCfg<DT, 64, 256, 1, 4, 4, FUSED, OUT_F32>>(q);
         case 3: return launch_tile<GemmCfg<DT, 32, 256, 1, 4, 4, FUSED, OUT_F32>>(q);

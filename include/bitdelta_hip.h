@@ -87,7 +87,8 @@ int bd_merge_delta(void* W, int64_t ldw, const int32_t* P, const float* coeff, i
 /* tuning / test hook: force a kernel family for bd_delta_bmm / bd_binary_linear.
  * -1 auto (default); 0..3 MFMA tile configs (256x256 ping-pong, 128x256, 64x256, 32x256); 4 = 256x256 single-barrier schedule;
  * 5 = 256x128 ping-pong (picked automatically when it fills the CUs better); 6 / 7 = the half-tile ping-pong schedule at
- * 256x256 / 256x128 (A/B reference for the shipped full-tile schedule);
+ * 256x256 / 256x128 (A/B reference for the shipped full-tile schedule); 8 = one-pass fused 256x128 kernel with two accumulator
+ * sets (bd_binary_linear only; the automatic choice for M > 128; 0 / 5 remain as the two-loop A/B references);
  * 100 generic edge kernel; 200 decode GEMV.
  * A forced variant whose preconditions fail returns BD_E_BAD_SHAPE instead of silently falling back. */
 int bd_set_gemm_variant(int variant);

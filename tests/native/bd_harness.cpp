@@ -18,6 +18,7 @@
 #include "../../bitdelta_amd/csrc/bd_gemm_pp.h"
 #include "../../bitdelta_amd/csrc/bd_gemm_sp.h"
 #include "../../bitdelta_amd/csrc/bd_gemm_pf.h"
+#include "../../bitdelta_amd/csrc/bd_gemm_fx.h"
 #include "../../include/bitdelta_hip.h"
 
 #define HIPCHECK(x)                                                                      \
@@ -198,6 +199,7 @@ template <class Cfg, int PP> struct KernSel { static auto get() { return bd::del
 template <class Cfg> struct KernSel<Cfg, 1> { static auto get() { return bd::delta_gemm_pp_kernel<Cfg>; } };
 template <class Cfg> struct KernSel<Cfg, 2> { static auto get() { return bd::delta_gemm_sp_kernel<Cfg>; } };
 template <class Cfg> struct KernSel<Cfg, 3> { static auto get() { return bd::delta_gemm_pf_kernel<Cfg>; } };
+template <class Cfg> struct KernSel<Cfg, 4> { static auto get() { return bd::delta_gemm_fx_kernel<Cfg>; } };
 
 template <class Cfg, int PP = 0>
 static void run_cfg(const char* name, int M, int N, int K, int iters, int nsamples) {
@@ -265,6 +267,17 @@ static void sweep_pf(int M, int N, int K, int iters) {
         CFGPF("pf_256x128_lut", DT_BF16, 256, 128, 2, 4, 4, false, false, 1);
         CFGPF("pf_256x128", DT_BF16, 256, 128, 2, 4, 4, false, false, 0);
         CFGPP("pp_256x128", DT_BF16, 256, 128, 2, 4, 4, false, false, 2);
+    }
+}
+
+#define CFGFX(name, ...) run_cfg<FxCfg<__VA_ARGS__>, 4>(name, M, N, K, iters, 4096)
+// one-pass fused (two accumulator sets) against the two-loop fused kernels, interleaved in one process
+static void sweep_fx(int M, int N, int K, int iters) {
+    for (int rep = 0; rep < 3; ++rep) {
+        CFGFX("fx_256x128_ns3_lut", DT_BF16, 256, 128, 3, false, 1);
+        CFGFX("fx_256x128_ns3_valu", DT_BF16, 256, 128, 3, false, 0);
+        CFGPF("pf_256x128_fused", DT_BF16, 256, 128, 2, 4, 4, true, false, 0);
+        CFGPP("pp_256x256_fused", DT_BF16, 256, 256, 2, 4, 4, true, false, 2);
     }
 }
 
@@ -377,6 +390,12 @@ int main(int argc, char** argv) {
             for (int fused : {0, 1}) {
                 for (int v : {0, 1, 2, 3, 4, 5, 6, 7, 100})
                     fails += run_case("tile", 2, 200, 520, 256, dt, BD_F32, fused, 2, v, 0, S);
+                if (fused) {        // one-pass fused kernel: multi-tenant, k shorter than the ring (nk = 1, 2), odd N
+                    fails += run_case("fx", 2, 200, 520, 256, dt, BD_F32, 1, 2, 8, 0, S);
+                    fails += run_case("fx_nk1", 1, 257, 136, 64, dt, dt, 1, 1, 8, 0, S);
+                    fails += run_case("fx_nk2", 3, 300, 264, 128, dt, dt, 1, 1, 8, 0, S);
+                    fails += run_case("fx_big", 1, 1024, 1024, 2048, dt, dt, 1, 1, 8, 0, S);
+                }
                 fails += run_case("tile_bcast", 3, 130, 300, 128, dt, dt, fused, 1, 0, 0, S);
                 fails += run_case("auto_big", 1, 512, 768, 1024, dt, dt, fused, 1, -1, 0, S);
                 fails += run_case("generic_k96", 2, 17, 40, 96, dt, BD_F32, fused, 2, -1, 0, S);
@@ -392,6 +411,15 @@ int main(int argc, char** argv) {
     } else if (mode == "perf") {
         const int it = 20;
         for (int M : {4096, 8192, 16384}) fails += run_case("delta_4096sq", 1, M, 4096, 4096, BD_BF16, BD_BF16, 0, 1, -1, it, 2048);
+        for (int v : {-1, 0, 5}) {       // auto (one-pass fused) vs the two-loop kernels
+        fails += run_case("fused_8192x4096sq", 1, 8192, 4096, 4096, BD_BF16, BD_BF16, 1, 1, v, it, 2048);
+        fails += run_case("fused_4096sq", 1, 4096, 4096, 4096, BD_BF16, BD_BF16, 1, 1, v, it, 2048);
+        fails += run_case("fused_2048x4096", 1, 2048, 4096, 4096, BD_BF16, BD_BF16, 1, 1, v, it, 2048);
+        fails += run_case("fused_gate", 1, 2048, 11008, 4096, BD_BF16, BD_BF16, 1, 1, v, it, 2048);
+        fails += run_case("fused_down", 1, 2048, 4096, 11008, BD_BF16, BD_BF16, 1, 1, v, it, 2048);
+        fails += run_case("fused_512", 1, 512, 4096, 4096, BD_BF16, BD_BF16, 1, 1, v, it, 2048);
+        fails += run_case("fused_256", 1, 256, 4096, 4096, BD_BF16, BD_BF16, 1, 1, v, it, 2048);
+        }
         fails += run_case("fused_4096sq", 1, 4096, 4096, 4096, BD_BF16, BD_BF16, 1, 1, -1, it, 2048);
         fails += run_case("fused_2048x4096", 1, 2048, 4096, 4096, BD_BF16, BD_BF16, 1, 1, -1, it, 2048);
         fails += run_case("fused_gate", 1, 2048, 11008, 4096, BD_BF16, BD_BF16, 1, 1, -1, it, 2048);
@@ -433,6 +461,9 @@ int main(int argc, char** argv) {
         CFGPF("pf_ns4", DT_BF16, 256, 256, 2, 4, 4, false, false, 0);
         CFGPF("pf_ns4_lut", DT_BF16, 256, 256, 2, 4, 4, false, false, 1);
         CFG("v1_256x256_2x4_ns4", DT_BF16, 256, 256, 2, 4, 4, false, false, 0);
+    } else if (mode == "fx") {
+        const int M = argc > 2 ? atoi(argv[2]) : 2048, N = argc > 3 ? atoi(argv[3]) : 4096, K = argc > 4 ? atoi(argv[4]) : 4096;
+        sweep_fx(M, N, K, argc > 5 ? atoi(argv[5]) : 20);
     } else if (mode == "pf") {
         sweep_pf(argc > 2 ? atoi(argv[2]) : 4096, 4096, argc > 3 ? atoi(argv[3]) : 4096, 30);
     } else if (mode == "sp") {

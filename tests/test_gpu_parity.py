@@ -201,8 +201,12 @@ def test_delta_bmm_vs_oracle(bd, oracle, dtype, shape):
             assert relerr(got.cpu(), ref32)[0] <= 1e-3
 
 
+# the one-pass fused kernel (variant 8, bd_binary_linear only): multi-tenant, ragged M/N, k shorter than its 3-slot ring
+LINEAR_SHAPES = SHAPES + [(2, 200, 256, 520, 2, 8), (1, 257, 64, 136, 1, 8), (3, 300, 128, 264, 1, 8), (1, 512, 1024, 384, 1, 8)]
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("shape", LINEAR_SHAPES)
 def test_binary_linear_vs_oracle(bd, oracle, dtype, shape):
     from bitdelta_amd import _lib
     B, M, K, N, T, variant = shape
