@@ -33,6 +33,7 @@ SIGNATURES = {
     "bd_merge_delta": (_ci, [_vp, _i64, _vp, _vp, _i64, _i64, _ci, _vp]),
     "bd_set_gemm_variant": (_ci, [_ci]),
     "bd_last_gemm_variant": (_ci, []),
+    "bd_set_tile_group_m": (_ci, [_ci]),
 }
 
 _lib = None

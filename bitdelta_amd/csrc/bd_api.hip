@@ -12,12 +12,14 @@
 using namespace bd;
 
 static int g_forced_variant = -1;
+static int g_forced_group_m = 0;        // 0 = automatic tile order
 static int g_gemv_target_blocks = 512;
 static thread_local int t_last_variant = -1;
 
 extern "C" int bd_version(void) { return 1; }
 extern "C" int bd_set_gemm_variant(int v) { g_forced_variant = v; return BD_OK; }
 extern "C" int bd_last_gemm_variant(void) { return t_last_variant; }
+extern "C" int bd_set_tile_group_m(int g) { g_forced_group_m = g; return BD_OK; }
 
 extern "C" const char* bd_error_string(int code) {
     switch (code) {
@@ -193,9 +195,11 @@ inline GemmParams make_params(const Problem& q, int BM, int BN) {
     p.sAm = (int)q.sAm; p.sCm = (int)q.sCm; p.ldw = (int)q.ldw;
     p.sAlb = (int)q.sAlb; p.gsz = q.N / q.G;
     p.round_mode = q.round_mode; p.accumulate = q.accumulate;
-    // m-fastest runs (an XCD owns a column slice of W) measured +5 % when the whole problem is one round of tiles and W is the
-    // larger operand, -4 % on multi-round shapes (profiles/r01_tile_order.txt): use it only in the first case.
-    p.m_fastest = (q.W != nullptr && (int64_t)q.N > (int64_t)q.M && (int64_t)p.tiles_m * p.tiles_n * q.B <= num_cus()) ? 1 : 0;
+    // Tile walk order (profiles/r01_tile_order.txt): delta-only = n fastest (the XCD's run shares X row panels; the mask is tiny).
+    // Fused = groups of 4 tile rows: each XCD's run covers a ~4 x 8 block of tiles, which minimises X + W bytes per XCD
+    // (+3..5 % on the MLP shapes over n-fastest, equal to m-fastest on the single-round ones).
+    p.group_m = q.W != nullptr ? (p.tiles_m < 4 ? p.tiles_m : 4) : 1;
+    if (g_forced_group_m > 0) p.group_m = g_forced_group_m < p.tiles_m ? g_forced_group_m : p.tiles_m;
     return p;
 }
 

@@ -39,16 +39,19 @@ struct GemmParams {
     int sAlb, gsz;            // alpha batch stride (0 = broadcast), columns per scale group
     int round_mode;           // 1: fp32 -> fp16 -> out (reference epilogue); 0: fp32 -> out
     int accumulate;           // delta-only: C = C_in + alpha * acc  (adds the delta onto an existing base GEMM result)
-    int m_fastest;            // tile order inside an XCD's contiguous run: 0 = n fastest (X row panel shared in L2; right when
-                              // the other operand is the tiny packed mask), 1 = m fastest (the XCD owns a column slice of W;
-                              // right for the fused kernel when N*K > M*K: measured 6x algorithmic L2->fabric bytes otherwise)
+    int group_m;              // tile order: tiles are walked in groups of group_m tile rows, m fastest inside a group, then n.
+                              // 1 = n fastest (an XCD's contiguous run shares X row panels in its L2; right when the other
+                              // operand is the tiny packed mask); tiles_m = m fastest (the XCD owns a column slice of W);
+                              // in between = a 2-D block per XCD, which minimises X + W bytes per XCD for the fused kernel
 };
 
 __device__ __forceinline__ void tile_coords(const GemmParams& p, int wg, int& tile_m, int& tile_n) {
-    const int inner = p.m_fastest ? p.tiles_m : p.tiles_n;      // branch-free: keeps the values provably wave-uniform
-    const int q = wg / inner, r = wg - q * inner;
-    tile_m = __builtin_amdgcn_readfirstlane(p.m_fastest ? r : q);
-    tile_n = __builtin_amdgcn_readfirstlane(p.m_fastest ? q : r);
+    const int gsz = p.group_m * p.tiles_n;                       // branch-free: keeps the values provably wave-uniform
+    const int g = wg / gsz, r = wg - g * gsz;
+    const int rows = min(p.group_m, p.tiles_m - g * p.group_m);  // the last group may be short
+    const int q = r / rows;
+    tile_m = __builtin_amdgcn_readfirstlane(g * p.group_m + (r - q * rows));
+    tile_n = __builtin_amdgcn_readfirstlane(q);
 }
 
 // OPT bits (tuning switches, measured in DESIGN.md): 1 = sched_group_barrier MFMA/VALU/DS interleave of the delta

@@ -94,6 +94,9 @@ int bd_merge_delta(void* W, int64_t ldw, const int32_t* P, const float* coeff, i
 int bd_set_gemm_variant(int variant);
 /* which family the LAST call on this thread dispatched to (same codes as above) */
 int bd_last_gemm_variant(void);
+/* tuning hook: tile walk order of the MFMA tile kernels -- groups of `group_m` tile rows, m fastest inside a group, then n
+ * (1 = n fastest, >= tiles_m = m fastest, 0 = automatic).  Results do not depend on it. */
+int bd_set_tile_group_m(int group_m);
 
 #ifdef __cplusplus
 }

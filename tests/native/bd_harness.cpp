@@ -201,6 +201,7 @@ template <class Cfg> struct KernSel<Cfg, 2> { static auto get() { return bd::del
 template <class Cfg> struct KernSel<Cfg, 3> { static auto get() { return bd::delta_gemm_pf_kernel<Cfg>; } };
 template <class Cfg> struct KernSel<Cfg, 4> { static auto get() { return bd::delta_gemm_fx_kernel<Cfg>; } };
 
+static int g_group_m = 1;
 template <class Cfg, int PP = 0>
 static void run_cfg(const char* name, int M, int N, int K, int iters, int nsamples) {
     auto kern = KernSel<Cfg, PP>::get();
@@ -212,7 +213,7 @@ static void run_cfg(const char* name, int M, int N, int K, int iters, int nsampl
     p.M = M; p.N = N; p.K = K;
     p.tiles_m = (M + Cfg::BM - 1) / Cfg::BM; p.tiles_n = (N + Cfg::BN - 1) / Cfg::BN;
     p.sAb = (long long)M * K; p.sPb = 0; p.sCb = (long long)M * N; p.sAm = K; p.sCm = N; p.ldw = K; p.sAlb = 0; p.gsz = N;
-    p.round_mode = 0; p.accumulate = 0;
+    p.round_mode = 0; p.accumulate = 0; p.group_m = g_group_m < p.tiles_m ? g_group_m : p.tiles_m;
     HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
     dim3 grid(p.tiles_m * p.tiles_n, 1);
     auto launch = [&] { hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, 0, p); };
@@ -279,6 +280,17 @@ static void sweep_fx(int M, int N, int K, int iters) {
         CFGPF("pf_256x128_fused", DT_BF16, 256, 128, 2, 4, 4, true, false, 0);
         CFGPP("pp_256x256_fused", DT_BF16, 256, 256, 2, 4, 4, true, false, 2);
     }
+}
+
+// tile walk order for the one-pass fused kernel: group_m tile rows per group (1 = n fastest, 99 = m fastest)
+static void sweep_order(int M, int N, int K, int iters) {
+    for (int rep = 0; rep < 2; ++rep)
+        for (int g : {1, 2, 4, 99}) {
+            g_group_m = g;
+            char nm[64]; snprintf(nm, sizeof nm, "fx_gm%d", g);
+            CFGFX(nm, DT_BF16, 256, 128, 3, false, 1);
+        }
+    g_group_m = 1;
 }
 
 static void sweep_sp(int M, int N, int K, int iters) {
@@ -464,6 +476,9 @@ int main(int argc, char** argv) {
     } else if (mode == "fx") {
         const int M = argc > 2 ? atoi(argv[2]) : 2048, N = argc > 3 ? atoi(argv[3]) : 4096, K = argc > 4 ? atoi(argv[4]) : 4096;
         sweep_fx(M, N, K, argc > 5 ? atoi(argv[5]) : 20);
+    } else if (mode == "order") {
+        const int M = argc > 2 ? atoi(argv[2]) : 2048, N = argc > 3 ? atoi(argv[3]) : 4096, K = argc > 4 ? atoi(argv[4]) : 4096;
+        sweep_order(M, N, K, argc > 5 ? atoi(argv[5]) : 20);
     } else if (mode == "pf") {
         sweep_pf(argc > 2 ? atoi(argv[2]) : 4096, 4096, argc > 3 ? atoi(argv[3]) : 4096, 30);
     } else if (mode == "sp") {

@@ -391,5 +391,6 @@ def test_full_size_fused_spot_rows(bd):
     rows = torch.tensor([0, 1, 255, 256, 1023, 2047], device="cuda")
     s = (bd.unpack(mod.mask).float() * 2 - 1)
     ref = x[0, rows].float() @ w.float().T + mod.coeff.detach() * (x[0, rows].float() @ s)
-    d = ulp_diff(y[0, rows], ref.bfloat16())
-    assert d.max().item() <= 1 and (d == 0).float().mean().item() >= 0.98
+    # 1 bf16 ulp, with the absolute floor of fp32 accumulation noise for outputs that cancel to ~0 (|y| ~ 1e-5 among O(1) values)
+    ok, same = within_one_ulp(y[0, rows].cpu(), ref.bfloat16().cpu(), K)
+    assert ok and same >= 0.98, (ok, same)
