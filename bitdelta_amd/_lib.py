@@ -34,6 +34,7 @@ SIGNATURES = {
     "bd_set_gemm_variant": (_ci, [_ci]),
     "bd_last_gemm_variant": (_ci, []),
     "bd_set_tile_group_m": (_ci, [_ci]),
+    "bd_set_decode_two_launch": (_ci, [_ci]),
 }
 
 _lib = None
@@ -85,7 +86,22 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
-def workspace(nbytes, device):
+_WORKSPACES = {}          # (device index, stream handle) -> persistent zero-initialised scratch tensor
+
+
+def workspace(nbytes, device, zeroed=False):
+    """Scratch for one launch.  `zeroed=True` (the GEMM paths): a persistent buffer per (device, stream), zero-filled once when it
+    is (re)allocated -- include/bitdelta_hip.h's contract for the decode path's ticket area; the library restores the zeros, and
+    launches on one stream are ordered, so the buffer is reused by every call on that stream."""
     if nbytes <= 0:
         return None, 0
-    return torch.empty(int(nbytes), dtype=torch.uint8, device=device), int(nbytes)
+    nbytes = int(nbytes)
+    if not zeroed:
+        return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    buf = _WORKSPACES.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _WORKSPACES[key] = buf
+    return buf, buf.numel()

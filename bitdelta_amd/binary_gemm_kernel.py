@@ -104,7 +104,7 @@ def delta_bmm(a, b, *, out=None, out_dtype=None, round_mode=1, alpha=None, accum
         assert alpha.shape[0] in (1, B)
         al_ptr, sAlb = ptr(alpha), (0 if alpha.shape[0] == 1 else groups)
     L = lib()
-    ws, ws_bytes = workspace(L.bd_gemm_workspace_bytes(B, M, N, K), a.device)
+    ws, ws_bytes = workspace(L.bd_gemm_workspace_bytes(B, M, N, K), a.device, zeroed=True)
     with torch.cuda.device(a.device):
         check(L.bd_delta_bmm(ptr(a), ptr(b), ptr(out), B, M, N, K, a.stride(0), a.stride(1), sPb, out.stride(0),
                              out.stride(1), DTYPE_CODE[a.dtype], DTYPE_CODE[out_dtype], int(round_mode), al_ptr, sAlb,
@@ -136,7 +136,7 @@ def binary_linear(x, weight, mask, alpha, *, out_dtype=None, groups=1):
     sPb = 0 if (mask.shape[0] == 1 and B > 1) else mask.stride(0)
     sAlb = 0 if alpha.shape[0] == 1 else groups
     L = lib()
-    ws, ws_bytes = workspace(L.bd_gemm_workspace_bytes(B, M, N, K), x.device)
+    ws, ws_bytes = workspace(L.bd_gemm_workspace_bytes(B, M, N, K), x.device, zeroed=True)
     with torch.cuda.device(x.device):
         check(L.bd_binary_linear(ptr(x), ptr(weight), ptr(mask), ptr(alpha), ptr(y), B, M, N, K, x.stride(0),
                                  x.stride(1), weight.stride(0), sPb, sAlb, groups, y.stride(0), y.stride(1),

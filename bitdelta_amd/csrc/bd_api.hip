@@ -13,6 +13,8 @@ using namespace bd;
 
 static int g_forced_variant = -1;
 static int g_forced_group_m = 0;        // 0 = automatic tile order
+static int g_gemv_two_launch = 1;       // 1 (default) = split-k partials are summed by gemv_reduce_kernel; 0 = in-launch tickets
+                                        // (measured slower: the last-arriver tail is serial inside every tile; bd_gemv.h)
 static int g_gemv_target_blocks = 512;
 static thread_local int t_last_variant = -1;
 
@@ -20,6 +22,7 @@ extern "C" int bd_version(void) { return 1; }
 extern "C" int bd_set_gemm_variant(int v) { g_forced_variant = v; return BD_OK; }
 extern "C" int bd_last_gemm_variant(void) { return t_last_variant; }
 extern "C" int bd_set_tile_group_m(int g) { g_forced_group_m = g; return BD_OK; }
+extern "C" int bd_set_decode_two_launch(int on) { g_gemv_two_launch = on ? 1 : 0; return BD_OK; }
 
 extern "C" const char* bd_error_string(int code) {
     switch (code) {
@@ -126,6 +129,8 @@ inline void gemv_split(const Problem& q, int& KS, int& kslice) {
     const int tiles_n = (q.N + 63) / 64;
     int want = (g_gemv_target_blocks + tiles_n - 1) / tiles_n;   // fat blocks keep many loads in flight each
     if (g_forced_variant > 200 && g_forced_variant <= 264) want = g_forced_variant - 200;     // test hook: 200 + KS
+    if (g_forced_variant > 300 && g_forced_variant <= 364) want = g_forced_variant - 300;
+    if (g_forced_variant > 400 && g_forced_variant <= 464) want = g_forced_variant - 400;
     int maxks = q.K / 512;                                // at least 512 k per slice
     if (maxks < 1) maxks = 1;
     KS = want < 1 ? 1 : (want > maxks ? maxks : want);
@@ -136,18 +141,35 @@ inline void gemv_split(const Problem& q, int& KS, int& kslice) {
 }
 
 template <int DT, int RMAX>
-int launch_gemv_r(const Problem& q, const GemvParams& gp) {
+int launch_gemv_valu(const Problem& q, const GemvParams& gp) {       // A/B reference (variant 300): VALU sign-flip form
     dim3 grid((unsigned)((q.N + 63) / 64), (unsigned)gp.KS);
     hipLaunchKernelGGL((gemv_kernel<DT, RMAX>), grid, dim3(256), 0, q.st, gp);
-    if (gp.KS > 1) {
-        dim3 g2((unsigned)((q.N + 255) / 256), (unsigned)gp.R);
-        hipLaunchKernelGGL((gemv_reduce_kernel<DT>), g2, dim3(256), 0, q.st, gp);
+    return BD_OK;
+}
+
+template <int DT, int NM>
+int launch_gemv_mfma(const Problem& q, const GemvParams& gp) {
+    dim3 grid((unsigned)((q.N + 63) / 64), (unsigned)gp.KS);
+    // LC = 16 (conflict-free 16-copy sign LUT, 64 KiB) measured SLOWER than the single 4-KiB table (T=6, 4096^2: 24.3 vs 17.9 us):
+    // building 64 KiB per block and 2 blocks/CU cost more than the ~3-way conflicts of random bytes on one table.
+    constexpr int LC = 1;
+    const unsigned lds = 256u * 16u * LC + (unsigned)gp.R * (gemv_kslice_max(16) * 2 + 16);
+    auto kw = gemv_mfma_kernel<DT, NM, true, LC>;
+    auto kd = gemv_mfma_kernel<DT, NM, false, LC>;
+    static bool attr_set = false;                // benign race: idempotent
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kw, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 16 * LC + 16 * 2064) != hipSuccess ||
+            hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 16 * LC + 16 * 2064) != hipSuccess)
+            return BD_E_LAUNCH;
+        attr_set = true;
     }
-    return launch_status();
+    if (q.W) hipLaunchKernelGGL(kw, grid, dim3(256), lds, q.st, gp);
+    else hipLaunchKernelGGL(kd, grid, dim3(256), lds, q.st, gp);
+    return BD_OK;
 }
 
 template <int DT>
-int launch_gemv(const Problem& q) {
+int launch_gemv(const Problem& q, bool valu_form) {
     GemvParams gp;
     gp.X = (const unsigned short*)q.A;
     gp.P = (const uint32_t*)q.P;
@@ -160,19 +182,40 @@ int launch_gemv(const Problem& q) {
     gp.sXm = (int)q.sAm; gp.sCm = (int)q.sCm; gp.ldw = (int)q.ldw; gp.sAlb = (int)q.sAlb; gp.gsz = q.N / q.G;
     gemv_split(q, gp.KS, gp.kslice);
     gp.round_mode = q.round_mode; gp.accumulate = q.accumulate; gp.out_f32 = (q.out_dtype == BD_F32);
+    gp.tickets = nullptr;
     if (gp.KS > 1) {
-        const int64_t need = (int64_t)gp.KS * gp.R * q.N * 4;
+        const int64_t need = GEMV_TICKET_BYTES + (int64_t)gp.KS * gp.R * q.N * 4;
         if (!q.ws || q.ws_bytes < need) return BD_E_WORKSPACE;
+        gp.ws = (float*)((char*)q.ws + GEMV_TICKET_BYTES);
+        // in-launch reduction unless the tile count exceeds the ticket area or the two-launch form is forced (g_gemv_two_launch)
+        if ((q.N + 63) / 64 <= GEMV_TICKET_BYTES / 4 && !g_gemv_two_launch) gp.tickets = (uint32_t*)q.ws;
     }
-    const int R = gp.R;      // rows >= R are computed and discarded, so the buckets are kept fine-grained
-    if (R <= 1) return launch_gemv_r<DT, 1>(q, gp);
-    if (R <= 2) return launch_gemv_r<DT, 2>(q, gp);
-    if (R <= 3) return launch_gemv_r<DT, 3>(q, gp);
-    if (R <= 4) return launch_gemv_r<DT, 4>(q, gp);
-    if (R <= 6) return launch_gemv_r<DT, 6>(q, gp);
-    if (R <= 8) return launch_gemv_r<DT, 8>(q, gp);
-    if (R <= 12) return launch_gemv_r<DT, 12>(q, gp);
-    return launch_gemv_r<DT, 16>(q, gp);
+    if (valu_form) {
+        const int R = gp.R;      // rows >= R are computed and discarded, so the buckets are kept fine-grained
+        if (R <= 1) launch_gemv_valu<DT, 1>(q, gp);
+        else if (R <= 2) launch_gemv_valu<DT, 2>(q, gp);
+        else if (R <= 3) launch_gemv_valu<DT, 3>(q, gp);
+        else if (R <= 4) launch_gemv_valu<DT, 4>(q, gp);
+        else if (R <= 6) launch_gemv_valu<DT, 6>(q, gp);
+        else if (R <= 8) launch_gemv_valu<DT, 8>(q, gp);
+        else if (R <= 12) launch_gemv_valu<DT, 12>(q, gp);
+        else launch_gemv_valu<DT, 16>(q, gp);
+    } else {
+        const int nm = q.sPb == 0 ? 1 : q.B;     // accumulator sets = distinct masks (extra sets of a bucket repeat the last mask)
+        if (nm <= 1) launch_gemv_mfma<DT, 1>(q, gp);
+        else if (nm <= 2) launch_gemv_mfma<DT, 2>(q, gp);
+        else if (nm <= 3) launch_gemv_mfma<DT, 3>(q, gp);
+        else if (nm <= 4) launch_gemv_mfma<DT, 4>(q, gp);
+        else if (nm <= 6) launch_gemv_mfma<DT, 6>(q, gp);
+        else if (nm <= 8) launch_gemv_mfma<DT, 8>(q, gp);
+        else if (nm <= 12) launch_gemv_mfma<DT, 12>(q, gp);
+        else launch_gemv_mfma<DT, 16>(q, gp);
+    }
+    if (gp.KS > 1 && !gp.tickets) {
+        dim3 g2((unsigned)((q.N + 255) / 256), (unsigned)gp.R);
+        hipLaunchKernelGGL((gemv_reduce_kernel<DT>), g2, dim3(256), 0, q.st, gp);
+    }
+    return launch_status();
 }
 
 inline int num_cus() {
@@ -246,7 +289,9 @@ inline int choose_big_tile(const Problem& q) {
 template <int DT, bool FUSED, bool OUT_F32>
 int dispatch3(const Problem& q) {
     int v = g_forced_variant;
-    if (v > 200 && v <= 264) v = 200;        // 200 + KS: decode kernel with a forced k-split (test hook)
+    if (v > 200 && v <= 264) v = 200;        // 200 + KS: decode path with a forced k-split (test hook)
+    if (v > 300 && v <= 364) v = 300;        // 300 (+ KS): force the VALU sign-flip decode kernel
+    if (v > 400 && v <= 464) v = 400;        // 400 (+ KS): force the MFMA + LUT decode kernel
     if (v < 0) {
         if (gemv_ok(q)) v = 200;
         else if (!fast_ok(q)) v = 100;
@@ -255,7 +300,7 @@ int dispatch3(const Problem& q) {
         else if (q.M > 32) v = 2;
         else v = 3;
     } else {
-        if (v == 200 && !gemv_ok(q)) return BD_E_BAD_SHAPE;
+        if ((v == 200 || v == 300 || v == 400) && !gemv_ok(q)) return BD_E_BAD_SHAPE;
         if (v >= 0 && v <= 8 && !fast_ok(q)) return BD_E_BAD_SHAPE;
         if (v == 8 && !FUSED) return BD_E_BAD_SHAPE;
     }
@@ -275,7 +320,11 @@ int dispatch3(const Problem& q) {
         case 2: return launch_tile<GemmCfg<DT, 64, 256, 1, 4, 4, FUSED, OUT_F32>>(q);
         case 3: return launch_tile<GemmCfg<DT, 32, 256, 1, 4, 4, FUSED, OUT_F32>>(q);
         case 100: return launch_generic<DT, FUSED, OUT_F32>(q);
-        case 200: return launch_gemv<DT>(q);
+        // decode: the VALU sign-flip kernel is as fast or faster on the fused Linear shapes (profiles/r01_decode_kernels.txt);
+        // the MFMA + LUT kernel wins when the delta dominates (delta-only with >= 8 masks) and on narrow outputs (k/v projections)
+        case 200: return launch_gemv<DT>(q, !((!q.W && (q.sPb == 0 ? 1 : q.B) >= 8) || q.N <= 2048));
+        case 300: return launch_gemv<DT>(q, true);
+        case 400: return launch_gemv<DT>(q, false);
         default: return BD_E_BAD_SHAPE;
     }
 }
@@ -309,7 +358,7 @@ extern "C" int64_t bd_gemm_workspace_bytes(int B, int M, int N, int K) {
     gemv_split(q, KS, kslice);
     int KSmax = K / 512 < 1 ? 1 : K / 512;               // upper bound over the auto rule and the forced-KS test hook
     if (KS > KSmax) KSmax = KS;
-    return (int64_t)KSmax * B * M * N * 4;
+    return GEMV_TICKET_BYTES + (int64_t)KSmax * B * M * N * 4;
 }
 
 extern "C" int bd_delta_bmm(const void* A, const int32_t* P, void* C, int B, int M, int N, int K, int64_t sAb, int64_t sAm,

@@ -11,7 +11,8 @@
 //   * each tenant's packed sign words P_b [K/32, N]: lane = output column (256-byte coalesced word rows), the 32 signs
 //     of a word are expanded to +-1.0 pairs (2 VALU / pair) and contracted with the wave-uniform activation pairs held
 //     in SGPRs by v_dot2c_f32_{bf16,f16} (fp32 accumulate) -- the "sign-flip GEMV" variant of the MFMA path.
-// Partial sums of the k-slices go to an fp32 workspace [KS][R][N]; gemv_reduce_kernel sums them and rounds once.
+// Partial sums of the k-slices go to an fp32 workspace [KS][R][N]; the last block to arrive at a column tile's ticket sums them
+// in k-slice order and rounds once (gemv_ticket_reduce; gemv_reduce_kernel is the two-launch fallback / A-B reference).
 // With KS == 1 the block writes the final result itself.
 #pragma once
 #include "bd_common.h"
@@ -28,6 +29,7 @@ struct GemvParams {
     const float* alpha;        // fp32 [B or 1, G] or nullptr
     void* C;                   // [B, M, N]
     float* ws;                 // [KS][R][N] fp32 partials (KS > 1)
+    uint32_t* tickets;         // one arrival counter per 64-column tile (KS > 1, in-launch reduction); nullptr -> gemv_reduce_kernel
     int B, M, N, K, R;
     long long sXb, sPb, sCb;
     int sXm, sCm, ldw, sAlb, gsz;
@@ -57,6 +59,49 @@ template <int DT> __device__ __forceinline__ void store_out(const GemvParams& p,
     }
     if (p.out_f32) ((float*)p.C)[off] = v;
     else ((unsigned short*)p.C)[off] = (unsigned short)f32_to_half_bits<DT>(v);
+}
+
+// In-launch split-k reduction.  Every block has stored its fp32 partial tile to ws[ks][r][n]; the block that arrives LAST at the
+// tile's ticket sums the KS partials in k-slice order (so the result does not depend on which block that is), rounds once, stores,
+// and puts the ticket back to 0 for the next launch.
+// Coherence: the XCDs' L2s are not coherent with each other for ordinary stores, and a real agent-scope release/acquire fence
+// costs an L2 write-back + invalidate per block (measured: 45-250 us per launch instead of 8-48).  So the shared words -- partials
+// and tickets -- are only ever touched by agent-scope RELAXED atomics (sc1 stores/loads that go to the coherence point), and the
+// ordering is explicit: s_waitcnt vmcnt(0) (every partial store of this wave acknowledged) -> s_barrier (... of this block) ->
+// ticket increment -> (last block only) partial loads, which are issued after the increment has returned.
+// Contract (include/bitdelta_hip.h): the ticket area of the workspace is zero when the launch is enqueued.
+constexpr int GEMV_TICKET_BYTES = 64 * 1024;      // fixed-size area at the start of the workspace: 16384 tiles (N <= 1 Mi columns)
+__device__ __forceinline__ void gemv_store_partial(float* dst, float v) {
+    __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int DT>
+__device__ __forceinline__ void gemv_ticket_reduce(const GemvParams& p, int n0, int lane, int wave) {
+    __shared__ int s_last;
+    __builtin_amdgcn_s_waitcnt(0x0f70);               // vmcnt(0): this wave's partial stores are acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t old = __hip_atomic_fetch_add(&p.tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old >= (uint32_t)p.KS) __builtin_trap();  // dirty workspace: fail loudly instead of returning garbage
+        s_last = (old == (uint32_t)p.KS - 1u);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const int n = n0 + lane;
+    if (n < p.N) {
+        for (int r = wave; r < p.R; r += 4) {
+            float s = 0.f;
+            for (int k0 = 0; k0 < p.KS; k0 += 8) {            // 8 independent loads in flight, summed in k order
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    v[j] = __hip_atomic_load(&p.ws[((long long)min(k0 + j, p.KS - 1) * p.R + r) * p.N + n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += (k0 + j < p.KS) ? v[j] : 0.f;
+            }
+            store_out<DT>(p, r, n, s);
+        }
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(&p.tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // words of RB k32-rows x RMAX activation rows are fetched as one batch (RB*R independent 256-byte loads per wave in flight)
@@ -204,9 +249,148 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvParams p) {
             if (p.alpha) d *= p.alpha[(long long)b * p.sAlb + n / p.gsz];
             if (p.W) d += bs[r][lane];
             if (p.KS == 1) store_out<DT>(p, r, n, d);
-            else p.ws[((long long)ks * p.R + r) * p.N + n] = d;
+            else gemv_store_partial(&p.ws[((long long)ks * p.R + r) * p.N + n], d);
         }
     }
+    if (p.KS > 1 && p.tickets) gemv_ticket_reduce<DT>(p, n0, lane, wave);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// MFMA form of the decode kernel (the shipped one; gemv_kernel above is kept as the A/B reference, variant 300).
+//
+// gemv_kernel spends 3 VALU per sign pair (2 to expand, 1 v_dot2c): at 6 tenants the delta part alone took longer than streaming
+// the base weight.  Here BOTH parts run on the matrix pipe with one shared activation fragment per k-step:
+//   * wave = 16 output columns x the block's k-slice; lane (c = l & 15, g = l >> 4);
+//   * an iteration covers 4 word rows (128 k): lane group g owns word row i+g, MFMA step s (of 4) covers the k-octets
+//     {32(i+g) + 8s .. +7 : g = 0..3} for every operand -- so a lane loads ONE sign word per mask per iteration (4 rows x 64 B
+//     per wave-load) and 64 contiguous bytes of its W row (4 x 16 B), with no cross-lane exchange;
+//   * sign fragment of step s = LUT[byte s of the word] (256 x 16 B table in LDS, one ds_read_b128; v_bfe + v_lshl_add for the
+//     address) -> 0.25 VALU per sign instead of 1.5;
+//   * D[col][row] = v_mfma_f32_16x16x32(W or S fragment, x fragment): base accumulator + one accumulator per distinct mask.
+//     With per-tenant masks only the rows of that tenant are kept from its accumulator (the other 16-M columns of D are wasted
+//     matrix-pipe work, which is idle here anyway: <= 68 MFMAs per 8 KB of HBM bytes per wave).
+// Rows >= R of the activation tile are never staged: they only feed D columns that are never stored.
+template <int DT, int NM, bool HASW, int LC>
+__global__ void __launch_bounds__(256) gemv_mfma_kernel(const GemvParams p) {
+    // LC = copies of the sign LUT.  LC = 16: entry e of copy c lives at e*256 + c*16 and lane l reads copy l & 15, so the 16 lanes of
+    // every ds_read_b128 service group hit 16 different 16-byte slots of the 256-byte bank row whatever their bytes are
+    // (conflict-free, 4 LDS cycles per read = 128 signs/clk/CU).  With one copy, random bytes collide ~3-way (measured 0.92 us per
+    // tenant per 4096^2 mask against 0.35 us of HBM time).  64 KiB of LDS: used when there are >= 3 masks to expand.
+    constexpr int XROW = gemv_kslice_max(16) * 2 + 16;
+    constexpr int LUT_BYTES = 256 * 16 * LC;
+    extern __shared__ __attribute__((aligned(256))) char dyn_lds[];     // [LUT][R rows x XROW bytes of activations]
+    __shared__ float outs[16][65];
+    char* const xs_lds = dyn_lds + LUT_BYTES;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 64, ks = blockIdx.y;
+    const int k_lo = ks * p.kslice, k_hi = min(p.K, k_lo + p.kslice);
+    const int i0 = k_lo >> 5, i_hi = k_hi >> 5, i_last = (p.K >> 5) - 1;
+    const int nit = (i_hi - i0 + 3) >> 2;
+    const int nmask = p.sPb == 0 ? 1 : p.B;                       // distinct masks (a stride-0 mask is shared by every row)
+
+    const int nw = min(n0 + wave * 16 + li, p.N - 1);
+    const unsigned short* wr = HASW ? p.W + (long long)nw * p.ldw : nullptr;
+    const uint32_t* pw[NM];
+#pragma unroll
+    for (int t = 0; t < NM; ++t) pw[t] = p.P + (long long)min(t, nmask - 1) * p.sPb + nw;
+
+    struct Stage { u32x4_t wf[4]; uint32_t wd[NM]; };
+    auto load_iter = [&](Stage& st, int it) {
+        const int irow = min(i0 + 4 * it + g, i_last);              // rows past the slice are zeroed through the x fragment
+#pragma unroll
+        for (int t = 0; t < NM; ++t) st.wd[t] = __builtin_nontemporal_load(pw[t] + (long long)irow * p.N);
+        if constexpr (HASW) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) st.wf[s] = __builtin_nontemporal_load((const u32x4_t*)(wr + irow * 32 + 8 * s));
+        }
+    };
+    // Two register stages alternate (loop unrolled by 2, static indices): the next 128 k of W rows and sign words are in flight
+    // under the current iteration's MFMAs and nothing is ever copied between stages.
+    Stage st[2];
+    load_iter(st[0], 0);
+
+    {   // sign LUT: entry e = the 8 (+-1.0) 16-bit values of byte e (bit j <-> k offset j)
+        constexpr uint32_t POS = One2<DT>::v & 0xffffu, NEG = POS | 0x8000u;
+        const int e = threadIdx.x;
+        u32x4_t v;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) v[d] = (((e >> (2 * d)) & 1) ? POS : NEG) | ((((e >> (2 * d + 1)) & 1) ? POS : NEG) << 16);
+#pragma unroll
+        for (int c = 0; c < LC; ++c) *(u32x4_t*)(dyn_lds + e * 16 * LC + c * 16) = v;
+    }
+    {   // activation slice -> LDS (rows < R only)
+        const int kn = k_hi - k_lo;                                   // multiple of 32
+        for (int idx = threadIdx.x; idx < p.R * (kn >> 3); idx += 256) {
+            const int r = idx / (kn >> 3), c = idx - r * (kn >> 3);
+            const int b = r / p.M, m = r - b * p.M;
+            *(u32x4_t*)(xs_lds + r * XROW + c * 16) =
+                *(const u32x4_t*)(p.X + (long long)b * p.sXb + (long long)m * p.sXm + k_lo + c * 8);
+        }
+    }
+    __syncthreads();
+
+    f32x4_t accB = {0.f, 0.f, 0.f, 0.f}, accD[NM];
+#pragma unroll
+    for (int t = 0; t < NM; ++t) accD[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const char* xl = xs_lds + li * XROW + 64 * g;                     // (32 (4 it + g) + 8 s) * 2 bytes = 256 it + 64 g + 16 s
+    const uint32_t copy_off = LC == 16 ? (uint32_t)li * 16u : 0u;
+
+    auto compute = [&](const Stage& cur, int it) {
+        const uint32_t keep = (i0 + 4 * it + g < i_hi) ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const u32x4_t xf = *(const u32x4_t*)(xl + it * 256 + 16 * s) & u32x4_t{keep, keep, keep, keep};
+            if constexpr (HASW) accB = mfma16<DT>(cur.wf[s], xf, accB);
+#pragma unroll
+            for (int t = 0; t < NM; ++t) {
+                uint32_t off;
+                if constexpr (LC == 16) off = __builtin_amdgcn_perm(cur.wd[t], copy_off, 0x0c0c0400u + ((uint32_t)s << 8));   // byte s -> bits 8..15, copy slot -> bits 0..7
+                else off = ((cur.wd[t] >> (8 * s)) & 0xffu) * 16u;
+                const u32x4_t sf = *(const u32x4_t*)(dyn_lds + off);
+                accD[t] = mfma16<DT>(sf, xf, accD[t]);
+            }
+        }
+    };
+    // One iteration ahead.  (Measured and rejected: two iterations ahead with unconditional, clamped loads -- the compiler's
+    // s_waitcnt pass needs straight-line loads to keep two stages in flight, and at the usual 4 iterations per wave (512-k slices)
+    // the re-fetched tail doubled the load instructions: T=1 10.0 -> 14.2 us, gate T=6 48.4 -> 58.1 us.)
+    for (int it = 0; it < nit; it += 2) {
+        if (it + 1 < nit) load_iter(st[1], it + 1);
+        compute(st[0], it);
+        if (it + 1 < nit) {
+            if (it + 2 < nit) load_iter(st[0], it + 2);
+            compute(st[1], it + 1);
+        }
+    }
+
+    // lane (li, g) holds D[col = 4g + e][row = li]: pick the accumulator of this row's mask, scale, add the base, stage in LDS
+    if (li < p.R) {
+        const int b = li / p.M;
+        const int bm = p.sPb == 0 ? 0 : b;
+        f32x4_t d = accD[0];
+#pragma unroll
+        for (int t = 1; t < NM; ++t)
+            if (bm == t) d = accD[t];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = d[e];
+            if (p.alpha) v *= p.alpha[(long long)b * p.sAlb + min(n0 + wave * 16 + 4 * g + e, p.N - 1) / p.gsz];
+            if constexpr (HASW) v += accB[e];
+            outs[li][wave * 16 + 4 * g + e] = v;
+        }
+    }
+    __syncthreads();
+    const int n = n0 + lane;
+    if (n < p.N) {
+        for (int r = wave; r < p.R; r += 4) {
+            const float v = outs[r][lane];
+            if (p.KS == 1) store_out<DT>(p, r, n, v);
+            else gemv_store_partial(&p.ws[((long long)ks * p.R + r) * p.N + n], v);
+        }
+    }
+    if (p.KS > 1 && p.tickets) gemv_ticket_reduce<DT>(p, n0, lane, wave);
 }
 
 template <int DT>
@@ -214,7 +398,13 @@ __global__ void __launch_bounds__(256) gemv_reduce_kernel(const GemvParams p) {
     const int n = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
     if (n >= p.N) return;
     float s = 0.f;
-    for (int ks = 0; ks < p.KS; ++ks) s += p.ws[((long long)ks * p.R + r) * p.N + n];
+    for (int k0 = 0; k0 < p.KS; k0 += 8) {                    // 8 independent loads in flight (a dependent chain of KS L2 round
+        float v[8];                                           // trips made this kernel 4.6 us), summed in k order
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p.ws[((long long)min(k0 + j, p.KS - 1) * p.R + r) * p.N + n];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += (k0 + j < p.KS) ? v[j] : 0.f;
+    }
     store_out<DT>(p, r, n, s);
 }
 

@@ -30,6 +30,7 @@ extern "C" {
 #define BD_E_BAD_DTYPE (-4)
 #define BD_E_BAD_SHAPE (-5)        /* negative / overflowing dimension */
 #define BD_E_WORKSPACE (-6)        /* workspace missing or too small */
+#define BD_WS_TICKET_BYTES 65536    /* leading bytes of a GEMM workspace that must be zero on entry (see bd_delta_bmm) */
 #define BD_E_LAUNCH (-7)           /* hipLaunchKernel failed (hipGetLastError has the detail) */
 #define BD_E_NULL (-8)
 
@@ -54,7 +55,12 @@ int bd_unpack(const void* words, int64_t batch, int64_t KW, int64_t N, void* out
  *   alpha != NULL: C = alpha[b, g(n)] * acc (accumulate = 0) or C = C_in + alpha[b, g(n)] * acc (accumulate = 1), fp32
  *   math, one rounding -- folds `coeff *` and `+` of bitdelta/diff.py:39 / demo_backend.py:97-98 into the epilogue.
  *   alpha: fp32 [B or 1, G], sAlb = its batch stride (0 = broadcast); G scale groups split N evenly.
- *   ws / ws_bytes: scratch of at least bd_gemm_workspace_bytes(B, M, N, K) bytes (may be NULL when that is 0). */
+ *   ws / ws_bytes: scratch of at least bd_gemm_workspace_bytes(B, M, N, K) bytes (may be NULL when that is 0).
+ *     The first BD_WS_TICKET_BYTES bytes are reserved for the arrival counters of the decode path's optional in-launch split-k
+ *     reduction (bd_set_decode_two_launch(0)).  ONLY in that mode they must be ZERO when the call is enqueued (hipMemsetAsync the
+ *     buffer once after allocating it); the library leaves them zero when the call completes, and a kernel that finds a counter out of
+ *     range traps (hipErrorLaunchFailure at the next synchronisation) rather than return wrong sums.  In the default mode (a second,
+ *     tiny reduce launch) the workspace needs no initialisation.  Do not share a workspace between concurrently running launches. */
 int bd_delta_bmm(const void* A, const int32_t* P, void* C, int B, int M, int N, int K,
                  int64_t sAb, int64_t sAm, int64_t sPb, int64_t sCb, int64_t sCm,
                  int dtype, int out_dtype, int round_mode,
@@ -89,7 +95,8 @@ int bd_merge_delta(void* W, int64_t ldw, const int32_t* P, const float* coeff, i
  * 5 = 256x128 ping-pong (picked automatically when it fills the CUs better); 6 / 7 = the half-tile ping-pong schedule at
  * 256x256 / 256x128 (A/B reference for the shipped full-tile schedule); 8 = one-pass fused 256x128 kernel with two accumulator
  * sets (bd_binary_linear only; the automatic choice for M > 128; 0 / 5 remain as the two-loop A/B references);
- * 100 generic edge kernel; 200 decode GEMV.
+ * 100 generic edge kernel; 200 decode path (200 + KS forces a k-split), which picks between 300 (+ KS) = the VALU sign-flip
+ * kernel and 400 (+ KS) = the MFMA + sign-LUT kernel.
  * A forced variant whose preconditions fail returns BD_E_BAD_SHAPE instead of silently falling back. */
 int bd_set_gemm_variant(int variant);
 /* which family the LAST call on this thread dispatched to (same codes as above) */
@@ -97,6 +104,9 @@ int bd_last_gemm_variant(void);
 /* tuning hook: tile walk order of the MFMA tile kernels -- groups of `group_m` tile rows, m fastest inside a group, then n
  * (1 = n fastest, >= tiles_m = m fastest, 0 = automatic).  Results do not depend on it. */
 int bd_set_tile_group_m(int group_m);
+/* 1 (default) = the decode path sums its split-k partials with a second launch (gemv_reduce_kernel); 0 = in-launch ticket
+ * reduction (single launch; measured equal within noise, and it needs the zeroed ticket area described at bd_delta_bmm) */
+int bd_set_decode_two_launch(int on);
 
 #ifdef __cplusplus
 }

@@ -77,7 +77,7 @@ static void make_problem(Problem& q) {
     }
     HIPCHECK(hipMalloc(&q.dC, q.c_elems() * 4));
     q.ws_bytes = bd_gemm_workspace_bytes(q.B, q.M, q.N, q.K);
-    if (q.ws_bytes) HIPCHECK(hipMalloc(&q.dWs, q.ws_bytes));
+    if (q.ws_bytes) { HIPCHECK(hipMalloc(&q.dWs, q.ws_bytes)); HIPCHECK(hipMemset(q.dWs, 0, q.ws_bytes)); }   // ticket-area contract
 }
 static void free_problem(Problem& q) {
     hipFree(q.dA); hipFree(q.dP); hipFree(q.dAl); hipFree(q.dC);
@@ -415,6 +415,15 @@ int main(int argc, char** argv) {
                 fails += run_case("gemv_m2", 3, 2, 512, 512, dt, dt, fused, 3, -1, 0, S);
                 fails += run_case("gemv_b1", 1, 1, 4096, 4096, dt, dt, fused, 1, -1, 0, S);
                 fails += run_case("gemv_bcast16", 16, 1, 256, 2048, dt, BD_F32, fused, 1, -1, 0, S);
+                fails += run_case("gemv_m4_t4", 4, 4, 200, 160, dt, dt, fused, 4, -1, 0, S);          // M > 1, ragged N, K % 128 != 0
+                fails += run_case("gemv_t16", 16, 1, 520, 1184, dt, BD_F32, fused, 16, -1, 0, S);    // 16 masks, partial last iteration
+                fails += run_case("gemv_ks3", 5, 1, 300, 1536, dt, dt, fused, 5, 203, 0, S);
+                for (int v : {300, 400}) {      // both decode kernel families, forced
+                    fails += run_case("gemv_forced", 6, 1, 1000, 1024, dt, BD_F32, fused, 6, v, 0, S);
+                    fails += run_case("gemv_forced_m4", 4, 4, 200, 160, dt, dt, fused, 4, v, 0, S);
+                    fails += run_case("gemv_forced_t16", 16, 1, 520, 1184, dt, BD_F32, fused, 16, v, 0, S);
+                    fails += run_case("gemv_forced_ks3", 5, 1, 300, 1536, dt, dt, fused, 5, v + 3, 0, S);
+                }
             }
         fails += run_case("edge_m1_tile", 1, 1, 256, 128, BD_BF16, BD_F32, 0, 1, 3, 0, S);
         fails += run_case("edge_n_odd", 1, 70, 77, 64, BD_BF16, BD_BF16, 0, 1, -1, 0, S);
@@ -437,14 +446,34 @@ int main(int argc, char** argv) {
         fails += run_case("fused_gate", 1, 2048, 11008, 4096, BD_BF16, BD_BF16, 1, 1, -1, it, 2048);
         fails += run_case("fused_down", 1, 2048, 4096, 11008, BD_BF16, BD_BF16, 1, 1, -1, it, 2048);
         fails += run_case("c1_128", 1, 128, 4096, 4096, BD_BF16, BD_BF16, 1, 1, -1, it, 2048);
+        for (int two : {1, 0})
+        for (int v : {-1, 300, 400})
         for (int T : {1, 6, 16}) {
-            fails += run_case("decode_delta", T, 1, 4096, 4096, BD_BF16, BD_BF16, 0, T, -1, 50, 2048);
-            fails += run_case("decode_fused", T, 1, 4096, 4096, BD_BF16, BD_BF16, 1, T, -1, 50, 2048);
+            bd_set_decode_two_launch(two);
+            fails += run_case("decode_delta", T, 1, 4096, 4096, BD_BF16, BD_BF16, 0, T, v, 50, 2048);
+            fails += run_case(two ? "decode_fused_2launch" : "decode_fused", T, 1, 4096, 4096, BD_BF16, BD_BF16, 1, T, v, 50, 2048);
+        }
+        bd_set_decode_two_launch(1);
+        for (int v : {-1, 300, 400}) {
+            fails += run_case("decode_fused_gate", 6, 1, 14336, 4096, BD_F16, BD_F16, 1, 6, v, 50, 2048);
+            fails += run_case("decode_fused_down", 6, 1, 4096, 14336, BD_F16, BD_F16, 1, 6, v, 50, 2048);
+            fails += run_case("decode_fused_kv", 6, 1, 1024, 4096, BD_F16, BD_F16, 1, 6, v, 50, 2048);
         }
         fails += run_case("decode_fused_gate", 6, 1, 14336, 4096, BD_F16, BD_F16, 1, 6, -1, 50, 2048);
         fails += run_case("decode_fused_down", 6, 1, 4096, 14336, BD_F16, BD_F16, 1, 6, -1, 50, 2048);
         fails += run_case("decode_fused_kv", 6, 1, 1024, 4096, BD_F16, BD_F16, 1, 6, -1, 50, 2048);
         fails += run_case("prefill64_t6", 6, 64, 4096, 4096, BD_F16, BD_F16, 1, 6, -1, it, 2048);
+    } else if (mode == "dec_pmc") {
+        // few launches of each decode kernel family for rocprofv3 counter passes (kernel name = family, grid size = shape)
+        for (int two : {1, 0})
+        for (int v : {300, 400}) {
+            bd_set_decode_two_launch(two);
+            if (!two && v == 300) continue;
+            fails += run_case("q_t1", 1, 1, 4096, 4096, BD_BF16, BD_BF16, 1, 1, v, 5, 0);
+            fails += run_case("q_t6", 6, 1, 4096, 4096, BD_BF16, BD_BF16, 1, 6, v, 5, 0);
+            fails += run_case("gate_t6", 6, 1, 14336, 4096, BD_BF16, BD_BF16, 1, 6, v, 5, 0);
+            fails += run_case("q_t16_delta", 16, 1, 4096, 4096, BD_BF16, BD_BF16, 0, 16, v, 5, 0);
+        }
     } else if (mode == "bits") {
         bits_bench();
     } else if (mode == "ks") {

@@ -173,6 +173,9 @@ SHAPES = [
     (1, 70, 64, 77, 1, None),                                                          # odd N
     (6, 1, 1024, 1000, 6, None), (3, 2, 512, 512, 3, None), (16, 1, 2048, 256, 1, None), (1, 1, 4096, 4096, 1, None),  # decode
     (6, 64, 1024, 1024, 6, None),                                                      # demo prefill
+    (4, 4, 160, 200, 4, None), (16, 1, 1184, 520, 16, None), (5, 1, 1536, 300, 5, 203),  # decode: M > 1, K % 128 != 0, 16 masks, forced k-split
+    (6, 1, 1024, 1000, 6, 300), (3, 2, 512, 512, 1, 300), (16, 1, 1184, 520, 16, 300),   # forced: VALU sign-flip decode kernel
+    (6, 1, 1024, 1000, 6, 400), (3, 2, 512, 512, 1, 400), (4, 4, 160, 200, 4, 400), (5, 1, 1536, 300, 5, 403),   # forced: MFMA + LUT decode kernel
 ]
 
 
@@ -229,6 +232,25 @@ def test_binary_linear_vs_oracle(bd, oracle, dtype, shape):
     # not worse than the reference's own multi-rounding chain (SURVEY.md 7b iv)
     ref_chain = oracle.binary_linear(a, w, p, alpha, round_mode=1)
     assert fro16 <= relerr(ref_chain, ref32)[0] * 1.05 + 1e-7
+
+
+def test_decode_in_launch_reduction_matches_two_launch_form(bd):
+    """Split-k partials are summed in k-slice order by whichever block arrives last (ticket) -- bit-identical to the two-launch
+    reduce kernel, on every repeat (the ticket area of the persistent workspace is handed back zeroed)."""
+    from bitdelta_amd import _lib
+    L = _lib.lib()
+    a, p, w, alpha = rand_problem(6, 1, 4096, 1024, torch.float16, 6, seed=21)
+    a, p, w, alpha = dev(a), dev(p), dev(w), dev(alpha)
+    try:
+        L.bd_set_decode_two_launch(1)
+        ref = bd.binary_linear(a, w, p, alpha).clone()
+        L.bd_set_decode_two_launch(0)
+        for _ in range(5):
+            got = bd.binary_linear(a, w, p, alpha)
+            assert L.bd_last_gemm_variant() == 200
+            assert torch.equal(got, ref)
+    finally:
+        L.bd_set_decode_two_launch(1)          # library default
 
 
 def test_delta_bmm_alpha_accumulate_and_groups(bd, oracle):
