@@ -104,7 +104,7 @@ struct Problem {
     hipStream_t st;
 };
 
-constexpr int GEMV_MAX_M = 4, GEMV_MAX_R = 16;
+constexpr int GEMV_MAX_M = 16, GEMV_MAX_R = 16;   // decode kernels: <= 16 activation rows per launch; larger batches are chunked
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
@@ -117,7 +117,7 @@ inline bool fast_ok(const Problem& q) {
     return ok;
 }
 inline bool gemv_ok(const Problem& q) {
-    bool ok = (q.M <= GEMV_MAX_M) && ((int64_t)q.B * q.M <= GEMV_MAX_R) && (q.K % 32 == 0) && aligned16(q.A) &&
+    bool ok = (q.M <= GEMV_MAX_M) && ((int64_t)q.B * q.M <= 4 * GEMV_MAX_R) && (q.K % 32 == 0) && aligned16(q.A) &&   // <= 4 chunks
               (q.sAm % 8 == 0) && (q.sAb % 8 == 0);
     if (q.W) ok = ok && aligned16(q.W) && (q.ldw % 8 == 0);
     return ok;
@@ -135,7 +135,7 @@ inline void gemv_split(const Problem& q, int& KS, int& kslice) {
     if (maxks < 1) maxks = 1;
     KS = want < 1 ? 1 : (want > maxks ? maxks : want);
     kslice = ((q.K + KS - 1) / KS + 127) / 128 * 128;
-    const int smax = gemv_kslice_max(gemv_rmax(q.B * q.M));
+    const int smax = gemv_kslice_max(16);
     if (kslice > smax) kslice = smax;                     // the activation slice lives in LDS
     KS = (q.K + kslice - 1) / kslice;
 }
@@ -169,7 +169,30 @@ int launch_gemv_mfma(const Problem& q, const GemvParams& gp) {
 }
 
 template <int DT>
+int launch_gemv_chunk(const Problem& q, bool valu_form);
+
+// batches of more than 16 activation rows run as consecutive launches over chunks of floor(16 / M) batch entries (each chunk streams
+// the base weight again; still far cheaper than M = 1 tiles of the MFMA tile kernels, which re-read it once per batch entry)
+template <int DT>
 int launch_gemv(const Problem& q, bool valu_form) {
+    const int cb = GEMV_MAX_R / q.M;
+    if (q.B <= cb) return launch_gemv_chunk<DT>(q, valu_form);
+    const int esz = q.out_dtype == BD_F32 ? 4 : 2;
+    for (int b0 = 0; b0 < q.B; b0 += cb) {
+        Problem c = q;
+        c.B = q.B - b0 < cb ? q.B - b0 : cb;
+        c.A = (const char*)q.A + (int64_t)b0 * q.sAb * 2;
+        c.P = q.P + (int64_t)b0 * q.sPb;
+        c.C = (char*)q.C + (int64_t)b0 * q.sCb * esz;
+        if (q.alpha) c.alpha = q.alpha + (int64_t)b0 * q.sAlb;
+        const int rc = launch_gemv_chunk<DT>(c, valu_form);
+        if (rc != BD_OK) return rc;
+    }
+    return BD_OK;
+}
+
+template <int DT>
+int launch_gemv_chunk(const Problem& q, bool valu_form) {
     GemvParams gp;
     gp.X = (const unsigned short*)q.A;
     gp.P = (const uint32_t*)q.P;
@@ -322,7 +345,11 @@ int dispatch3(const Problem& q) {
         case 100: return launch_generic<DT, FUSED, OUT_F32>(q);
         // decode: the VALU sign-flip kernel is as fast or faster on the fused Linear shapes (profiles/r01_decode_kernels.txt);
         // the MFMA + LUT kernel wins when the delta dominates (delta-only with >= 8 masks) and on narrow outputs (k/v projections)
-        case 200: return launch_gemv<DT>(q, !((!q.W && (q.sPb == 0 ? 1 : q.B) >= 8) || q.N <= 2048));
+        // ... and whenever a mask is shared by >= 2 rows (M > 1 or a broadcast mask): it expands each word once for all rows
+        case 200: {
+            const int cb = GEMV_MAX_R / q.M, bc = q.B < cb ? q.B : cb, nmask = q.sPb == 0 ? 1 : bc;
+            return launch_gemv<DT>(q, !((!q.W && nmask >= 8) || q.N <= 2048 || bc * q.M >= 2 * nmask));
+        }
         case 300: return launch_gemv<DT>(q, true);
         case 400: return launch_gemv<DT>(q, false);
         default: return BD_E_BAD_SHAPE;
@@ -351,8 +378,9 @@ int dispatch(const Problem& q) {
 
 extern "C" int64_t bd_gemm_workspace_bytes(int B, int M, int N, int K) {
     if (B <= 0 || M <= 0 || N <= 0 || K <= 0) return 0;
-    if (M > GEMV_MAX_M || (int64_t)B * M > GEMV_MAX_R) return 0;
+    if (M > GEMV_MAX_M || (int64_t)B * M > 4 * GEMV_MAX_R) return 0;
     Problem q{};
+    { const int cb = GEMV_MAX_R / M; B = B < cb ? B : cb; }     // the decode path works on chunks of <= 16 rows
     q.B = B; q.M = M; q.N = N; q.K = K;
     int KS, kslice;
     gemv_split(q, KS, kslice);

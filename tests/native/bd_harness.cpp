@@ -418,6 +418,9 @@ int main(int argc, char** argv) {
                 fails += run_case("gemv_m4_t4", 4, 4, 200, 160, dt, dt, fused, 4, -1, 0, S);          // M > 1, ragged N, K % 128 != 0
                 fails += run_case("gemv_t16", 16, 1, 520, 1184, dt, BD_F32, fused, 16, -1, 0, S);    // 16 masks, partial last iteration
                 fails += run_case("gemv_ks3", 5, 1, 300, 1536, dt, dt, fused, 5, 203, 0, S);
+                fails += run_case("gemv_m16", 1, 16, 300, 512, dt, dt, fused, 1, -1, 0, S);           // 16 rows sharing one mask
+                fails += run_case("gemv_chunks", 40, 1, 200, 256, dt, BD_F32, fused, 40, -1, 0, S);   // 40 tenants -> 3 chunks of <= 16 rows
+                fails += run_case("gemv_chunks_m3", 7, 3, 136, 192, dt, dt, fused, 7, -1, 0, S);      // chunks of 5 batch entries
                 for (int v : {300, 400}) {      // both decode kernel families, forced
                     fails += run_case("gemv_forced", 6, 1, 1000, 1024, dt, BD_F32, fused, 6, v, 0, S);
                     fails += run_case("gemv_forced_m4", 4, 4, 200, 160, dt, dt, fused, 4, v, 0, S);
@@ -463,6 +466,18 @@ int main(int argc, char** argv) {
         fails += run_case("decode_fused_down", 6, 1, 4096, 14336, BD_F16, BD_F16, 1, 6, -1, 50, 2048);
         fails += run_case("decode_fused_kv", 6, 1, 1024, 4096, BD_F16, BD_F16, 1, 6, -1, 50, 2048);
         fails += run_case("prefill64_t6", 6, 64, 4096, 4096, BD_F16, BD_F16, 1, 6, -1, it, 2048);
+    } else if (mode == "notebook") {
+        // the shapes the reference's notebook publishes (fp16, FLOP = 2*B*M*N*K, delta-only kernels)
+        for (int NK : {4096, 8192}) {
+            fails += run_case("nb_matmul_m1", 1, 1, NK, NK, BD_F16, BD_F16, 0, 1, -1, 100, 1024);
+            fails += run_case("nb_matmul_m16", 1, 16, NK, NK, BD_F16, BD_F16, 0, 1, -1, 100, 1024);
+            fails += run_case("nb_bmm_b16", 16, 1, NK, NK, BD_F16, BD_F16, 0, 16, -1, 100, 1024);
+            fails += run_case("nb_bmm_b8", 8, 1, NK, NK, BD_F16, BD_F16, 0, 8, -1, 100, 1024);
+            fails += run_case("nb_bmm_b1", 1, 1, NK, NK, BD_F16, BD_F16, 0, 1, -1, 100, 1024);
+        }
+        // the blog's "one Linear, decode" plots: B = 8 tenants at hidden ~10k; N = K = 8192 with 4..64 tenants (fused: base + deltas)
+        fails += run_case("blog_b8_h10240", 8, 1, 10240, 10240, BD_F16, BD_F16, 1, 8, -1, 50, 1024);
+        for (int T : {4, 16, 64}) fails += run_case("blog_8192_models", T, 1, 8192, 8192, BD_F16, BD_F16, 1, T, -1, 30, 1024);
     } else if (mode == "dec_pmc") {
         // few launches of each decode kernel family for rocprofv3 counter passes (kernel name = family, grid size = shape)
         for (int two : {1, 0})

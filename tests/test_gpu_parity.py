@@ -174,6 +174,7 @@ SHAPES = [
     (6, 1, 1024, 1000, 6, None), (3, 2, 512, 512, 3, None), (16, 1, 2048, 256, 1, None), (1, 1, 4096, 4096, 1, None),  # decode
     (6, 64, 1024, 1024, 6, None),                                                      # demo prefill
     (4, 4, 160, 200, 4, None), (16, 1, 1184, 520, 16, None), (5, 1, 1536, 300, 5, 203),  # decode: M > 1, K % 128 != 0, 16 masks, forced k-split
+    (1, 16, 512, 300, 1, None), (40, 1, 256, 200, 40, None), (7, 3, 192, 136, 7, None), (20, 1, 512, 264, 1, None),  # decode: 16 rows on one mask; > 16 rows -> chunks
     (6, 1, 1024, 1000, 6, 300), (3, 2, 512, 512, 1, 300), (16, 1, 1184, 520, 16, 300),   # forced: VALU sign-flip decode kernel
     (6, 1, 1024, 1000, 6, 400), (3, 2, 512, 512, 1, 400), (4, 4, 160, 200, 4, 400), (5, 1, 1536, 300, 5, 403),   # forced: MFMA + LUT decode kernel
 ]
