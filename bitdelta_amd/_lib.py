@@ -35,6 +35,7 @@ SIGNATURES = {
     "bd_last_gemm_variant": (_ci, []),
     "bd_set_tile_group_m": (_ci, [_ci]),
     "bd_set_decode_two_launch": (_ci, [_ci]),
+    "bd_set_decode_small_lut": (_ci, [_ci]),
 }
 
 _lib = None

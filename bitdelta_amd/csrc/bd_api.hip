@@ -13,6 +13,8 @@ using namespace bd;
 
 static int g_forced_variant = -1;
 static int g_forced_group_m = 0;        // 0 = automatic tile order
+static int g_col16_small_lut = 1;       // 1 (default) = the 16-column decode kernel uses the single 4-KiB sign LUT; 0 = 16-copy
+                                        // conflict-free table (measured: no gain at 4096^2, -15 % on 14336x4096; r01_decode_kernels.txt)
 static int g_gemv_two_launch = 1;       // 1 (default) = split-k partials are summed by gemv_reduce_kernel; 0 = in-launch tickets
                                         // (measured slower: the last-arriver tail is serial inside every tile; bd_gemv.h)
 static int g_gemv_target_blocks = 512;
@@ -23,6 +25,7 @@ extern "C" int bd_set_gemm_variant(int v) { g_forced_variant = v; return BD_OK; 
 extern "C" int bd_last_gemm_variant(void) { return t_last_variant; }
 extern "C" int bd_set_tile_group_m(int g) { g_forced_group_m = g; return BD_OK; }
 extern "C" int bd_set_decode_two_launch(int on) { g_gemv_two_launch = on ? 1 : 0; return BD_OK; }
+extern "C" int bd_set_decode_small_lut(int on) { g_col16_small_lut = on ? 1 : 0; return BD_OK; }
 
 extern "C" const char* bd_error_string(int code) {
     switch (code) {
@@ -171,12 +174,88 @@ int launch_gemv_mfma(const Problem& q, const GemvParams& gp) {
 template <int DT>
 int launch_gemv_chunk(const Problem& q, bool valu_form);
 
+// ---- no-split-k decode kernel (gemv_col16_kernel): 16 columns x all of k per block, 8 waves split k, LDS reduction
+constexpr int COL16_LDS_BUDGET = 160 * 1024 - 16 * 1024 /* red */ - 4096 /* LUT */ - 1024 /* slack */;
+inline void col16_split(int R, int K, int forced_ks, int& KS, int& kslice) {
+    int kmax = (COL16_LDS_BUDGET / (R * 2) - 8) / 128 * 128;      // k per block whose R activation rows fit in LDS
+    if (kmax < 128) kmax = 128;
+    KS = (K + kmax - 1) / kmax;
+    if (forced_ks > KS) KS = forced_ks;
+    kslice = ((K + KS - 1) / KS + 127) / 128 * 128;
+    KS = (K + kslice - 1) / kslice;
+}
+
+template <int DT, int NM, int LC>
+int launch_gemv_col16_lc(const Problem& q, const GemvParams& gp) {
+    dim3 grid((unsigned)((q.N + 15) / 16), (unsigned)gp.KS);
+    const unsigned lds = 4096u * LC + (unsigned)gp.R * (unsigned)(gp.kslice * 2 + 16);
+    auto kw = gemv_col16_kernel<DT, NM, true, LC>;
+    auto kd = gemv_col16_kernel<DT, NM, false, LC>;
+    static bool attr_set = false;                // benign race: idempotent
+    if (!attr_set) {
+        const int mx = 160 * 1024 - 16 * 1024 - 256;
+        if (hipFuncSetAttribute((const void*)kw, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+            hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
+            return BD_E_LAUNCH;
+        attr_set = true;
+    }
+    if (q.W) hipLaunchKernelGGL(kw, grid, dim3(512), lds, q.st, gp);
+    else hipLaunchKernelGGL(kd, grid, dim3(512), lds, q.st, gp);
+    return BD_OK;
+}
+
+template <int DT, int NM>
+int launch_gemv_col16(const Problem& q, const GemvParams& gp) {
+    // 16-copy conflict-free sign LUT when it fits next to the activation rows and there are masks enough to expand
+    const bool big = NM >= 2 && !g_col16_small_lut &&
+                     65536 + (int64_t)gp.R * (gp.kslice * 2 + 16) <= 160 * 1024 - 16 * 1024 - 256;
+    if constexpr (NM >= 2) { if (big) return launch_gemv_col16_lc<DT, NM, 16>(q, gp); }
+    return launch_gemv_col16_lc<DT, NM, 1>(q, gp);
+}
+
+template <int DT>
+int launch_gemv_col16_chunk(const Problem& q) {
+    GemvParams gp;
+    gp.X = (const unsigned short*)q.A;
+    gp.P = (const uint32_t*)q.P;
+    gp.W = (const unsigned short*)q.W;
+    gp.alpha = q.alpha;
+    gp.C = q.C;
+    gp.B = q.B; gp.M = q.M; gp.N = q.N; gp.K = q.K; gp.R = q.B * q.M;
+    gp.sXb = q.sAb; gp.sPb = q.sPb; gp.sCb = q.sCb;
+    gp.sXm = (int)q.sAm; gp.sCm = (int)q.sCm; gp.ldw = (int)q.ldw; gp.sAlb = (int)q.sAlb; gp.gsz = q.N / q.G;
+    const int forced = (g_forced_variant > 500 && g_forced_variant <= 564) ? g_forced_variant - 500 : 0;
+    col16_split(gp.R, q.K, forced, gp.KS, gp.kslice);
+    gp.round_mode = q.round_mode; gp.accumulate = q.accumulate; gp.out_f32 = (q.out_dtype == BD_F32);
+    gp.tickets = nullptr;
+    gp.ws = nullptr;
+    if (gp.KS > 1) {
+        const int64_t need = GEMV_TICKET_BYTES + (int64_t)gp.KS * gp.R * q.N * 4;
+        if (!q.ws || q.ws_bytes < need) return BD_E_WORKSPACE;
+        gp.ws = (float*)((char*)q.ws + GEMV_TICKET_BYTES);
+    }
+    const int nm = q.sPb == 0 ? 1 : q.B;
+    if (nm <= 1) launch_gemv_col16<DT, 1>(q, gp);
+    else if (nm <= 2) launch_gemv_col16<DT, 2>(q, gp);
+    else if (nm <= 3) launch_gemv_col16<DT, 3>(q, gp);
+    else if (nm <= 4) launch_gemv_col16<DT, 4>(q, gp);
+    else if (nm <= 6) launch_gemv_col16<DT, 6>(q, gp);
+    else if (nm <= 8) launch_gemv_col16<DT, 8>(q, gp);
+    else if (nm <= 12) launch_gemv_col16<DT, 12>(q, gp);
+    else launch_gemv_col16<DT, 16>(q, gp);
+    if (gp.KS > 1) {
+        dim3 g2((unsigned)((q.N + 255) / 256), (unsigned)gp.R);
+        hipLaunchKernelGGL((gemv_reduce_kernel<DT>), g2, dim3(256), 0, q.st, gp);
+    }
+    return launch_status();
+}
+
 // batches of more than 16 activation rows run as consecutive launches over chunks of floor(16 / M) batch entries (each chunk streams
 // the base weight again; still far cheaper than M = 1 tiles of the MFMA tile kernels, which re-read it once per batch entry)
 template <int DT>
-int launch_gemv(const Problem& q, bool valu_form) {
+int launch_gemv(const Problem& q, bool valu_form, bool col16 = false) {
     const int cb = GEMV_MAX_R / q.M;
-    if (q.B <= cb) return launch_gemv_chunk<DT>(q, valu_form);
+    if (q.B <= cb) return col16 ? launch_gemv_col16_chunk<DT>(q) : launch_gemv_chunk<DT>(q, valu_form);
     const int esz = q.out_dtype == BD_F32 ? 4 : 2;
     for (int b0 = 0; b0 < q.B; b0 += cb) {
         Problem c = q;
@@ -185,7 +264,7 @@ int launch_gemv(const Problem& q, bool valu_form) {
         c.P = q.P + (int64_t)b0 * q.sPb;
         c.C = (char*)q.C + (int64_t)b0 * q.sCb * esz;
         if (q.alpha) c.alpha = q.alpha + (int64_t)b0 * q.sAlb;
-        const int rc = launch_gemv_chunk<DT>(c, valu_form);
+        const int rc = col16 ? launch_gemv_col16_chunk<DT>(c) : launch_gemv_chunk<DT>(c, valu_form);
         if (rc != BD_OK) return rc;
     }
     return BD_OK;
@@ -315,6 +394,7 @@ int dispatch3(const Problem& q) {
     if (v > 200 && v <= 264) v = 200;        // 200 + KS: decode path with a forced k-split (test hook)
     if (v > 300 && v <= 364) v = 300;        // 300 (+ KS): force the VALU sign-flip decode kernel
     if (v > 400 && v <= 464) v = 400;        // 400 (+ KS): force the MFMA + LUT decode kernel
+    if (v > 500 && v <= 564) v = 500;        // 500 (+ KS): force the no-split-k 16-column decode kernel
     if (v < 0) {
         if (gemv_ok(q)) v = 200;
         else if (!fast_ok(q)) v = 100;
@@ -323,7 +403,7 @@ int dispatch3(const Problem& q) {
         else if (q.M > 32) v = 2;
         else v = 3;
     } else {
-        if ((v == 200 || v == 300 || v == 400) && !gemv_ok(q)) return BD_E_BAD_SHAPE;
+        if ((v == 200 || v == 300 || v == 400 || v == 500) && !gemv_ok(q)) return BD_E_BAD_SHAPE;
         if (v >= 0 && v <= 8 && !fast_ok(q)) return BD_E_BAD_SHAPE;
         if (v == 8 && !FUSED) return BD_E_BAD_SHAPE;
     }
@@ -348,10 +428,16 @@ int dispatch3(const Problem& q) {
         // ... and whenever a mask is shared by >= 2 rows (M > 1 or a broadcast mask): it expands each word once for all rows
         case 200: {
             const int cb = GEMV_MAX_R / q.M, bc = q.B < cb ? q.B : cb, nmask = q.sPb == 0 ? 1 : bc;
+            // no-split-k kernel (one launch) when the chunk's activations fit in LDS and there are enough 16-column blocks to fill
+            // the chip but not several rounds of them: 4096 < ... <= 8192 columns (+3..10 % over the two-launch kernels there)
+            int ks16, ksl16;
+            col16_split(bc * q.M, q.K, 0, ks16, ksl16);
+            if (ks16 == 1 && q.N > 2048 && q.N <= 8192) return launch_gemv<DT>(q, false, true);
             return launch_gemv<DT>(q, !((!q.W && nmask >= 8) || q.N <= 2048 || bc * q.M >= 2 * nmask));
         }
         case 300: return launch_gemv<DT>(q, true);
         case 400: return launch_gemv<DT>(q, false);
+        case 500: return launch_gemv<DT>(q, false, true);
         default: return BD_E_BAD_SHAPE;
     }
 }

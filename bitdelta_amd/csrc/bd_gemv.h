@@ -393,6 +393,146 @@ __global__ void __launch_bounds__(256) gemv_mfma_kernel(const GemvParams p) {
     if (p.KS > 1 && p.tickets) gemv_ticket_reduce<DT>(p, n0, lane, wave);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// No-split-k form of the MFMA decode kernel: ONE launch per Linear whenever the activation rows fit in LDS.
+//
+// gemv_kernel / gemv_mfma_kernel need ~512 blocks, so they slice k across blocks and pay a second launch (4.6 us of an 18 us
+// Linear) to sum the slices.  Here a block owns 16 output columns and ALL of k (or one of KS large slices when R*K*2 bytes of
+// activations exceed the LDS): its 8 waves split the k range, each running gemv_mfma_kernel's iteration (lane group g <-> word
+// row i+g, sign fragments from the LUT, base + per-mask accumulators on the matrix pipe), and the 8 partial tiles are summed
+// through LDS in wave order.  N/16 blocks fill the chip from N = 4096 up; column groups are XCD-remapped so the two 16-column
+// blocks that share every 128-byte line of sign words run on the same XCD.
+template <int DT, int NM, bool HASW, int LC>
+__global__ void __launch_bounds__(512) gemv_col16_kernel(const GemvParams p) {
+    constexpr int NW = 8;
+    // LC = copies of the sign LUT.  LC = 16 (used when 64 KiB more LDS is free): entry e of copy c sits at e*256 + c*16 and lane l
+    // reads copy l & 15, so the 16 lanes of every ds_read_b128 service group hit 16 different 16-byte slots of the 256-byte bank
+    // row whatever their bytes are -- conflict-free (random bytes on ONE table collide ~3-way, the measured 0.65 us per tenant per
+    // 4096^2 mask on top of the HBM time).  Here the table is built once per block of 8 waves under the first loads' latency.
+    constexpr int LUT_BYTES = 4096 * LC;
+    extern __shared__ __attribute__((aligned(256))) char dyn_lds[];     // [LUT][R rows x xrow bytes of activations]
+    __shared__ float red[NW][64][8];                                     // per wave, per lane: 4 base + 4 delta partials
+    char* const xs_lds = dyn_lds + LUT_BYTES;
+    const int xrow = p.kslice * 2 + 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    const int n0 = xcd_remap(blockIdx.x, gridDim.x) * 16, ks = blockIdx.y;
+    const int k_lo = ks * p.kslice, k_hi = min(p.K, k_lo + p.kslice);
+    const int i0 = k_lo >> 5, i_hi = k_hi >> 5, i_last = (p.K >> 5) - 1;
+    const int nit_blk = (i_hi - i0 + 3) >> 2;                            // 128-k iterations in this block's slice
+    const int per = (nit_blk + NW - 1) / NW;
+    const int it_lo = min(wave * per, nit_blk), it_hi = min(it_lo + per, nit_blk);
+    const int nmask = p.sPb == 0 ? 1 : p.B;
+
+    const int nw = min(n0 + li, p.N - 1);
+    const unsigned short* wr = HASW ? p.W + (long long)nw * p.ldw : nullptr;
+    const uint32_t* pw[NM];
+#pragma unroll
+    for (int t = 0; t < NM; ++t) pw[t] = p.P + (long long)min(t, nmask - 1) * p.sPb + nw;
+
+    struct Stage { u32x4_t wf[4]; uint32_t wd[NM]; };
+    auto load_iter = [&](Stage& st, int it) {
+        const int irow = min(i0 + 4 * it + g, i_last);
+#pragma unroll
+        for (int t = 0; t < NM; ++t) st.wd[t] = __builtin_nontemporal_load(pw[t] + (long long)irow * p.N);
+        if constexpr (HASW) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) st.wf[s] = __builtin_nontemporal_load((const u32x4_t*)(wr + irow * 32 + 8 * s));
+        }
+    };
+    Stage st[2];
+    if (it_lo < it_hi) load_iter(st[0], it_lo);
+
+    if (threadIdx.x < 256 || LC == 16) {   // sign LUT (LC = 16: both halves of the block write 8 copies each): entry e = the 8 (+-1.0) 16-bit values of byte e (bit j <-> k offset j)
+        constexpr uint32_t POS = One2<DT>::v & 0xffffu, NEG = POS | 0x8000u;
+        const int e = threadIdx.x & 255, half = threadIdx.x >> 8;
+        u32x4_t v;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) v[d] = (((e >> (2 * d)) & 1) ? POS : NEG) | ((((e >> (2 * d + 1)) & 1) ? POS : NEG) << 16);
+        if constexpr (LC == 16) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) *(u32x4_t*)(dyn_lds + e * 256 + (half * 8 + c) * 16) = v;
+        } else {
+            *(u32x4_t*)(dyn_lds + e * 16) = v;
+        }
+    }
+    {   // activation slice -> LDS (rows < R only)
+        const int kn = k_hi - k_lo;                                   // multiple of 32
+        for (int idx = threadIdx.x; idx < p.R * (kn >> 3); idx += 512) {
+            const int r = idx / (kn >> 3), c = idx - r * (kn >> 3);
+            const int b = r / p.M, m = r - b * p.M;
+            *(u32x4_t*)(xs_lds + r * xrow + c * 16) =
+                *(const u32x4_t*)(p.X + (long long)b * p.sXb + (long long)m * p.sXm + k_lo + c * 8);
+        }
+    }
+    __syncthreads();
+
+    f32x4_t accB = {0.f, 0.f, 0.f, 0.f}, accD[NM];
+#pragma unroll
+    for (int t = 0; t < NM; ++t) accD[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const char* xl = xs_lds + li * xrow + 64 * g;
+    const uint32_t copy_off = (uint32_t)li * 16u;
+
+    auto compute = [&](const Stage& cur, int it) {
+        const uint32_t keep = (i0 + 4 * it + g < i_hi) ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const u32x4_t xf = *(const u32x4_t*)(xl + it * 256 + 16 * s) & u32x4_t{keep, keep, keep, keep};
+            if constexpr (HASW) accB = mfma16<DT>(cur.wf[s], xf, accB);
+#pragma unroll
+            for (int t = 0; t < NM; ++t) {
+                uint32_t off;
+                if constexpr (LC == 16) off = __builtin_amdgcn_perm(cur.wd[t], copy_off, 0x0c0c0400u + ((uint32_t)s << 8));   // byte s -> bits 8..15, copy slot -> bits 0..7
+                else off = ((cur.wd[t] >> (8 * s)) & 0xffu) * 16u;
+                const u32x4_t sf = *(const u32x4_t*)(dyn_lds + off);
+                accD[t] = mfma16<DT>(sf, xf, accD[t]);
+            }
+        }
+    };
+    for (int it = it_lo; it < it_hi; it += 2) {
+        if (it + 1 < it_hi) load_iter(st[1], it + 1);
+        compute(st[0], it);
+        if (it + 1 < it_hi) {
+            if (it + 2 < it_hi) load_iter(st[0], it + 2);
+            compute(st[1], it + 1);
+        }
+    }
+
+    // lane (li, g) holds D[col = 4g + e][row = li] of this wave's k range: pick the accumulator of the row's mask, park both parts
+    {
+        const int b = min(li, p.R - 1) / p.M;
+        const int bm = p.sPb == 0 ? 0 : b;
+        f32x4_t d = accD[0];
+#pragma unroll
+        for (int t = 1; t < NM; ++t)
+            if (bm == t) d = accD[t];
+        *(f32x4_t*)&red[wave][lane][0] = accB;
+        *(f32x4_t*)&red[wave][lane][4] = d;
+    }
+    __syncthreads();
+    if (wave == 0 && li < p.R) {
+        const int b = li / p.M;
+        f32x4_t sb = {0.f, 0.f, 0.f, 0.f}, sd = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {                                 // fixed wave order: deterministic
+            sb += *(const f32x4_t*)&red[w][lane][0];
+            sd += *(const f32x4_t*)&red[w][lane][4];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = n0 + 4 * g + e;
+            if (n < p.N) {
+                float v = sd[e];
+                if (p.alpha) v *= p.alpha[(long long)b * p.sAlb + n / p.gsz];
+                if constexpr (HASW) v += sb[e];
+                if (p.KS == 1) store_out<DT>(p, li, n, v);
+                else gemv_store_partial(&p.ws[((long long)ks * p.R + li) * p.N + n], v);
+            }
+        }
+    }
+}
+
 template <int DT>
 __global__ void __launch_bounds__(256) gemv_reduce_kernel(const GemvParams p) {
     const int n = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;

@@ -96,7 +96,7 @@ int bd_merge_delta(void* W, int64_t ldw, const int32_t* P, const float* coeff, i
  * 256x256 / 256x128 (A/B reference for the shipped full-tile schedule); 8 = one-pass fused 256x128 kernel with two accumulator
  * sets (bd_binary_linear only; the automatic choice for M > 128; 0 / 5 remain as the two-loop A/B references);
  * 100 generic edge kernel; 200 decode path (200 + KS forces a k-split), which picks between 300 (+ KS) = the VALU sign-flip
- * kernel and 400 (+ KS) = the MFMA + sign-LUT kernel.
+ * kernel, 400 (+ KS) = the MFMA + sign-LUT kernel and 500 (+ KS) = the no-split-k kernel (16 columns x all of k per block).
  * A forced variant whose preconditions fail returns BD_E_BAD_SHAPE instead of silently falling back. */
 int bd_set_gemm_variant(int variant);
 /* which family the LAST call on this thread dispatched to (same codes as above) */
@@ -107,6 +107,8 @@ int bd_set_tile_group_m(int group_m);
 /* 1 (default) = the decode path sums its split-k partials with a second launch (gemv_reduce_kernel); 0 = in-launch ticket
  * reduction (single launch; measured equal within noise, and it needs the zeroed ticket area described at bd_delta_bmm) */
 int bd_set_decode_two_launch(int on);
+/* A/B hook: 1 (default) = the no-split-k decode kernel uses the single 4-KiB sign LUT; 0 = the 16-copy conflict-free table */
+int bd_set_decode_small_lut(int on);
 
 #ifdef __cplusplus
 }

@@ -421,12 +421,16 @@ int main(int argc, char** argv) {
                 fails += run_case("gemv_m16", 1, 16, 300, 512, dt, dt, fused, 1, -1, 0, S);           // 16 rows sharing one mask
                 fails += run_case("gemv_chunks", 40, 1, 200, 256, dt, BD_F32, fused, 40, -1, 0, S);   // 40 tenants -> 3 chunks of <= 16 rows
                 fails += run_case("gemv_chunks_m3", 7, 3, 136, 192, dt, dt, fused, 7, -1, 0, S);      // chunks of 5 batch entries
-                for (int v : {300, 400}) {      // both decode kernel families, forced
+                for (int v : {300, 400, 500}) {      // every decode kernel family, forced
                     fails += run_case("gemv_forced", 6, 1, 1000, 1024, dt, BD_F32, fused, 6, v, 0, S);
                     fails += run_case("gemv_forced_m4", 4, 4, 200, 160, dt, dt, fused, 4, v, 0, S);
                     fails += run_case("gemv_forced_t16", 16, 1, 520, 1184, dt, BD_F32, fused, 16, v, 0, S);
                     fails += run_case("gemv_forced_ks3", 5, 1, 300, 1536, dt, dt, fused, 5, v + 3, 0, S);
                 }
+                fails += run_case("col16_m16", 1, 16, 300, 512, dt, dt, fused, 1, 500, 0, S);
+                fails += run_case("col16_chunks", 40, 1, 200, 256, dt, BD_F32, fused, 40, 500, 0, S);
+                fails += run_case("col16_k8192_t16", 16, 1, 72, 8192, dt, dt, fused, 16, 500, 0, S);      // R*K*2 > LDS -> 2 k slices + reduce
+                fails += run_case("col16_q", 6, 1, 4096, 4096, dt, dt, fused, 6, 500, 0, S);
             }
         fails += run_case("edge_m1_tile", 1, 1, 256, 128, BD_BF16, BD_F32, 0, 1, 3, 0, S);
         fails += run_case("edge_n_odd", 1, 70, 77, 64, BD_BF16, BD_BF16, 0, 1, -1, 0, S);
@@ -449,15 +453,15 @@ int main(int argc, char** argv) {
         fails += run_case("fused_gate", 1, 2048, 11008, 4096, BD_BF16, BD_BF16, 1, 1, -1, it, 2048);
         fails += run_case("fused_down", 1, 2048, 4096, 11008, BD_BF16, BD_BF16, 1, 1, -1, it, 2048);
         fails += run_case("c1_128", 1, 128, 4096, 4096, BD_BF16, BD_BF16, 1, 1, -1, it, 2048);
-        for (int two : {1, 0})
-        for (int v : {-1, 300, 400})
+        for (int two : {1})
+        for (int v : {-1, 300, 400, 500})
         for (int T : {1, 6, 16}) {
             bd_set_decode_two_launch(two);
             fails += run_case("decode_delta", T, 1, 4096, 4096, BD_BF16, BD_BF16, 0, T, v, 50, 2048);
             fails += run_case(two ? "decode_fused_2launch" : "decode_fused", T, 1, 4096, 4096, BD_BF16, BD_BF16, 1, T, v, 50, 2048);
         }
         bd_set_decode_two_launch(1);
-        for (int v : {-1, 300, 400}) {
+        for (int v : {-1, 300, 400, 500}) {
             fails += run_case("decode_fused_gate", 6, 1, 14336, 4096, BD_F16, BD_F16, 1, 6, v, 50, 2048);
             fails += run_case("decode_fused_down", 6, 1, 4096, 14336, BD_F16, BD_F16, 1, 6, v, 50, 2048);
             fails += run_case("decode_fused_kv", 6, 1, 1024, 4096, BD_F16, BD_F16, 1, 6, v, 50, 2048);
@@ -466,6 +470,21 @@ int main(int argc, char** argv) {
         fails += run_case("decode_fused_down", 6, 1, 4096, 14336, BD_F16, BD_F16, 1, 6, -1, 50, 2048);
         fails += run_case("decode_fused_kv", 6, 1, 1024, 4096, BD_F16, BD_F16, 1, 6, -1, 50, 2048);
         fails += run_case("prefill64_t6", 6, 64, 4096, 4096, BD_F16, BD_F16, 1, 6, -1, it, 2048);
+    } else if (mode == "dec500") {
+        // the no-split-k decode kernel with the 16-copy conflict-free sign LUT (default) vs the single 4-KiB table, interleaved
+        for (int rep = 0; rep < 2; ++rep)
+            for (int small : {0, 1}) {
+                bd_set_decode_small_lut(small);
+                const char* tg = small ? "lut4k" : "lut64k";
+                for (int T : {2, 6, 8}) {
+                    fails += run_case(tg, T, 1, 4096, 4096, BD_BF16, BD_BF16, 0, T, 500, 50, 2048);
+                    fails += run_case(tg, T, 1, 4096, 4096, BD_BF16, BD_BF16, 1, T, 500, 50, 2048);
+                }
+                fails += run_case(tg, 6, 1, 14336, 4096, BD_F16, BD_F16, 1, 6, 500, 50, 2048);
+                fails += run_case(tg, 6, 1, 1024, 4096, BD_F16, BD_F16, 1, 6, 500, 50, 2048);
+                fails += run_case(tg, 4, 4, 4096, 4096, BD_BF16, BD_BF16, 1, 4, 500, 50, 2048);
+            }
+        bd_set_decode_small_lut(1);
     } else if (mode == "notebook") {
         // the shapes the reference's notebook publishes (fp16, FLOP = 2*B*M*N*K, delta-only kernels)
         for (int NK : {4096, 8192}) {

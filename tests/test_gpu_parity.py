@@ -177,6 +177,8 @@ SHAPES = [
     (1, 16, 512, 300, 1, None), (40, 1, 256, 200, 40, None), (7, 3, 192, 136, 7, None), (20, 1, 512, 264, 1, None),  # decode: 16 rows on one mask; > 16 rows -> chunks
     (6, 1, 1024, 1000, 6, 300), (3, 2, 512, 512, 1, 300), (16, 1, 1184, 520, 16, 300),   # forced: VALU sign-flip decode kernel
     (6, 1, 1024, 1000, 6, 400), (3, 2, 512, 512, 1, 400), (4, 4, 160, 200, 4, 400), (5, 1, 1536, 300, 5, 403),   # forced: MFMA + LUT decode kernel
+    (6, 1, 1024, 1000, 6, 500), (3, 2, 512, 512, 1, 500), (4, 4, 160, 200, 4, 500), (5, 1, 1536, 300, 5, 503),   # forced: no-split-k 16-column kernel
+    (16, 1, 8192, 72, 16, 500), (1, 16, 512, 300, 1, 500), (40, 1, 256, 200, 40, 500),
 ]
 
 
