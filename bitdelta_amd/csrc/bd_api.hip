@@ -388,6 +388,17 @@ inline int choose_big_tile(const Problem& q) {
     return c5 < c0 ? 5 : 0;
 }
 
+// one-pass fused kernel: 256x128 tile vs 128x128 tile.  Rounds of CU-wide tile waves x measured relative tile cost: a 128x128 tile
+// takes ~0.70 of a 256x128 tile's k loop (profiles/r01_small_m.txt), so it wins exactly when it does not add rounds (M <~ 1024 at
+// N = 4096; M <= 256 at N = 11008).
+inline int choose_fused_tile(const Problem& q) {
+    const long long cus = num_cus();
+    const long long tn = (q.N + 127) / 128;
+    const long long t8 = (q.M + 255) / 256 * tn * q.B, t9 = (q.M + 127) / 128 * tn * q.B;
+    const double c8 = (double)((t8 + cus - 1) / cus), c9 = (double)((t9 + cus - 1) / cus) * 0.70;
+    return c9 < c8 ? 9 : 8;
+}
+
 template <int DT, bool FUSED, bool OUT_F32>
 int dispatch3(const Problem& q) {
     int v = g_forced_variant;
@@ -398,14 +409,15 @@ int dispatch3(const Problem& q) {
     if (v < 0) {
         if (gemv_ok(q)) v = 200;
         else if (!fast_ok(q)) v = 100;
-        else if (q.M > 128) v = FUSED ? 8 : choose_big_tile(q);   // fused: one-pass 256x128 kernel (profiles/r01_fx_vs_two_loop.txt)
+        else if (FUSED && q.M > 64) v = choose_fused_tile(q);     // fused: one-pass kernel (profiles/r01_fx_vs_two_loop.txt, r01_small_m.txt)
+        else if (q.M > 128) v = choose_big_tile(q);
         else if (q.M > 64) v = 1;
         else if (q.M > 32) v = 2;
         else v = 3;
     } else {
         if ((v == 200 || v == 300 || v == 400 || v == 500) && !gemv_ok(q)) return BD_E_BAD_SHAPE;
-        if (v >= 0 && v <= 8 && !fast_ok(q)) return BD_E_BAD_SHAPE;
-        if (v == 8 && !FUSED) return BD_E_BAD_SHAPE;
+        if (v >= 0 && v <= 9 && !fast_ok(q)) return BD_E_BAD_SHAPE;
+        if ((v == 8 || v == 9) && !FUSED) return BD_E_BAD_SHAPE;
     }
     t_last_variant = v;
     switch (v) {
@@ -418,6 +430,9 @@ int dispatch3(const Problem& q) {
         case 5: return launch_tile<GemmCfg<DT, 256, 128, 2, 4, 4, FUSED, OUT_F32, 0>, 2>(q);
         case 8:
             if constexpr (FUSED) return launch_tile<FxCfg<DT, 256, 128, 3, OUT_F32, 1>, 3>(q);
+            else return BD_E_BAD_SHAPE;
+        case 9:      // one-pass fused, 128x128 tile, 4-slot ring: twice the tiles when 256x128 cannot fill the CUs (128 < M <~ 768)
+            if constexpr (FUSED) return launch_tile<FxCfg<DT, 128, 128, 4, OUT_F32, 1>, 3>(q);
             else return BD_E_BAD_SHAPE;
         case 1: return launch_tile<GemmCfg<DT, 128, 256, 1, 4, 4, FUSED, OUT_F32>>(q);
         case 2: return launch_tile<GemmCfg<DT, 64, 256, 1, 4, 4, FUSED, OUT_F32>>(q);

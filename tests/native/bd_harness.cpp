@@ -407,6 +407,10 @@ int main(int argc, char** argv) {
                     fails += run_case("fx_nk1", 1, 257, 136, 64, dt, dt, 1, 1, 8, 0, S);
                     fails += run_case("fx_nk2", 3, 300, 264, 128, dt, dt, 1, 1, 8, 0, S);
                     fails += run_case("fx_big", 1, 1024, 1024, 2048, dt, dt, 1, 1, 8, 0, S);
+                    fails += run_case("fx128", 2, 200, 520, 256, dt, BD_F32, 1, 2, 9, 0, S);
+                    fails += run_case("fx128_nk1", 1, 257, 136, 64, dt, dt, 1, 1, 9, 0, S);
+                    fails += run_case("fx128_nk2", 3, 300, 264, 128, dt, dt, 1, 1, 9, 0, S);
+                    fails += run_case("fx128_big", 1, 640, 1024, 2048, dt, dt, 1, 1, 9, 0, S);
                 }
                 fails += run_case("tile_bcast", 3, 130, 300, 128, dt, dt, fused, 1, 0, 0, S);
                 fails += run_case("auto_big", 1, 512, 768, 1024, dt, dt, fused, 1, -1, 0, S);
@@ -470,6 +474,16 @@ int main(int argc, char** argv) {
         fails += run_case("decode_fused_down", 6, 1, 4096, 14336, BD_F16, BD_F16, 1, 6, -1, 50, 2048);
         fails += run_case("decode_fused_kv", 6, 1, 1024, 4096, BD_F16, BD_F16, 1, 6, -1, 50, 2048);
         fails += run_case("prefill64_t6", 6, 64, 4096, 4096, BD_F16, BD_F16, 1, 6, -1, it, 2048);
+    } else if (mode == "smallm") {
+        // fused Linear at 128 < M <= 1024: 256x128 one-pass tile (8) vs 128x128 one-pass tile (9) vs the two-loop 128x256 tile (1)
+        for (int rep = 0; rep < 2; ++rep)
+            for (int M : {192, 256, 384, 512, 768, 1024})
+                for (int v : {8, 9, 1}) {
+                    fails += run_case("smallm_q", 1, M, 4096, 4096, BD_BF16, BD_BF16, 1, 1, v, 20, 1024);
+                    fails += run_case("smallm_gate", 1, M, 11008, 4096, BD_BF16, BD_BF16, 1, 1, v, 20, 1024);
+                }
+        fails += run_case("smallm_t6", 6, 200, 4096, 4096, BD_F16, BD_F16, 1, 6, 9, 20, 1024);
+        fails += run_case("smallm_t6", 6, 200, 4096, 4096, BD_F16, BD_F16, 1, 6, 8, 20, 1024);
     } else if (mode == "dec500") {
         // the no-split-k decode kernel with the 16-copy conflict-free sign LUT (default) vs the single 4-KiB table, interleaved
         for (int rep = 0; rep < 2; ++rep)
