@@ -13,8 +13,9 @@ using namespace bd;
 
 static int g_forced_variant = -1;
 static int g_forced_group_m = 0;        // 0 = automatic tile order
-static int g_col16_small_lut = 1;       // 1 (default) = the 16-column decode kernel uses the single 4-KiB sign LUT; 0 = 16-copy
-                                        // conflict-free table (measured: no gain at 4096^2, -15 % on 14336x4096; r01_decode_kernels.txt)
+static int g_col16_small_lut = -1;      // sign LUT of the 16-column decode kernel: -1 auto, 1 = single 4-KiB table, 0 = 16-copy conflict-free
+                                        // table whenever it fits.  Auto = 16 copies for delta-only launches (-16..18 % at 6-8 masks;
+                                        // fused: -2 %, and -15 % WORSE on 14336x4096 where it drops to one block per CU)
 static int g_gemv_two_launch = 1;       // 1 (default) = split-k partials are summed by gemv_reduce_kernel; 0 = in-launch tickets
                                         // (measured slower: the last-arriver tail is serial inside every tile; bd_gemv.h)
 static int g_gemv_target_blocks = 512;
@@ -25,7 +26,7 @@ extern "C" int bd_set_gemm_variant(int v) { g_forced_variant = v; return BD_OK; 
 extern "C" int bd_last_gemm_variant(void) { return t_last_variant; }
 extern "C" int bd_set_tile_group_m(int g) { g_forced_group_m = g; return BD_OK; }
 extern "C" int bd_set_decode_two_launch(int on) { g_gemv_two_launch = on ? 1 : 0; return BD_OK; }
-extern "C" int bd_set_decode_small_lut(int on) { g_col16_small_lut = on ? 1 : 0; return BD_OK; }
+extern "C" int bd_set_decode_small_lut(int mode) { g_col16_small_lut = mode < 0 ? -1 : (mode ? 1 : 0); return BD_OK; }
 
 extern "C" const char* bd_error_string(int code) {
     switch (code) {
@@ -207,8 +208,8 @@ int launch_gemv_col16_lc(const Problem& q, const GemvParams& gp) {
 template <int DT, int NM>
 int launch_gemv_col16(const Problem& q, const GemvParams& gp) {
     // 16-copy conflict-free sign LUT when it fits next to the activation rows and there are masks enough to expand
-    const bool big = NM >= 2 && !g_col16_small_lut &&
-                     65536 + (int64_t)gp.R * (gp.kslice * 2 + 16) <= 160 * 1024 - 16 * 1024 - 256;
+    const bool want = g_col16_small_lut < 0 ? (q.W == nullptr) : (g_col16_small_lut == 0);
+    const bool big = NM >= 2 && want && 65536 + (int64_t)gp.R * (gp.kslice * 2 + 16) <= 160 * 1024 - 16 * 1024 - 256;
     if constexpr (NM >= 2) { if (big) return launch_gemv_col16_lc<DT, NM, 16>(q, gp); }
     return launch_gemv_col16_lc<DT, NM, 1>(q, gp);
 }

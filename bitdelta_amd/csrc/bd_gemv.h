@@ -451,8 +451,16 @@ __global__ void __launch_bounds__(512) gemv_col16_kernel(const GemvParams p) {
 #pragma unroll
         for (int d = 0; d < 4; ++d) v[d] = (((e >> (2 * d)) & 1) ? POS : NEG) | ((((e >> (2 * d + 1)) & 1) ? POS : NEG) << 16);
         if constexpr (LC == 16) {
+            // slot index = 16 e + c is linear in the thread id, so every ds_write_b128 stores 64 consecutive 16-byte slots
+            // (one entry per 16 lanes): conflict-free.  (Thread = entry, 16 strided copies each, was 8-way conflicted: +1.5 us.)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) *(u32x4_t*)(dyn_lds + e * 256 + (half * 8 + c) * 16) = v;
+            for (int j = 0; j < 8; ++j) {
+                const int slot = threadIdx.x + 512 * j, ee = slot >> 4;
+                u32x4_t w;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) w[d] = (((ee >> (2 * d)) & 1) ? POS : NEG) | ((((ee >> (2 * d + 1)) & 1) ? POS : NEG) << 16);
+                *(u32x4_t*)(dyn_lds + slot * 16) = w;
+            }
         } else {
             *(u32x4_t*)(dyn_lds + e * 16) = v;
         }

@@ -108,8 +108,9 @@ int bd_set_tile_group_m(int group_m);
 /* 1 (default) = the decode path sums its split-k partials with a second launch (gemv_reduce_kernel); 0 = in-launch ticket
  * reduction (single launch; measured equal within noise, and it needs the zeroed ticket area described at bd_delta_bmm) */
 int bd_set_decode_two_launch(int on);
-/* A/B hook: 1 (default) = the no-split-k decode kernel uses the single 4-KiB sign LUT; 0 = the 16-copy conflict-free table */
-int bd_set_decode_small_lut(int on);
+/* A/B hook, sign LUT of the no-split-k decode kernel: -1 (default) automatic, 1 = single 4-KiB table, 0 = 16-copy conflict-free
+ * 64-KiB table whenever it fits in LDS */
+int bd_set_decode_small_lut(int mode);
 
 #ifdef __cplusplus
 }

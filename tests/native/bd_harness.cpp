@@ -435,6 +435,10 @@ int main(int argc, char** argv) {
                 fails += run_case("col16_chunks", 40, 1, 200, 256, dt, BD_F32, fused, 40, 500, 0, S);
                 fails += run_case("col16_k8192_t16", 16, 1, 72, 8192, dt, dt, fused, 16, 500, 0, S);      // R*K*2 > LDS -> 2 k slices + reduce
                 fails += run_case("col16_q", 6, 1, 4096, 4096, dt, dt, fused, 6, 500, 0, S);
+                bd_set_decode_small_lut(0);       // 16-copy sign LUT, forced for fused launches too
+                fails += run_case("col16_lut64k", 6, 1, 1000, 1024, dt, BD_F32, fused, 6, 500, 0, S);
+                fails += run_case("col16_lut64k_m2", 3, 2, 520, 544, dt, dt, fused, 3, 500, 0, S);
+                bd_set_decode_small_lut(-1);
             }
         fails += run_case("edge_m1_tile", 1, 1, 256, 128, BD_BF16, BD_F32, 0, 1, 3, 0, S);
         fails += run_case("edge_n_odd", 1, 70, 77, 64, BD_BF16, BD_BF16, 0, 1, -1, 0, S);
@@ -484,6 +488,13 @@ int main(int argc, char** argv) {
                 }
         fails += run_case("smallm_t6", 6, 200, 4096, 4096, BD_F16, BD_F16, 1, 6, 9, 20, 1024);
         fails += run_case("smallm_t6", 6, 200, 4096, 4096, BD_F16, BD_F16, 1, 6, 8, 20, 1024);
+    } else if (mode == "dec_pmc2") {
+        // one shape per kernel instantiation (NM = 1 / 6 / 16) so that counters can be keyed by kernel name: 4096^2 fused
+        const bool big_lut = argc > 2 && atoi(argv[2]) == 64;
+        bd_set_decode_small_lut(big_lut ? 0 : 1);
+        for (int v : {500, 300})
+            for (int T : {1, 6, 8, 16}) fails += run_case("q", T, 1, 4096, 4096, BD_BF16, BD_BF16, 1, T, v, 5, 0);
+        bd_set_decode_small_lut(-1);
     } else if (mode == "dec500") {
         // the no-split-k decode kernel with the 16-copy conflict-free sign LUT (default) vs the single 4-KiB table, interleaved
         for (int rep = 0; rep < 2; ++rep)
@@ -498,7 +509,7 @@ int main(int argc, char** argv) {
                 fails += run_case(tg, 6, 1, 1024, 4096, BD_F16, BD_F16, 1, 6, 500, 50, 2048);
                 fails += run_case(tg, 4, 4, 4096, 4096, BD_BF16, BD_BF16, 1, 4, 500, 50, 2048);
             }
-        bd_set_decode_small_lut(1);
+        bd_set_decode_small_lut(-1);
     } else if (mode == "notebook") {
         // the shapes the reference's notebook publishes (fp16, FLOP = 2*B*M*N*K, delta-only kernels)
         for (int NK : {4096, 8192}) {

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-(kernel, grid) table from rocprofv3 outputs: kernel-trace durations + any number of --pmc counter_collection CSVs.
+"""Per-kernel table from rocprofv3 outputs: kernel-trace durations + any number of --pmc counter_collection CSVs.
 
 usage: pmc_table.py <kernel_trace.csv> <counter_collection.csv>... [--match substring]
 Counters are averaged per dispatch (summed over dimensions/instances inside one dispatch first)."""
@@ -24,13 +24,13 @@ dur = collections.defaultdict(list)
 for r in csv.DictReader(open(args[0])):
     if match and match not in r["Kernel_Name"]:
         continue
-    dur[(short(r["Kernel_Name"]), r.get("Grid_Size", r.get("Grid_Size_X", "?")))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    dur[(short(r["Kernel_Name"]), "*")].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 ctr = collections.defaultdict(lambda: collections.defaultdict(dict))
 for path in args[1:]:
     for r in csv.DictReader(open(path)):
         if match and match not in r["Kernel_Name"]:
             continue
-        key = (short(r["Kernel_Name"]), r.get("Grid_Size", "?"))
+        key = (short(r["Kernel_Name"]), "*")
         d = ctr[key][r["Counter_Name"]]
         d[r["Dispatch_Id"]] = d.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
 for key in sorted(dur):
