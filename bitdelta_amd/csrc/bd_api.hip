@@ -16,6 +16,7 @@ static int g_forced_group_m = 0;        // 0 = automatic tile order
 static int g_col16_small_lut = -1;      // sign LUT of the 16-column decode kernel: -1 auto, 1 = single 4-KiB table, 0 = 16-copy conflict-free
                                         // table whenever it fits.  Auto = 16 copies for delta-only launches (-16..18 % at 6-8 masks;
                                         // fused: -2 %, and -15 % WORSE on 14336x4096 where it drops to one block per CU)
+static int g_col16_no_per4 = 0;         // A/B hook: 1 = the 16-column decode kernel always uses its generic one-ahead loop
 static int g_gemv_two_launch = 1;       // 1 (default) = split-k partials are summed by gemv_reduce_kernel; 0 = in-launch tickets
                                         // (measured slower: the last-arriver tail is serial inside every tile; bd_gemv.h)
 static int g_gemv_target_blocks = 512;
@@ -26,6 +27,7 @@ extern "C" int bd_set_gemm_variant(int v) { g_forced_variant = v; return BD_OK; 
 extern "C" int bd_last_gemm_variant(void) { return t_last_variant; }
 extern "C" int bd_set_tile_group_m(int g) { g_forced_group_m = g; return BD_OK; }
 extern "C" int bd_set_decode_two_launch(int on) { g_gemv_two_launch = on ? 1 : 0; return BD_OK; }
+extern "C" int bd_set_decode_generic_loop(int on) { g_col16_no_per4 = on ? 1 : 0; return BD_OK; }
 extern "C" int bd_set_decode_small_lut(int mode) { g_col16_small_lut = mode < 0 ? -1 : (mode ? 1 : 0); return BD_OK; }
 
 extern "C" const char* bd_error_string(int code) {
@@ -186,12 +188,12 @@ inline void col16_split(int R, int K, int forced_ks, int& KS, int& kslice) {
     KS = (K + kslice - 1) / kslice;
 }
 
-template <int DT, int NM, int LC>
+template <int DT, int NM, int LC, int PER>
 int launch_gemv_col16_lc(const Problem& q, const GemvParams& gp) {
     dim3 grid((unsigned)((q.N + 15) / 16), (unsigned)gp.KS);
     const unsigned lds = 4096u * LC + (unsigned)gp.R * (unsigned)(gp.kslice * 2 + 16);
-    auto kw = gemv_col16_kernel<DT, NM, true, LC>;
-    auto kd = gemv_col16_kernel<DT, NM, false, LC>;
+    auto kw = gemv_col16_kernel<DT, NM, true, LC, PER>;
+    auto kd = gemv_col16_kernel<DT, NM, false, LC, PER>;
     static bool attr_set = false;                // benign race: idempotent
     if (!attr_set) {
         const int mx = 160 * 1024 - 16 * 1024 - 256;
@@ -205,13 +207,21 @@ int launch_gemv_col16_lc(const Problem& q, const GemvParams& gp) {
     return BD_OK;
 }
 
+template <int DT, int NM, int LC>
+int launch_gemv_col16_per(const Problem& q, const GemvParams& gp) {
+    // every wave owns exactly 4 whole iterations (one slice of K = 4096): the straight-line, everything-in-flight instantiation
+    // (measured, `bd_harness dec500`: -3..7 % for delta-only launches, but +7..13 % SLOWER for fused ones -> delta-only only)
+    const bool per4 = gp.KS == 1 && q.K == 4096 && !q.W && !g_col16_no_per4;
+    return per4 ? launch_gemv_col16_lc<DT, NM, LC, 4>(q, gp) : launch_gemv_col16_lc<DT, NM, LC, 0>(q, gp);
+}
+
 template <int DT, int NM>
 int launch_gemv_col16(const Problem& q, const GemvParams& gp) {
     // 16-copy conflict-free sign LUT when it fits next to the activation rows and there are masks enough to expand
     const bool want = g_col16_small_lut < 0 ? (q.W == nullptr) : (g_col16_small_lut == 0);
     const bool big = NM >= 2 && want && 65536 + (int64_t)gp.R * (gp.kslice * 2 + 16) <= 160 * 1024 - 16 * 1024 - 256;
-    if constexpr (NM >= 2) { if (big) return launch_gemv_col16_lc<DT, NM, 16>(q, gp); }
-    return launch_gemv_col16_lc<DT, NM, 1>(q, gp);
+    if constexpr (NM >= 2) { if (big) return launch_gemv_col16_per<DT, NM, 16>(q, gp); }
+    return launch_gemv_col16_per<DT, NM, 1>(q, gp);
 }
 
 template <int DT>

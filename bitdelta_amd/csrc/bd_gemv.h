@@ -402,7 +402,7 @@ __global__ void __launch_bounds__(256) gemv_mfma_kernel(const GemvParams p) {
 // row i+g, sign fragments from the LUT, base + per-mask accumulators on the matrix pipe), and the 8 partial tiles are summed
 // through LDS in wave order.  N/16 blocks fill the chip from N = 4096 up; column groups are XCD-remapped so the two 16-column
 // blocks that share every 128-byte line of sign words run on the same XCD.
-template <int DT, int NM, bool HASW, int LC>
+template <int DT, int NM, bool HASW, int LC, int PER>
 __global__ void __launch_bounds__(512) gemv_col16_kernel(const GemvParams p) {
     constexpr int NW = 8;
     // LC = copies of the sign LUT.  LC = 16 (used when 64 KiB more LDS is free): entry e of copy c sits at e*256 + c*16 and lane l
@@ -441,8 +441,19 @@ __global__ void __launch_bounds__(512) gemv_col16_kernel(const GemvParams p) {
             for (int s = 0; s < 4; ++s) st.wf[s] = __builtin_nontemporal_load((const u32x4_t*)(wr + irow * 32 + 8 * s));
         }
     };
-    Stage st[2];
-    if (it_lo < it_hi) load_iter(st[0], it_lo);
+    // PER = 4 (every wave owns exactly 4 iterations: K = 4096 in one slice), straight-line: iterations 0-1 are in flight while the
+    // activations are staged; iterations 2-3 are issued right after the barrier and land under the MFMAs of 0-1.  (vmcnt retires in
+    // order, so anything issued BEFORE the staging loads must land before the staged data can be used: issuing all four up front
+    // would serialise "everything arrives" -> "all compute".)  With one iteration of prefetch the base stream and the delta work of a
+    // wave ran back to back (floor + base + delta; profiles/r01_decode_kernels.txt).  PER = 0: generic loop, one iteration ahead.
+    constexpr int NST = PER == 4 ? 4 : 2;
+    Stage st[NST];
+    if constexpr (PER == 4) {
+        load_iter(st[0], it_lo);
+        load_iter(st[1], it_lo + 1);
+    } else {
+        if (it_lo < it_hi) load_iter(st[0], it_lo);
+    }
 
     if (threadIdx.x < 256 || LC == 16) {   // sign LUT (LC = 16: both halves of the block write 8 copies each): entry e = the 8 (+-1.0) 16-bit values of byte e (bit j <-> k offset j)
         constexpr uint32_t POS = One2<DT>::v & 0xffffu, NEG = POS | 0x8000u;
@@ -498,12 +509,19 @@ __global__ void __launch_bounds__(512) gemv_col16_kernel(const GemvParams p) {
             }
         }
     };
-    for (int it = it_lo; it < it_hi; it += 2) {
-        if (it + 1 < it_hi) load_iter(st[1], it + 1);
-        compute(st[0], it);
-        if (it + 1 < it_hi) {
-            if (it + 2 < it_hi) load_iter(st[0], it + 2);
-            compute(st[1], it + 1);
+    if constexpr (PER == 4) {
+        load_iter(st[2], it_lo + 2);
+        load_iter(st[3], it_lo + 3);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) compute(st[u], it_lo + u);
+    } else {
+        for (int it = it_lo; it < it_hi; it += 2) {
+            if (it + 1 < it_hi) load_iter(st[1], it + 1);
+            compute(st[0], it);
+            if (it + 1 < it_hi) {
+                if (it + 2 < it_hi) load_iter(st[0], it + 2);
+                compute(st[1], it + 1);
+            }
         }
     }
 

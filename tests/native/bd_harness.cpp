@@ -498,10 +498,11 @@ int main(int argc, char** argv) {
     } else if (mode == "dec500") {
         // the no-split-k decode kernel with the 16-copy conflict-free sign LUT (default) vs the single 4-KiB table, interleaved
         for (int rep = 0; rep < 2; ++rep)
-            for (int small : {0, 1}) {
-                bd_set_decode_small_lut(small);
-                const char* tg = small ? "lut4k" : "lut64k";
-                for (int T : {2, 6, 8}) {
+            for (int small : {0, 1, 2}) {
+                bd_set_decode_small_lut(small == 2 ? 1 : small);
+                bd_set_decode_generic_loop(small == 2 ? 1 : 0);
+                const char* tg = small == 2 ? "lut4k_loop" : small ? "lut4k" : "lut64k";
+                for (int T : {1, 6, 8, 16}) {
                     fails += run_case(tg, T, 1, 4096, 4096, BD_BF16, BD_BF16, 0, T, 500, 50, 2048);
                     fails += run_case(tg, T, 1, 4096, 4096, BD_BF16, BD_BF16, 1, T, 500, 50, 2048);
                 }
@@ -509,7 +510,7 @@ int main(int argc, char** argv) {
                 fails += run_case(tg, 6, 1, 1024, 4096, BD_F16, BD_F16, 1, 6, 500, 50, 2048);
                 fails += run_case(tg, 4, 4, 4096, 4096, BD_BF16, BD_BF16, 1, 4, 500, 50, 2048);
             }
-        bd_set_decode_small_lut(-1);
+        bd_set_decode_small_lut(-1); bd_set_decode_generic_loop(0);
     } else if (mode == "notebook") {
         // the shapes the reference's notebook publishes (fp16, FLOP = 2*B*M*N*K, delta-only kernels)
         for (int NK : {4096, 8192}) {
