@@ -110,6 +110,17 @@ struct Problem {
     hipStream_t st;
 };
 
+inline int num_cus() {
+    static int cus = 0;   // benign race: idempotent
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        cus = n;
+    }
+    return cus;
+}
+
 constexpr int GEMV_MAX_M = 16, GEMV_MAX_R = 16;   // decode kernels: <= 16 activation rows per launch; larger batches are chunked
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -219,7 +230,8 @@ template <int DT, int NM>
 int launch_gemv_col16(const Problem& q, const GemvParams& gp) {
     // 16-copy conflict-free sign LUT when it fits next to the activation rows and there are masks enough to expand
     const bool want = g_col16_small_lut < 0 ? (q.W == nullptr) : (g_col16_small_lut == 0);
-    const bool big = NM >= 2 && want && 65536 + (int64_t)gp.R * (gp.kslice * 2 + 16) <= 160 * 1024 - 16 * 1024 - 256;
+    const bool big = NM >= 2 && want && 65536 + (int64_t)gp.R * (gp.kslice * 2 + 16) <= 160 * 1024 - 16 * 1024 - 256 &&
+                     (g_col16_small_lut == 0 || (q.N + 15) / 16 <= num_cus());      // auto: only when one block per CU covers N
     if constexpr (NM >= 2) { if (big) return launch_gemv_col16_per<DT, NM, 16>(q, gp); }
     return launch_gemv_col16_per<DT, NM, 1>(q, gp);
 }
@@ -331,16 +343,6 @@ int launch_gemv_chunk(const Problem& q, bool valu_form) {
     return launch_status();
 }
 
-inline int num_cus() {
-    static int cus = 0;   // benign race: idempotent
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
-        cus = n;
-    }
-    return cus;
-}
 
 inline GemmParams make_params(const Problem& q, int BM, int BN) {
     GemmParams p;
@@ -456,9 +458,14 @@ int dispatch3(const Problem& q) {
             const int cb = GEMV_MAX_R / q.M, bc = q.B < cb ? q.B : cb, nmask = q.sPb == 0 ? 1 : bc;
             // no-split-k kernel (one launch) when the chunk's activations fit in LDS and there are enough 16-column blocks to fill
             // the chip but not several rounds of them: 4096 < ... <= 8192 columns (+3..10 % over the two-launch kernels there)
+            // (all of its N/16 blocks must be resident at once: a second round of 8-wave blocks pays the start-up latency again --
+            // 8192x8192, 4 tenants: 50.8 vs 37.5 us)
             int ks16, ksl16;
             col16_split(bc * q.M, q.K, 0, ks16, ksl16);
-            if (ks16 == 1 && q.N > 2048 && q.N <= 8192) return launch_gemv<DT>(q, false, true);
+            const long long lds16 = 4096 + (long long)bc * q.M * (ksl16 * 2 + 16) + 16 * 1024 + 512;
+            const long long per_cu = lds16 > 0 ? (160 * 1024) / lds16 : 0;
+            if (ks16 == 1 && q.N > 2048 && (q.N + 15) / 16 <= (long long)num_cus() * (per_cu < 2 ? per_cu : 2))
+                return launch_gemv<DT>(q, false, true);
             return launch_gemv<DT>(q, !((!q.W && nmask >= 8) || q.N <= 2048 || bc * q.M >= 2 * nmask));
         }
         case 300: return launch_gemv<DT>(q, true);

@@ -111,8 +111,8 @@ int bd_set_decode_two_launch(int on);
 /* A/B hook, sign LUT of the no-split-k decode kernel: -1 (default) automatic, 1 = single 4-KiB table, 0 = 16-copy conflict-free
  * 64-KiB table whenever it fits in LDS */
 int bd_set_decode_small_lut(int mode);
-/* A/B hook: 1 = the no-split-k decode kernel always runs its generic one-iteration-ahead loop (default 0: K = 4096 launches use the
- * straight-line instantiation that issues all of a wave's loads up front) */
+/* A/B hook: 1 = the no-split-k decode kernel always runs its generic one-iteration-ahead loop (default 0: delta-only K = 4096
+ * launches use the straight-line instantiation: iterations 0-1 in flight during activation staging, 2-3 issued after the barrier) */
 int bd_set_decode_generic_loop(int on);
 
 #ifdef __cplusplus
