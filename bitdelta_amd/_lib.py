@@ -34,6 +34,7 @@ SIGNATURES = {
     "bd_set_gemm_variant": (_ci, [_ci]),
     "bd_last_gemm_variant": (_ci, []),
     "bd_set_tile_group_m": (_ci, [_ci]),
+    "bd_set_launch_chunking": (_ci, [_ci]),
     "bd_set_decode_two_launch": (_ci, [_ci]),
     "bd_set_decode_small_lut": (_ci, [_ci]),
     "bd_set_decode_generic_loop": (_ci, [_ci]),

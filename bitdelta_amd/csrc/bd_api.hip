@@ -17,6 +17,7 @@ static int g_col16_small_lut = -1;      // sign LUT of the 16-column decode kern
                                         // table whenever it fits.  Auto = 16 copies for delta-only launches (-16..18 % at 6-8 masks;
                                         // fused: -2 %, and -15 % WORSE on 14336x4096 where it drops to one block per CU)
 static int g_col16_no_per4 = 0;         // A/B hook: 1 = the 16-column decode kernel always uses its generic one-ahead loop
+static int g_launch_chunking = 0;       // 1 = multi-round tile problems are issued as single-round launches (measured: no gain; off)
 static int g_gemv_two_launch = 1;       // 1 (default) = split-k partials are summed by gemv_reduce_kernel; 0 = in-launch tickets
                                         // (measured slower: the last-arriver tail is serial inside every tile; bd_gemv.h)
 static int g_gemv_target_blocks = 512;
@@ -27,6 +28,7 @@ extern "C" int bd_set_gemm_variant(int v) { g_forced_variant = v; return BD_OK; 
 extern "C" int bd_last_gemm_variant(void) { return t_last_variant; }
 extern "C" int bd_set_tile_group_m(int g) { g_forced_group_m = g; return BD_OK; }
 extern "C" int bd_set_decode_two_launch(int on) { g_gemv_two_launch = on ? 1 : 0; return BD_OK; }
+extern "C" int bd_set_launch_chunking(int on) { g_launch_chunking = on ? 1 : 0; return BD_OK; }
 extern "C" int bd_set_decode_generic_loop(int on) { g_col16_no_per4 = on ? 1 : 0; return BD_OK; }
 extern "C" int bd_set_decode_small_lut(int mode) { g_col16_small_lut = mode < 0 ? -1 : (mode ? 1 : 0); return BD_OK; }
 
@@ -349,6 +351,7 @@ inline GemmParams make_params(const Problem& q, int BM, int BN) {
     p.A = (const char*)q.A; p.P = q.P; p.C = (char*)q.C; p.W = (const char*)q.W; p.alpha = q.alpha;
     p.M = q.M; p.N = q.N; p.K = q.K;
     p.tiles_m = (q.M + BM - 1) / BM; p.tiles_n = (q.N + BN - 1) / BN;
+    p.tile_m0 = 0; p.tile_n0 = 0;
     p.sAb = q.sAb; p.sPb = q.sPb; p.sCb = q.sCb;
     p.sAm = (int)q.sAm; p.sCm = (int)q.sCm; p.ldw = (int)q.ldw;
     p.sAlb = (int)q.sAlb; p.gsz = q.N / q.G;
@@ -377,6 +380,32 @@ int launch_tile(const Problem& q) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess)
             return BD_E_LAUNCH;
         attr_set = true;
+    }
+    // Experiment kept behind bd_set_launch_chunking(1): issue a multi-round problem as several launches of at most one tile per CU
+    // (an mc x nc block of tiles each, via GemmParams::tile_m0 / tile_n0).  Hypothesis: rounds inside one launch drift apart and that
+    // is why 8192x4096x4096 runs 10 % below back-to-back 2048-row launches.  Measured (profiles/r01_launch_chunking.txt): no gain
+    // (-0..3 %, -15 % with 6 tenants) -- the back-to-back figure was warm-cache re-reads of the same operands, not synchronisation.
+    const long long cus = num_cus();
+    const long long total = (long long)p.tiles_m * p.tiles_n * q.B;
+    if (SCHED >= 2 && g_launch_chunking && total > cus && q.B <= cus) {
+        const long long per = cus / q.B;                                   // tiles per launch and batch entry
+        // orientation A: all tile rows x as many tile columns as fit; B: all tile columns x as many rows as fit
+        long long mcA = p.tiles_m < per ? p.tiles_m : per, ncA = per / mcA; if (ncA > p.tiles_n) ncA = p.tiles_n;
+        long long ncB = p.tiles_n < per ? p.tiles_n : per, mcB = per / ncB; if (mcB > p.tiles_m) mcB = p.tiles_m;
+        const long long nA = ((p.tiles_m + mcA - 1) / mcA) * ((p.tiles_n + ncA - 1) / ncA);
+        const long long nB = ((p.tiles_m + mcB - 1) / mcB) * ((p.tiles_n + ncB - 1) / ncB);
+        const int mc = (int)(nA <= nB ? mcA : mcB), nc = (int)(nA <= nB ? ncA : ncB);
+        for (int m0 = 0; m0 < p.tiles_m; m0 += mc)
+            for (int n0 = 0; n0 < p.tiles_n; n0 += nc) {
+                GemmParams c = p;
+                c.tile_m0 = m0; c.tile_n0 = n0;
+                c.tiles_m = p.tiles_m - m0 < mc ? p.tiles_m - m0 : mc;
+                c.tiles_n = p.tiles_n - n0 < nc ? p.tiles_n - n0 : nc;
+                if (c.group_m > c.tiles_m) c.group_m = c.tiles_m;
+                dim3 grid((unsigned)(c.tiles_m * c.tiles_n), (unsigned)q.B);
+                hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, q.st, c);
+            }
+        return launch_status();
     }
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)q.B);
     hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, q.st, p);

@@ -33,7 +33,9 @@ struct GemmParams {
     const char* W;        // base weight [N, K] 16-bit (fused only)
     const float* alpha;   // fp32 [B or 1, G] (fused / accumulate only)
     int M, N, K;
-    int tiles_m, tiles_n;
+    int tiles_m, tiles_n;     // tiles covered by THIS launch ...
+    int tile_m0, tile_n0;     // ... starting at this tile of the problem (the host splits multi-round problems into launches of
+                              // at most one tile per CU: bd_api.hip launch_tile)
     long long sAb, sPb, sCb;  // batch strides in elements (sPb = 0 broadcasts one mask)
     int sAm, sCm, ldw;        // row strides in elements
     int sAlb, gsz;            // alpha batch stride (0 = broadcast), columns per scale group
@@ -50,8 +52,8 @@ __device__ __forceinline__ void tile_coords(const GemmParams& p, int wg, int& ti
     const int g = wg / gsz, r = wg - g * gsz;
     const int rows = min(p.group_m, p.tiles_m - g * p.group_m);  // the last group may be short
     const int q = r / rows;
-    tile_m = __builtin_amdgcn_readfirstlane(g * p.group_m + (r - q * rows));
-    tile_n = __builtin_amdgcn_readfirstlane(q);
+    tile_m = __builtin_amdgcn_readfirstlane(p.tile_m0 + g * p.group_m + (r - q * rows));
+    tile_n = __builtin_amdgcn_readfirstlane(p.tile_n0 + q);
 }
 
 // OPT bits (tuning switches, measured in DESIGN.md): 1 = sched_group_barrier MFMA/VALU/DS interleave of the delta

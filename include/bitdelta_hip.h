@@ -105,6 +105,8 @@ int bd_last_gemm_variant(void);
 /* tuning hook: tile walk order of the MFMA tile kernels -- groups of `group_m` tile rows, m fastest inside a group, then n
  * (1 = n fastest, >= tiles_m = m fastest, 0 = automatic).  Results do not depend on it. */
 int bd_set_tile_group_m(int group_m);
+/* A/B hook: 1 = problems of more than one tile per CU are issued as consecutive single-round launches; 0 (default) = one launch */
+int bd_set_launch_chunking(int on);
 /* 1 (default) = the decode path sums its split-k partials with a second launch (gemv_reduce_kernel); 0 = in-launch ticket
  * reduction (single launch; measured equal within noise, and it needs the zeroed ticket area described at bd_delta_bmm) */
 int bd_set_decode_two_launch(int on);

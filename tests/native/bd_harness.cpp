@@ -478,6 +478,23 @@ int main(int argc, char** argv) {
         fails += run_case("decode_fused_down", 6, 1, 4096, 14336, BD_F16, BD_F16, 1, 6, -1, 50, 2048);
         fails += run_case("decode_fused_kv", 6, 1, 1024, 4096, BD_F16, BD_F16, 1, 6, -1, 50, 2048);
         fails += run_case("prefill64_t6", 6, 64, 4096, 4096, BD_F16, BD_F16, 1, 6, -1, it, 2048);
+    } else if (mode == "chunk") {
+        // multi-round shapes: one launch vs single-round launch chunks (dispatcher hook), interleaved
+        for (int rep = 0; rep < 2; ++rep)
+            for (int on : {1, 0}) {
+                bd_set_launch_chunking(on);
+                const char* tg = on ? "chunked" : "one_launch";
+                fails += run_case(tg, 1, 2048, 11008, 4096, BD_BF16, BD_BF16, 1, 1, -1, 20, 2048);
+                fails += run_case(tg, 1, 4096, 4096, 4096, BD_BF16, BD_BF16, 1, 1, -1, 20, 2048);
+                fails += run_case(tg, 1, 8192, 4096, 4096, BD_BF16, BD_BF16, 1, 1, -1, 20, 2048);
+                fails += run_case(tg, 1, 4096, 11008, 4096, BD_BF16, BD_BF16, 1, 1, -1, 20, 2048);
+                fails += run_case(tg, 1, 4096, 4096, 11008, BD_BF16, BD_BF16, 1, 1, -1, 20, 2048);
+                fails += run_case(tg, 1, 8192, 4096, 4096, BD_BF16, BD_BF16, 0, 1, -1, 20, 2048);
+                fails += run_case(tg, 1, 16384, 4096, 4096, BD_BF16, BD_BF16, 0, 1, -1, 20, 2048);
+                fails += run_case(tg, 6, 1024, 4096, 4096, BD_F16, BD_F16, 1, 6, -1, 20, 2048);
+                fails += run_case(tg, 1, 3000, 5000, 1024, BD_F16, BD_F32, 1, 1, -1, 20, 4096);      // ragged edges in both directions
+            }
+        bd_set_launch_chunking(0);
     } else if (mode == "smallm") {
         // fused Linear at 128 < M <= 1024: 256x128 one-pass tile (8) vs 128x128 one-pass tile (9) vs the two-loop 128x256 tile (1)
         for (int rep = 0; rep < 2; ++rep)
