@@ -351,7 +351,7 @@ inline GemmParams make_params(const Problem& q, int BM, int BN) {
     p.A = (const char*)q.A; p.P = q.P; p.C = (char*)q.C; p.W = (const char*)q.W; p.alpha = q.alpha;
     p.M = q.M; p.N = q.N; p.K = q.K;
     p.tiles_m = (q.M + BM - 1) / BM; p.tiles_n = (q.N + BN - 1) / BN;
-    p.tile_m0 = 0; p.tile_n0 = 0;
+    p.tile_m0 = 0; p.tile_n0 = 0; p.ksplit = 1;
     p.sAb = q.sAb; p.sPb = q.sPb; p.sCb = q.sCb;
     p.sAm = (int)q.sAm; p.sCm = (int)q.sCm; p.ldw = (int)q.ldw;
     p.sAlb = (int)q.sAlb; p.gsz = q.N / q.G;
@@ -441,6 +441,49 @@ inline int choose_fused_tile(const Problem& q) {
     return c9 < c8 ? 9 : 8;
 }
 
+// Split-k for the one-pass fused kernel at mid-size M (16 < M <= 512: decode batches, speculative decoding, short prefills), where
+// even 128x128 tiles leave most CUs idle and the launch is bound by how fast FEW CUs can stream W.  KS slices of k per tile (each
+// block writes an fp32 partial [M][N] slab to the workspace) + one reduce launch.  Returns KS (1 = do not split).
+constexpr int64_t SPLITK_WS_CAP = 64ll << 20;
+inline int splitk_factor(int B, int M, int N, int K) {
+    if (M <= 16 || M > 512 || K % 64 || N % 8) return 1;
+    const long long cus = num_cus();
+    const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128) * B;
+    if (tiles * 2 > cus) return 1;                       // already at least half a round of tiles
+    long long ks = cus / tiles;
+    if (ks > 8) ks = 8;
+    const long long by_k = (K / 64) / 8;                 // at least 8 k-tiles (512 k) per slice
+    if (ks > by_k) ks = by_k;
+    while (ks > 1 && (int64_t)B * ks * M * N * 4 > SPLITK_WS_CAP) --ks;
+    return ks < 2 ? 1 : (int)ks;
+}
+
+template <int DT>
+int launch_fused_splitk(const Problem& q, int KS) {
+    const int64_t need = GEMV_TICKET_BYTES + (int64_t)q.B * KS * q.M * q.N * 4;
+    if (!q.ws || q.ws_bytes < need) return BD_E_WORKSPACE;
+    float* part = (float*)((char*)q.ws + GEMV_TICKET_BYTES);
+    Problem c = q;
+    c.C = part; c.out_dtype = BD_F32; c.sCm = q.N; c.sCb = (int64_t)q.M * q.N;     // slab y = b * KS + ks
+    using Cfg = FxCfg<DT, 128, 128, 4, true, 1>;
+    GemmParams p = make_params(c, Cfg::BM, Cfg::BN);
+    p.ksplit = KS;
+    auto kern = delta_gemm_fx_kernel<Cfg>;
+    static bool attr_set = false;   // benign race: idempotent
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess)
+            return BD_E_LAUNCH;
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)(q.B * KS));
+    hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, q.st, p);
+    const long long per = (long long)q.M * q.N / 4;
+    dim3 g2((unsigned)((per + 255) / 256), (unsigned)q.B);
+    hipLaunchKernelGGL((splitk_reduce_kernel<DT>), g2, dim3(256), 0, q.st, (const float*)part, q.C, q.B, KS, q.M, q.N,
+                       (long long)q.sCb, (int)q.sCm, q.out_dtype == BD_F32 ? 1 : 0);
+    return launch_status();
+}
+
 template <int DT, bool FUSED, bool OUT_F32>
 int dispatch3(const Problem& q) {
     int v = g_forced_variant;
@@ -451,15 +494,19 @@ int dispatch3(const Problem& q) {
     if (v < 0) {
         if (gemv_ok(q)) v = 200;
         else if (!fast_ok(q)) v = 100;
-        else if (FUSED && q.M > 64) v = choose_fused_tile(q);     // fused: one-pass kernel (profiles/r01_fx_vs_two_loop.txt, r01_small_m.txt)
+        else if (FUSED && q.M > 16 && q.sCm % 4 == 0 && q.sCb % 4 == 0 && splitk_factor(q.B, q.M, q.N, q.K) > 1 && q.ws &&
+                 q.ws_bytes >= GEMV_TICKET_BYTES + (int64_t)q.B * splitk_factor(q.B, q.M, q.N, q.K) * q.M * q.N * 4) v = 10;
+        else if (FUSED && q.M > 16) v = choose_fused_tile(q);     // fused: one-pass kernel (profiles/r01_fx_vs_two_loop.txt, r01_small_m.txt,
+                                                                  // r01_mid_m.txt: also for 16 < M <= 64, rows padded to the 128-row tile)
         else if (q.M > 128) v = choose_big_tile(q);
         else if (q.M > 64) v = 1;
         else if (q.M > 32) v = 2;
         else v = 3;
     } else {
         if ((v == 200 || v == 300 || v == 400 || v == 500) && !gemv_ok(q)) return BD_E_BAD_SHAPE;
-        if (v >= 0 && v <= 9 && !fast_ok(q)) return BD_E_BAD_SHAPE;
-        if ((v == 8 || v == 9) && !FUSED) return BD_E_BAD_SHAPE;
+        if (v >= 0 && v <= 10 && !fast_ok(q)) return BD_E_BAD_SHAPE;
+        if ((v == 8 || v == 9 || v == 10) && !FUSED) return BD_E_BAD_SHAPE;
+        if (v == 10 && (q.N % 8 || q.sCm % 4 || q.sCb % 4)) return BD_E_BAD_SHAPE;
     }
     t_last_variant = v;
     switch (v) {
@@ -473,6 +520,14 @@ int dispatch3(const Problem& q) {
         case 8:
             if constexpr (FUSED) return launch_tile<FxCfg<DT, 256, 128, 3, OUT_F32, 1>, 3>(q);
             else return BD_E_BAD_SHAPE;
+        case 10: {   // one-pass fused, 128x128 tile, split-k over blockIdx.y + reduce launch (forced: KS from the rule, at least 2)
+            if constexpr (FUSED) {
+                int ks = splitk_factor(q.B, q.M, q.N, q.K);
+                if (ks < 2) ks = (q.K / 64 >= 2) ? 2 : 1;
+                if (ks < 2) return BD_E_BAD_SHAPE;
+                return launch_fused_splitk<DT>(q, ks);
+            } else return BD_E_BAD_SHAPE;
+        }
         case 9:      // one-pass fused, 128x128 tile, 4-slot ring: twice the tiles when 256x128 cannot fill the CUs (128 < M <~ 768)
             if constexpr (FUSED) return launch_tile<FxCfg<DT, 128, 128, 4, OUT_F32, 1>, 3>(q);
             else return BD_E_BAD_SHAPE;
@@ -526,7 +581,16 @@ int dispatch(const Problem& q) {
 
 extern "C" int64_t bd_gemm_workspace_bytes(int B, int M, int N, int K) {
     if (B <= 0 || M <= 0 || N <= 0 || K <= 0) return 0;
-    if (M > GEMV_MAX_M || (int64_t)B * M > 4 * GEMV_MAX_R) return 0;
+    if (M > GEMV_MAX_M || (int64_t)B * M > 4 * GEMV_MAX_R) {
+        // mid-size M: split-k partial slabs of the fused tile kernel (also covers the forced-variant test hook's KS = 2)
+        if (M > 16 && M <= 512 && K % 64 == 0 && N % 8 == 0) {
+            int ks = splitk_factor(B, M, N, K);
+            if (ks < 2) ks = 2;
+            const int64_t need = (int64_t)B * ks * M * N * 4;
+            return need <= SPLITK_WS_CAP * 2 ? GEMV_TICKET_BYTES + need : 0;
+        }
+        return 0;
+    }
     Problem q{};
     { const int cb = GEMV_MAX_R / M; B = B < cb ? B : cb; }     // the decode path works on chunks of <= 16 rows
     q.B = B; q.M = M; q.N = N; q.K = K;

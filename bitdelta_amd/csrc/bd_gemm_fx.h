@@ -55,16 +55,22 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_fx_kernel(const GemmParams
     int tile_m, tile_n;
     tile_coords(p, wg, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int b = blockIdx.y;
-    const int nk = p.K >> 6;
+    // split-k (mid-size M: too few tiles to fill the chip): y = b * ksplit + ks; partials go to an fp32 workspace indexed by y
+    const int by = blockIdx.y;
+    const int ksp = max(p.ksplit, 1);
+    const int b = by / ksp;
+    const int ksi = by - b * ksp;
+    const int nk_all = p.K >> 6;
+    const int kt_lo = (int)((long long)ksi * nk_all / ksp), kt_hi = (int)((long long)(ksi + 1) * nk_all / ksp);
+    const int nk = kt_hi - kt_lo;
 
     uint32_t one2;
     asm volatile("v_mov_b32 %0, %1" : "=v"(one2) : "n"(One2<DT>::v));
 
     // ---- DMA source offsets (per lane, constant over k) and ring-slot destinations
-    const char* a_src = p.A + ((long long)b * p.sAb + (long long)m0 * p.sAm) * 2;
-    const char* w_src = p.W + (long long)n0 * p.ldw * 2;
-    const char* p_src = (const char*)p.P + ((long long)b * p.sPb + n0) * 4;
+    const char* a_src = p.A + ((long long)b * p.sAb + (long long)m0 * p.sAm) * 2 + (long long)kt_lo * 128;
+    const char* w_src = p.W + (long long)n0 * p.ldw * 2 + (long long)kt_lo * 128;
+    const char* p_src = (const char*)p.P + ((long long)b * p.sPb + n0) * 4 + (long long)kt_lo * 2 * p.N * 4;
     uint32_t a_voff[A_PW], w_voff[W_PW], bw_voff[BW_PW], a_lds[A_PW], w_lds[W_PW], bw_lds[BW_PW];
 #pragma unroll
     for (int i = 0; i < A_PW; ++i) {
@@ -242,7 +248,7 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_fx_kernel(const GemmParams
                 for (int i = 0; i < TM; ++i) accW[i][j][q * 4 + e] = __builtin_fmaf(a, accS[i][j][q * 4 + e], accW[i][j][q * 4 + e]);
             }
     __builtin_amdgcn_s_barrier();
-    gemm_epilogue<Cfg>(p, accW, smem, m0, n0, wm, wn, b, lane, wave);
+    gemm_epilogue<Cfg>(p, accW, smem, m0, n0, wm, wn, by, lane, wave);
 }
 
 }  // namespace bd

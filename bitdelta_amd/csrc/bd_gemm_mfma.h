@@ -34,8 +34,9 @@ struct GemmParams {
     const float* alpha;   // fp32 [B or 1, G] (fused / accumulate only)
     int M, N, K;
     int tiles_m, tiles_n;     // tiles covered by THIS launch ...
-    int tile_m0, tile_n0;     // ... starting at this tile of the problem (the host splits multi-round problems into launches of
-                              // at most one tile per CU: bd_api.hip launch_tile)
+    int tile_m0, tile_n0;     // ... starting at this tile of the problem (launch-chunking experiment, bd_api.hip launch_tile)
+    int ksplit;               // >= 1.  > 1 (bd_gemm_fx.h only): blockIdx.y = b * ksplit + ks; the block contracts k-tiles
+                              // [ks*nk/ksplit, (ks+1)*nk/ksplit) and writes its partial to C[blockIdx.y] (an fp32 workspace)
     long long sAb, sPb, sCb;  // batch strides in elements (sPb = 0 broadcasts one mask)
     int sAm, sCm, ldw;        // row strides in elements
     int sAlb, gsz;            // alpha batch stride (0 = broadcast), columns per scale group

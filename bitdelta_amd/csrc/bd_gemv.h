@@ -574,4 +574,34 @@ __global__ void __launch_bounds__(256) gemv_reduce_kernel(const GemvParams p) {
     store_out<DT>(p, r, n, s);
 }
 
+// Sum of the split-k partials of the fused tile kernel (bd_gemm_fx.h, GemmParams::ksplit): ws [B][KS][M][N] fp32 -> C [B][M][N].
+// One thread per 4 consecutive columns; partials are read as float4 (N % 4 == 0 is guaranteed by the fast-path checks).
+template <int DT>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, void* C, int B, int KS, int M, int N,
+                                                             long long sCb, int sCm, int out_f32) {
+    const long long q4 = (long long)blockIdx.x * 256 + threadIdx.x;        // index of a float4 inside one [M][N] slab
+    const int b = blockIdx.y;
+    const long long per = (long long)M * N / 4;
+    if (q4 >= per) return;
+    const long long e = q4 * 4;
+    const int m = (int)(e / N), n = (int)(e - (long long)m * N);
+    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < KS; k0 += 4) {
+        f32x4_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = *(const f32x4_t*)(ws + ((long long)b * KS + min(k0 + j, KS - 1)) * M * N + e);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k0 + j < KS) s += v[j];
+    }
+    const long long off = (long long)b * sCb + (long long)m * sCm + n;
+    if (out_f32) {
+        *(f32x4_t*)((float*)C + off) = s;
+    } else {
+        const uint32_t h0 = f32_to_half_bits<DT>(s[0]), h1 = f32_to_half_bits<DT>(s[1]);
+        const uint32_t h2 = f32_to_half_bits<DT>(s[2]), h3 = f32_to_half_bits<DT>(s[3]);
+        *(u32x2_t*)((unsigned short*)C + off) = u32x2_t{h0 | (h1 << 16), h2 | (h3 << 16)};
+    }
+}
+
 }  // namespace bd

@@ -95,7 +95,8 @@ int bd_merge_delta(void* W, int64_t ldw, const int32_t* P, const float* coeff, i
  * 5 = 256x128 ping-pong (picked automatically when it fills the CUs better); 6 / 7 = the half-tile ping-pong schedule at
  * 256x256 / 256x128 (A/B reference for the shipped full-tile schedule); 8 = one-pass fused 256x128 kernel with two accumulator
  * sets (bd_binary_linear only; the automatic choice for M > 128; 0 / 5 remain as the two-loop A/B references); 9 = the same kernel
- * with a 128x128 tile (picked when 256x128 tiles cannot fill the CUs);
+ * with a 128x128 tile (picked when 256x128 tiles cannot fill the CUs); 10 = the 128x128 kernel with split-k over blockIdx.y and a
+ * reduce launch (automatic for 16 < M <= 512 when the tiles would leave more than half the CUs idle; needs the workspace);
  * 100 generic edge kernel; 200 decode path (200 + KS forces a k-split), which picks between 300 (+ KS) = the VALU sign-flip
  * kernel, 400 (+ KS) = the MFMA + sign-LUT kernel and 500 (+ KS) = the no-split-k kernel (16 columns x all of k per block).
  * A forced variant whose preconditions fail returns BD_E_BAD_SHAPE instead of silently falling back. */

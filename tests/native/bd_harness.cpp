@@ -213,7 +213,7 @@ static void run_cfg(const char* name, int M, int N, int K, int iters, int nsampl
     p.M = M; p.N = N; p.K = K;
     p.tiles_m = (M + Cfg::BM - 1) / Cfg::BM; p.tiles_n = (N + Cfg::BN - 1) / Cfg::BN;
     p.sAb = (long long)M * K; p.sPb = 0; p.sCb = (long long)M * N; p.sAm = K; p.sCm = N; p.ldw = K; p.sAlb = 0; p.gsz = N;
-    p.round_mode = 0; p.accumulate = 0; p.group_m = g_group_m < p.tiles_m ? g_group_m : p.tiles_m;
+    p.round_mode = 0; p.accumulate = 0; p.group_m = g_group_m < p.tiles_m ? g_group_m : p.tiles_m; p.ksplit = 1;
     HIPCHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
     dim3 grid(p.tiles_m * p.tiles_n, 1);
     auto launch = [&] { hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, 0, p); };
@@ -411,6 +411,11 @@ int main(int argc, char** argv) {
                     fails += run_case("fx128_nk1", 1, 257, 136, 64, dt, dt, 1, 1, 9, 0, S);
                     fails += run_case("fx128_nk2", 3, 300, 264, 128, dt, dt, 1, 1, 9, 0, S);
                     fails += run_case("fx128_big", 1, 640, 1024, 2048, dt, dt, 1, 1, 9, 0, S);
+                    fails += run_case("splitk_forced", 2, 200, 520, 256, dt, BD_F32, 1, 2, 10, 0, S);      // KS = 2, 2 k-tiles per slice
+                    fails += run_case("splitk_forced2", 1, 128, 384, 512, dt, dt, 1, 1, 10, 0, S);
+                    fails += run_case("splitk_auto", 1, 40, 264, 1024, dt, dt, 1, 1, -1, 0, S);
+                    fails += run_case("splitk_auto_q", 1, 96, 4096, 4096, dt, dt, 1, 1, -1, 0, S);         // KS = 8
+                    fails += run_case("splitk_auto_t3", 3, 33, 1024, 2048, dt, dt, 1, 3, -1, 0, S);
                 }
                 fails += run_case("tile_bcast", 3, 130, 300, 128, dt, dt, fused, 1, 0, 0, S);
                 fails += run_case("auto_big", 1, 512, 768, 1024, dt, dt, fused, 1, -1, 0, S);
@@ -478,6 +483,18 @@ int main(int argc, char** argv) {
         fails += run_case("decode_fused_down", 6, 1, 4096, 14336, BD_F16, BD_F16, 1, 6, -1, 50, 2048);
         fails += run_case("decode_fused_kv", 6, 1, 1024, 4096, BD_F16, BD_F16, 1, 6, -1, 50, 2048);
         fails += run_case("prefill64_t6", 6, 64, 4096, 4096, BD_F16, BD_F16, 1, 6, -1, it, 2048);
+    } else if (mode == "midm") {
+        // fused Linear at 16 < M <= 512: split-k one-pass kernel (auto = variant 10 where the rule fires) vs unsplit tiles
+        for (int rep = 0; rep < 2; ++rep)
+            for (int M : {32, 64, 128, 256, 512}) {
+                for (int v : {-1, 9, 2}) {
+                    if (v == 2 && M > 64) continue;
+                    fails += run_case("midm_q", 1, M, 4096, 4096, BD_BF16, BD_BF16, 1, 1, v, 20, 1024);
+                    fails += run_case("midm_gate", 1, M, 11008, 4096, BD_BF16, BD_BF16, 1, 1, v, 20, 1024);
+                    fails += run_case("midm_down", 1, M, 4096, 11008, BD_BF16, BD_BF16, 1, 1, v, 20, 1024);
+                }
+            }
+        for (int v : {-1, 9, 2}) fails += run_case("prefill64_t6", 6, 64, 4096, 4096, BD_F16, BD_F16, 1, 6, v, 20, 1024);
     } else if (mode == "chunk") {
         // multi-round shapes: one launch vs single-round launch chunks (dispatcher hook), interleaved
         for (int rep = 0; rep < 2; ++rep)

@@ -21,7 +21,7 @@ template <class Cfg> void run(const char* name) {
     CK(hipMemcpy(dA, a.data(), a.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dP, pw.data(), pw.size() * 4, hipMemcpyHostToDevice));
     GemmParams p{};
     p.A = (const char*)dA; p.P = (const int32_t*)dP; p.C = (char*)dC; p.M = M; p.N = N; p.K = K;
-    p.tiles_m = M / Cfg::BM; p.tiles_n = N / Cfg::BN; p.sAb = (long long)M * K; p.sCb = (long long)M * N; p.sAm = K; p.sCm = N; p.gsz = N; p.group_m = 1;
+    p.tiles_m = M / Cfg::BM; p.tiles_n = N / Cfg::BN; p.sAb = (long long)M * K; p.sCb = (long long)M * N; p.sAm = K; p.sCm = N; p.gsz = N; p.group_m = 1; p.ksplit = 1;
     auto kern = delta_gemm_pp_kernel<Cfg>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
     for (int it = 0; it < 5; ++it) hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(Cfg::NT), Cfg::LDS_BYTES, 0, p);
@@ -51,7 +51,7 @@ template <class Cfg> void run_pf(const char* name) {
     CK(hipMemcpy(dA, a.data(), a.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dP, pw.data(), pw.size() * 4, hipMemcpyHostToDevice));
     GemmParams p{};
     p.A = (const char*)dA; p.P = (const int32_t*)dP; p.C = (char*)dC; p.M = M; p.N = N; p.K = K;
-    p.tiles_m = M / Cfg::BM; p.tiles_n = N / Cfg::BN; p.sAb = (long long)M * K; p.sCb = (long long)M * N; p.sAm = K; p.sCm = N; p.gsz = N; p.group_m = 1;
+    p.tiles_m = M / Cfg::BM; p.tiles_n = N / Cfg::BN; p.sAb = (long long)M * K; p.sCb = (long long)M * N; p.sAm = K; p.sCm = N; p.gsz = N; p.group_m = 1; p.ksplit = 1;
     auto kern = delta_gemm_pf_kernel<Cfg>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
     for (int it = 0; it < 5; ++it) hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(Cfg::NT), Cfg::LDS_BYTES, 0, p);

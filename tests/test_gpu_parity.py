@@ -209,7 +209,9 @@ def test_delta_bmm_vs_oracle(bd, oracle, dtype, shape):
 
 # the one-pass fused kernel (variant 8, bd_binary_linear only): multi-tenant, ragged M/N, k shorter than its 3-slot ring
 LINEAR_SHAPES = SHAPES + [(2, 200, 256, 520, 2, 8), (1, 257, 64, 136, 1, 8), (3, 300, 128, 264, 1, 8), (1, 512, 1024, 384, 1, 8),
-                          (2, 200, 256, 520, 2, 9), (1, 257, 64, 136, 1, 9), (3, 300, 128, 264, 1, 9), (1, 512, 1024, 384, 1, 9)]   # 9 = 128x128 tile
+                          (2, 200, 256, 520, 2, 9), (1, 257, 64, 136, 1, 9), (3, 300, 128, 264, 1, 9), (1, 512, 1024, 384, 1, 9),   # 9 = 128x128 tile
+                          (2, 200, 256, 520, 2, 10), (1, 128, 512, 384, 1, 10), (1, 40, 1024, 264, 1, None), (3, 33, 2048, 1024, 3, None),  # split-k (mid M)
+                          (1, 96, 4096, 1024, 1, None)]
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
