@@ -239,7 +239,8 @@ def main():
             lin_bytes = k_bytes / args.steps
             out["roofline"]["step_linear_bytes"] = lin_bytes
             out["roofline"]["whole_step_gbs_if_only_linears"] = lin_bytes / (graph_ms * 1e-3) * 1e-9
-        print(json.dumps(out))
+        if rank == 0:
+            print(json.dumps(out), flush=True)
         return
     mb = delta_gemm_microbench(dev)
     achieved = k_flops / k_ms * 1e-9 if k_ms > 0 else 0.0
@@ -273,8 +274,14 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
-    print(json.dumps(out))
+    if rank == 0:                       # one JSON line per job (the contract); other ranks only contributed to the MAX time
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        import torch.distributed as _dist
+        if _dist.is_available() and _dist.is_initialized():
+            _dist.destroy_process_group()
