@@ -149,6 +149,7 @@ def main():
     rank, world, local = bdd.init_from_env()
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a ROCm device (there is no CPU path)"
+    local = local % torch.cuda.device_count()        # one rank per GPU on a full node; wraps only in the gloo smoke test of this path
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
