@@ -38,6 +38,10 @@ def test_library_exports_every_declared_symbol():
     assert L.bd_pack(None, 0, 64, 4, 0, 4, 1, None, 32, None) == 0           # empty batch is a no-op
     assert L.bd_gemm_workspace_bytes(6, 1, 4096, 4096) > 0 and L.bd_gemm_workspace_bytes(1, 2048, 4096, 4096) == 0
     assert L.bd_binarize_workspace_bytes(4096, 4096) == 64 * 16 * 4
+    # decode path: <= 16 rows per launch, up to 4 chunks; mid-size M: split-k slabs (ticket area + B*KS*M*N fp32, KS = 8 here)
+    assert L.bd_gemm_workspace_bytes(64, 1, 4096, 4096) > 0 and L.bd_gemm_workspace_bytes(65, 1, 4096, 4096) == 0
+    assert L.bd_gemm_workspace_bytes(1, 64, 4096, 4096) == 65536 + 8 * 64 * 4096 * 4
+    assert L.bd_gemm_workspace_bytes(1, 1024, 4096, 4096) == 0
 
 
 def test_python_surface_matches_reference_names_and_signatures():
