@@ -36,6 +36,7 @@ SIGNATURES = {
     "bd_set_tile_group_m": (_ci, [_ci]),
     "bd_set_launch_chunking": (_ci, [_ci]),
     "bd_set_decode_two_launch": (_ci, [_ci]),
+    "bd_set_decode_wave_spec": (_ci, [_ci]),
     "bd_set_decode_small_lut": (_ci, [_ci]),
     "bd_set_decode_generic_loop": (_ci, [_ci]),
 }

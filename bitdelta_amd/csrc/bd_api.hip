@@ -18,6 +18,7 @@ static int g_col16_small_lut = -1;      // sign LUT of the 16-column decode kern
                                         // fused: -2 %, and -15 % WORSE on 14336x4096 where it drops to one block per CU)
 static int g_col16_no_per4 = 0;         // A/B hook: 1 = the 16-column decode kernel always uses its generic one-ahead loop
 static int g_launch_chunking = 0;       // 1 = multi-round tile problems are issued as single-round launches (measured: no gain; off)
+static int g_gemv_wave_spec = 1;        // 1 = fused launches of the VALU decode kernel use its wave-specialised form
 static int g_gemv_two_launch = 1;       // 1 (default) = split-k partials are summed by gemv_reduce_kernel; 0 = in-launch tickets
                                         // (measured slower: the last-arriver tail is serial inside every tile; bd_gemv.h)
 static int g_gemv_target_blocks = 512;
@@ -28,6 +29,7 @@ extern "C" int bd_set_gemm_variant(int v) { g_forced_variant = v; return BD_OK; 
 extern "C" int bd_last_gemm_variant(void) { return t_last_variant; }
 extern "C" int bd_set_tile_group_m(int g) { g_forced_group_m = g; return BD_OK; }
 extern "C" int bd_set_decode_two_launch(int on) { g_gemv_two_launch = on ? 1 : 0; return BD_OK; }
+extern "C" int bd_set_decode_wave_spec(int on) { g_gemv_wave_spec = on ? 1 : 0; return BD_OK; }
 extern "C" int bd_set_launch_chunking(int on) { g_launch_chunking = on ? 1 : 0; return BD_OK; }
 extern "C" int bd_set_decode_generic_loop(int on) { g_col16_no_per4 = on ? 1 : 0; return BD_OK; }
 extern "C" int bd_set_decode_small_lut(int mode) { g_col16_small_lut = mode < 0 ? -1 : (mode ? 1 : 0); return BD_OK; }
@@ -162,7 +164,10 @@ inline void gemv_split(const Problem& q, int& KS, int& kslice) {
 template <int DT, int RMAX>
 int launch_gemv_valu(const Problem& q, const GemvParams& gp) {       // A/B reference (variant 300): VALU sign-flip form
     dim3 grid((unsigned)((q.N + 63) / 64), (unsigned)gp.KS);
-    hipLaunchKernelGGL((gemv_kernel<DT, RMAX>), grid, dim3(256), 0, q.st, gp);
+    // fused launches: the wave-specialised instantiation (4 weight-streaming waves + 4 sign waves per block)
+    // (-6..13 % up to 8 rows; at 16 tenants the sign work dominates and halving the sign waves per CU costs 22 %)
+    if (q.W && g_gemv_wave_spec && gp.R <= 8) hipLaunchKernelGGL((gemv_kernel<DT, RMAX, true>), grid, dim3(512), 0, q.st, gp);
+    else hipLaunchKernelGGL((gemv_kernel<DT, RMAX, false>), grid, dim3(256), 0, q.st, gp);
     return BD_OK;
 }
 
@@ -544,6 +549,9 @@ int dispatch3(const Problem& q) {
             // the chip but not several rounds of them: 4096 < ... <= 8192 columns (+3..10 % over the two-launch kernels there)
             // (all of its N/16 blocks must be resident at once: a second round of 8-wave blocks pays the start-up latency again --
             // 8192x8192, 4 tenants: 50.8 vs 37.5 us)
+            // up to 8 rows, fused: the wave-specialised VALU kernel is the fastest on every Llama / Mistral shape
+            // (profiles/r01_decode_kernels.txt: 4096^2 T=6 14.4 us vs 15.8 one-launch kernel vs 16.7 single-role)
+            if (q.W && bc * q.M <= 8 && bc * q.M < 2 * nmask && g_gemv_wave_spec) return launch_gemv<DT>(q, true);
             int ks16, ksl16;
             col16_split(bc * q.M, q.K, 0, ks16, ksl16);
             const long long lds16 = 4096 + (long long)bc * q.M * (ksl16 * 2 + 16) + 16 * 1024 + 512;

@@ -111,15 +111,22 @@ template <int RMAX> struct GemvBatch { static constexpr int RB = (32 / RMAX) < 1
 // (measured: 4096-k slices for <= 6 rows cut occupancy to 3 blocks/CU and were 15-20 % slower than 1024-k slices + more k-splits)
 constexpr int gemv_kslice_max(int /*rmax*/) { return 1024; }
 
-template <int DT, int RMAX>
-__global__ void __launch_bounds__(256) gemv_kernel(const GemvParams p) {
+// SPEC = wave-specialised form (fused launches): 8 waves per block, waves 0-3 stream the base weight (MFMA, load-bound), waves 4-7
+// expand and contract the sign words (VALU-bound).  One wave of each kind shares a SIMD, so the weight stream and the sign work
+// overlap instead of adding up (the single-role kernel measured floor + base + delta: a wave busy expanding signs is not issuing
+// weight loads, and in-order vmcnt stops one wave from keeping both streams in flight).
+template <int DT, int RMAX, bool SPEC = false>
+__global__ void __launch_bounds__(SPEC ? 512 : 256) gemv_kernel(const GemvParams p) {
     constexpr int RB = GemvBatch<RMAX>::RB;
     constexpr int XROW = gemv_kslice_max(RMAX) * 2 + 16;    // padded LDS row of the activation slice (bytes)
     __shared__ float red[4][RMAX][64];    // delta partials per wave
     __shared__ float bs[RMAX][64];        // base GEMV tile
     __shared__ __attribute__((aligned(16))) char xs_lds[RMAX * XROW];
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = wave_id & 3;                                   // column group (base role) / word-row phase (delta role)
+    const bool do_base = SPEC ? wave_id < 4 : true, do_delta = SPEC ? wave_id >= 4 : true;
+    constexpr int NTHR = SPEC ? 512 : 256;
     const int n0 = blockIdx.x * 64, ks = blockIdx.y;
     const int k_lo = ks * p.kslice, k_hi = min(p.K, k_lo + p.kslice);
     uint32_t one2;
@@ -140,12 +147,12 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvParams p) {
         }
     };
     uint32_t wcur[RB][RMAX];
-    load_batch(wcur, i_lo);
+    if (do_delta) load_batch(wcur, i_lo);
 
     // ---------------- activation slice -> LDS (once per block; rows >= R repeat the last row) ----------------
     {
         const int kn = k_hi - k_lo;                                   // multiple of 32
-        for (int idx = threadIdx.x; idx < RMAX * (kn >> 3); idx += 256) {
+        for (int idx = threadIdx.x; idx < RMAX * (kn >> 3); idx += NTHR) {
             const int r = idx / (kn >> 3), c = idx - r * (kn >> 3);
             const int rr = min(r, p.R - 1), b = rr / p.M, m = rr - b * p.M;
             *(u32x4_t*)(xs_lds + r * XROW + c * 16) =
@@ -156,7 +163,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvParams p) {
 
     // ---------------- base part: D[n][r] += W[n][k] x[r][k], one 16-column group per wave (weights streamed once) -------
     auto base_part = [&]() {
-    if (p.W) {
+    if (p.W && do_base) {
         const int li = lane & 15, g = lane >> 4;
         const int nw = min(n0 + wave * 16 + li, p.N - 1);
         const unsigned short* wr = p.W + (long long)nw * p.ldw + 8 * g;
@@ -199,8 +206,9 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvParams p) {
         for (int c = 0; c < 4; ++c) dacc[r][c] = 0.f;
     // The base part is load-bound and the delta part VALU-bound; blocks alternate the order so that, CU-wide, one half's
     // weight stream overlaps the other half's sign expansion (measured: the two phases otherwise simply add up).
-    const bool delta_first = ((blockIdx.x + blockIdx.y) & 1) != 0;
+    const bool delta_first = SPEC ? false : ((blockIdx.x + blockIdx.y) & 1) != 0;
     if (!delta_first) base_part();
+    if (do_delta)
     for (int ib = i_lo; ib < i_hi; ib += 4 * RB) {
         uint32_t wnext[RB][RMAX];
         const bool more = ib + 4 * RB < i_hi;
@@ -236,13 +244,15 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvParams p) {
         }
     }
     if (delta_first) base_part();
+    if (do_delta) {
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) red[wave][r][lane] = (dacc[r][0] + dacc[r][1]) + (dacc[r][2] + dacc[r][3]);
+        for (int r = 0; r < RMAX; ++r) red[wave][r][lane] = (dacc[r][0] + dacc[r][1]) + (dacc[r][2] + dacc[r][3]);
+    }
     __syncthreads();
 
     // ---------------- combine: wave w finishes rows r = w, w+4, ... ----------------
     const int n = n0 + lane;
-    if (n < p.N) {
+    if (n < p.N && wave_id < 4) {
         for (int r = wave; r < p.R; r += 4) {
             const int b = r / p.M;
             float d = (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]);

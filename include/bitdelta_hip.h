@@ -111,6 +111,8 @@ int bd_set_launch_chunking(int on);
 /* 1 (default) = the decode path sums its split-k partials with a second launch (gemv_reduce_kernel); 0 = in-launch ticket
  * reduction (single launch; measured equal within noise, and it needs the zeroed ticket area described at bd_delta_bmm) */
 int bd_set_decode_two_launch(int on);
+/* A/B hook: 1 (default) = fused launches of the VALU decode kernel run wave-specialised (4 weight-streaming + 4 sign waves per block) */
+int bd_set_decode_wave_spec(int on);
 /* A/B hook, sign LUT of the no-split-k decode kernel: -1 (default) automatic, 1 = single 4-KiB table, 0 = 16-copy conflict-free
  * 64-KiB table whenever it fits in LDS */
 int bd_set_decode_small_lut(int mode);

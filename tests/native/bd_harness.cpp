@@ -529,6 +529,19 @@ int main(int argc, char** argv) {
         for (int v : {500, 300})
             for (int T : {1, 6, 8, 16}) fails += run_case("q", T, 1, 4096, 4096, BD_BF16, BD_BF16, 1, T, v, 5, 0);
         bd_set_decode_small_lut(-1);
+    } else if (mode == "wspec") {
+        // VALU decode kernel: wave-specialised (4 base + 4 delta waves) vs single-role, fused launches, interleaved
+        for (int rep = 0; rep < 2; ++rep)
+            for (int on : {1, 0}) {
+                bd_set_decode_wave_spec(on);
+                const char* tg = on ? "spec" : "plain";
+                for (int T : {1, 6, 16}) fails += run_case(tg, T, 1, 4096, 4096, BD_BF16, BD_BF16, 1, T, 300, 50, 2048);
+                fails += run_case(tg, 6, 1, 14336, 4096, BD_F16, BD_F16, 1, 6, 300, 50, 2048);
+                fails += run_case(tg, 6, 1, 4096, 14336, BD_F16, BD_F16, 1, 6, 300, 50, 2048);
+                fails += run_case(tg, 6, 1, 1024, 4096, BD_F16, BD_F16, 1, 6, 300, 50, 2048);
+                fails += run_case(tg, 3, 4, 1000, 1184, BD_BF16, BD_F32, 1, 3, 300, 20, 4096);
+            }
+        bd_set_decode_wave_spec(1);
     } else if (mode == "dec500") {
         // the no-split-k decode kernel with the 16-copy conflict-free sign LUT (default) vs the single 4-KiB table, interleaved
         for (int rep = 0; rep < 2; ++rep)
