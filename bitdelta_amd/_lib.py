@@ -90,13 +90,14 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
-_WORKSPACES = {}          # (device index, stream handle) -> persistent zero-initialised scratch tensor
+_WORKSPACES = {}          # (device index, stream handle) -> [scratch tensors, newest (largest) last]
 
 
 def workspace(nbytes, device, zeroed=False):
     """Scratch for one launch.  `zeroed=True` (the GEMM paths): a persistent buffer per (device, stream), zero-filled once when it
-    is (re)allocated -- include/bitdelta_hip.h's contract for the decode path's ticket area; the library restores the zeros, and
-    launches on one stream are ordered, so the buffer is reused by every call on that stream."""
+    is allocated -- include/bitdelta_hip.h's contract for the decode path's optional ticket area; the library restores the zeros,
+    and launches on one stream are ordered, so the buffer is reused by every call on that stream.  When a larger buffer is needed a
+    new one is added and the old ones are KEPT alive: a captured hipGraph may still hold their addresses."""
     if nbytes <= 0:
         return None, 0
     nbytes = int(nbytes)
@@ -104,8 +105,7 @@ def workspace(nbytes, device, zeroed=False):
         return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
     dev = torch.device(device)
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
-    buf = _WORKSPACES.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _WORKSPACES[key] = buf
-    return buf, buf.numel()
+    bufs = _WORKSPACES.setdefault(key, [])
+    if not bufs or bufs[-1].numel() < nbytes:
+        bufs.append(torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device))
+    return bufs[-1], bufs[-1].numel()
