@@ -27,6 +27,9 @@ SIGNATURES = {
                            _vp, _i64, _ci, _ci, _vp, _i64, _vp]),
     "bd_binary_linear": (_ci, [_vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _ci,
                                _i64, _i64, _ci, _ci, _vp, _i64, _vp]),
+    "bd_binary_linear_residual": (_ci, [_vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _ci,
+                                        _i64, _i64, _ci, _ci, _vp, _i64, _vp]),
+    "bd_tenant_linear": (_ci, [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _i64, _ci, _ci, _vp]),
     "bd_gemm_workspace_bytes": (_i64, [_ci, _ci, _ci, _ci]),
     "bd_binarize": (_ci, [_vp, _vp, _i64, _i64, _i64, _ci, _vp, _vp, _vp, _i64, _vp]),
     "bd_binarize_workspace_bytes": (_i64, [_i64, _i64]),
@@ -96,8 +99,12 @@ _WORKSPACES = {}          # (device index, stream handle) -> [scratch tensors, n
 def workspace(nbytes, device, zeroed=False):
     """Scratch for one launch.  `zeroed=True` (the GEMM paths): a persistent buffer per (device, stream), zero-filled once when it
     is allocated -- include/bitdelta_hip.h's contract for the decode path's optional ticket area; the library restores the zeros,
-    and launches on one stream are ordered, so the buffer is reused by every call on that stream.  When a larger buffer is needed a
-    new one is added and the old ones are KEPT alive: a captured hipGraph may still hold their addresses."""
+    and launches on one stream are ordered, so the buffer is reused by every call on that stream.
+
+    Growth is GEOMETRIC (request rounded up to a power of two, at least 1 MiB): a caller whose problem size creeps up call by call
+    (generation without a KV cache, length-sorted batches) allocates O(log size) buffers and the memory retained per stream stays
+    below 2 x the largest request.  Superseded buffers are kept alive rather than freed -- a captured hipGraph may still hold their
+    addresses, and nothing here can tell whether one does -- which is what bounds the retained total at ~2 x peak instead of 1 x."""
     if nbytes <= 0:
         return None, 0
     nbytes = int(nbytes)
@@ -107,5 +114,13 @@ def workspace(nbytes, device, zeroed=False):
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
     bufs = _WORKSPACES.setdefault(key, [])
     if not bufs or bufs[-1].numel() < nbytes:
-        bufs.append(torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device))
+        size = 1 << 20
+        while size < nbytes:
+            size <<= 1
+        bufs.append(torch.zeros(size, dtype=torch.uint8, device=device))
     return bufs[-1], bufs[-1].numel()
+
+
+def workspace_bytes_retained():
+    """Total bytes held by the persistent GEMM workspaces (diagnostic; tests use it to pin the growth policy)."""
+    return sum(b.numel() for bufs in _WORKSPACES.values() for b in bufs)

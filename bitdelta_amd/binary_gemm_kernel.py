@@ -16,7 +16,7 @@ import torch
 from . import _lib
 from ._lib import DTYPE_CODE, WORD_DTYPE, check, lib, ptr, require_gpu, stream_ptr, workspace
 
-__all__ = ["pack", "unpack", "binary_matmul", "binary_bmm", "delta_bmm", "binary_linear"]
+__all__ = ["pack", "unpack", "binary_matmul", "binary_bmm", "delta_bmm", "binary_linear", "tenant_linear"]
 
 
 def pack(x, n_bits=32):
@@ -112,14 +112,16 @@ def delta_bmm(a, b, *, out=None, out_dtype=None, round_mode=1, alpha=None, accum
     return out
 
 
-def binary_linear(x, weight, mask, alpha, *, out_dtype=None, groups=1):
+def binary_linear(x, weight, mask, alpha, *, out_dtype=None, groups=1, residual=None):
     """Fused 16-bit base + 1-bit delta Linear:  y[i] = x[i] . weight^T + alpha[i] * (x[i] . S[i])  in ONE launch.
 
     x: (B, M, K); weight: (N, K) rows k-contiguous; mask: (B or 1, K/32, N) int32; alpha: fp32 (B or 1, groups).
     Replaces the four launches of BinaryDiff.forward (bitdelta/diff.py:38-39) / DiffCompressModule.forward
     (demo/demo_backend.py:95-98).  fp32 accumulation, one rounding to ``out_dtype`` (default: x.dtype).
+    residual: optional (B, M, N) tensor of out_dtype that is updated IN PLACE to residual + y and returned (the decoder layer's
+    `hidden = residual + proj(...)`): folded into the kernel epilogue at decode shapes, a separate add otherwise.
     """
-    require_gpu(x, weight, mask, alpha)
+    require_gpu(x, weight, mask, alpha, residual)
     assert x.dim() == 3 and mask.dim() == 3 and weight.dim() == 2
     B, M, K = x.shape
     N = weight.shape[0]
@@ -132,16 +134,51 @@ def binary_linear(x, weight, mask, alpha, *, out_dtype=None, groups=1):
         alpha = alpha.float().contiguous()
     alpha = alpha.reshape(-1, groups)
     assert alpha.shape[0] in (1, B)
-    y = torch.empty((B, M, N), device=x.device, dtype=out_dtype)
     sPb = 0 if (mask.shape[0] == 1 and B > 1) else mask.stride(0)
     sAlb = 0 if alpha.shape[0] == 1 else groups
     L = lib()
+    fused_residual = (residual is not None and M <= 16 and B * M <= 64 and K % 32 == 0 and x.data_ptr() % 16 == 0 and
+                      x.stride(0) % 8 == 0 and x.stride(1) % 8 == 0 and weight.data_ptr() % 16 == 0 and weight.stride(0) % 8 == 0)
+    if residual is not None:
+        assert residual.shape == (B, M, N) and residual.dtype == out_dtype and residual.stride(2) == 1
+    y = residual if fused_residual else torch.empty((B, M, N), device=x.device, dtype=out_dtype)
+    fn = L.bd_binary_linear_residual if fused_residual else L.bd_binary_linear
     ws, ws_bytes = workspace(L.bd_gemm_workspace_bytes(B, M, N, K), x.device, zeroed=True)
     with torch.cuda.device(x.device):
-        check(L.bd_binary_linear(ptr(x), ptr(weight), ptr(mask), ptr(alpha), ptr(y), B, M, N, K, x.stride(0),
-                                 x.stride(1), weight.stride(0), sPb, sAlb, groups, y.stride(0), y.stride(1),
-                                 DTYPE_CODE[x.dtype], DTYPE_CODE[out_dtype], ptr(ws), ws_bytes, stream_ptr()),
+        check(fn(ptr(x), ptr(weight), ptr(mask), ptr(alpha), ptr(y), B, M, N, K, x.stride(0),
+                 x.stride(1), weight.stride(0), sPb, sAlb, groups, y.stride(0), y.stride(1),
+                 DTYPE_CODE[x.dtype], DTYPE_CODE[out_dtype], ptr(ws), ws_bytes, stream_ptr()),
               "binary_linear")
+    if residual is not None and not fused_residual:
+        residual += y
+        return residual
+    return y
+
+
+def tenant_linear(x, weights, *, out_dtype=None):
+    """Per-tenant dense Linear:  y[t] = x[t] . weights[t]^T   (row block t uses tenant t's own matrix).
+
+    x: (T, M, K); weights: (T, N, K), rows k-contiguous.  The batched counterpart of the weight-swapping loop in the reference's
+    DataParallelModule.forward (demo/demo_backend.py:69-79) for nn.Linear leaves such as per-tenant lm_heads.  Decode shapes
+    (M <= 16) stream every tenant's weights once in ONE HIP launch; larger M is an ordinary batched GEMM (torch.bmm / rocBLAS).
+    """
+    require_gpu(x, weights)
+    assert x.dim() == 3 and weights.dim() == 3 and x.shape[0] == weights.shape[0] and x.shape[2] == weights.shape[2]
+    assert x.dtype == weights.dtype and x.dtype in (torch.float16, torch.bfloat16)
+    T, M, K = x.shape
+    N = weights.shape[1]
+    out_dtype = out_dtype or x.dtype
+    if M > 16 or K % 32 or T == 0 or N == 0:
+        return torch.bmm(x, weights.transpose(1, 2)).to(out_dtype)
+    if x.stride(2) != 1 or x.stride(1) % 8 or x.stride(0) % 8 or x.data_ptr() % 16:
+        x = x.contiguous()
+    if weights.stride(2) != 1 or weights.stride(1) % 8 or weights.stride(0) % 8 or weights.data_ptr() % 16:
+        weights = weights.contiguous()
+    y = torch.empty((T, M, N), device=x.device, dtype=out_dtype)
+    with torch.cuda.device(x.device):
+        check(lib().bd_tenant_linear(ptr(x), ptr(weights), ptr(y), T, M, N, K, x.stride(0), x.stride(1), weights.stride(0),
+                                     weights.stride(1), y.stride(0), y.stride(1), DTYPE_CODE[x.dtype], DTYPE_CODE[out_dtype],
+                                     stream_ptr()), "tenant_linear")
     return y
 
 

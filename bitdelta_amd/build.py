@@ -1,4 +1,11 @@
-"""Build libbitdelta_hip.so for gfx950 with hipcc (cross-compiles without a GPU).  `python -m bitdelta_amd.build`."""
+"""Build libbitdelta_hip.so for gfx950 with hipcc (cross-compiles without a GPU).  `python -m bitdelta_amd.build`.
+
+The rebuild gate is a CONTENT hash of every source the library is compiled from (csrc/*.hip, csrc/*.h, include/*.h) plus the
+compiler command, stored next to the .so -- not mtimes, and not a hand-kept dependency list (round 1's list missed the header of
+the headline kernel, so editing it silently kept a stale library).
+"""
+import glob
+import hashlib
 import os
 import subprocess
 import sys
@@ -6,31 +13,52 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "bd_api.hip")
 OUT = os.path.join(HERE, "lib", "libbitdelta_hip.so")
-DEPS = [os.path.join(HERE, "csrc", f) for f in
-        ("bd_api.hip", "bd_common.h", "bd_bits.h", "bd_gemm_mfma.h", "bd_gemm_pp.h", "bd_gemm_pf.h", "bd_gemm_generic.h", "bd_gemv.h")] + \
-       [os.path.join(os.path.dirname(HERE), "include", "bitdelta_hip.h")]
+STAMP = OUT + ".srchash"
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-pass-failed"]
+
+
+def sources():
+    """Every file the library is built from, in a stable order."""
+    files = sorted(glob.glob(os.path.join(HERE, "csrc", "*.hip")) + glob.glob(os.path.join(HERE, "csrc", "*.h")) +
+                   glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h")))
+    return files
+
+
+def source_hash():
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in sources():
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def needs_build():
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    with open(STAMP) as fh:
+        return fh.read().strip() != source_hash()
 
 
 def build(force=False, verbose=True):
+    """Returns (path, compiled): `compiled` says whether hipcc actually ran."""
     if not force and not needs_build():
-        return OUT
+        if verbose:
+            print(f"bitdelta_amd.build: {OUT} is up to date (source hash matches)", file=sys.stderr)
+        return OUT, False
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-pass-failed", "-o", OUT, SRC]
+    cmd = [hipcc] + FLAGS + ["-o", OUT, SRC]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return OUT
+    with open(STAMP, "w") as fh:
+        fh.write(source_hash() + "\n")
+    if verbose:
+        print(f"bitdelta_amd.build: compiled {OUT}", file=sys.stderr)
+    return OUT, True
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(OUT)
+    path, compiled = build(force="--force" in sys.argv)
+    print(path, "(compiled)" if compiled else "(up to date)")

@@ -1,27 +1,33 @@
 // C ABI of libbitdelta_hip.so (see include/bitdelta_hip.h): argument checking + kernel dispatch.
-// No torch types, no hidden state (apart from the test/tuning override bd_set_gemm_variant).
+// No torch types.  State: the test / tuning overrides (bd_set_*) are THREAD-LOCAL, so a thread that forces a kernel family does not
+// change what other threads launch; the per-DEVICE caches (CU count, "max dynamic LDS already raised for this kernel") are keyed
+// by the current device id -- the reference's demo runs one process over several GPUs (demo/demo_backend.py:23-25).
 #include "../../include/bitdelta_hip.h"
 #include "bd_bits.h"
 #include "bd_gemm_generic.h"
 #include "bd_gemm_mfma.h"
-#include "bd_gemm_pp.h"
+#ifdef BD_AB_VARIANTS      // rejected schedules kept as A/B references: harness-only build (tests/native/Makefile)
+#include "../../tests/native/ab/bd_gemm_pp.h"
+#endif
 #include "bd_gemm_pf.h"
 #include "bd_gemm_fx.h"
 #include "bd_gemv.h"
+#include "bd_gemv_stream.h"
+#include <atomic>
 
 using namespace bd;
 
-static int g_forced_variant = -1;
-static int g_forced_group_m = 0;        // 0 = automatic tile order
-static int g_col16_small_lut = -1;      // sign LUT of the 16-column decode kernel: -1 auto, 1 = single 4-KiB table, 0 = 16-copy conflict-free
+static thread_local int g_forced_variant = -1;
+static thread_local int g_forced_group_m = 0;        // 0 = automatic tile order
+static thread_local int g_col16_small_lut = -1;      // sign LUT of the 16-column decode kernel: -1 auto, 1 = single 4-KiB table, 0 = 16-copy conflict-free
                                         // table whenever it fits.  Auto = 16 copies for delta-only launches (-16..18 % at 6-8 masks;
                                         // fused: -2 %, and -15 % WORSE on 14336x4096 where it drops to one block per CU)
-static int g_col16_no_per4 = 0;         // A/B hook: 1 = the 16-column decode kernel always uses its generic one-ahead loop
-static int g_launch_chunking = 0;       // 1 = multi-round tile problems are issued as single-round launches (measured: no gain; off)
-static int g_gemv_wave_spec = 1;        // 1 = fused launches of the VALU decode kernel use its wave-specialised form
-static int g_gemv_two_launch = 1;       // 1 (default) = split-k partials are summed by gemv_reduce_kernel; 0 = in-launch tickets
+static thread_local int g_col16_no_per4 = 0;         // A/B hook: 1 = the 16-column decode kernel always uses its generic one-ahead loop
+static thread_local int g_launch_chunking = 0;       // 1 = multi-round tile problems are issued as single-round launches (measured: no gain; off)
+static thread_local int g_gemv_wave_spec = 1;        // 1 = fused launches of the VALU decode kernel use its wave-specialised form
+static thread_local int g_gemv_two_launch = 1;       // 1 (default) = split-k partials are summed by gemv_reduce_kernel; 0 = in-launch tickets
                                         // (measured slower: the last-arriver tail is serial inside every tile; bd_gemv.h)
-static int g_gemv_target_blocks = 512;
+static thread_local int g_gemv_target_blocks = 512;
 static thread_local int t_last_variant = -1;
 
 extern "C" int bd_version(void) { return 1; }
@@ -114,15 +120,32 @@ struct Problem {
     hipStream_t st;
 };
 
+constexpr int MAX_DEVICES = 64;
+inline int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev;
+}
 inline int num_cus() {
-    static int cus = 0;   // benign race: idempotent
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
-        cus = n;
+    static std::atomic<int> cus[MAX_DEVICES];     // 0 = not queried yet; benign race: idempotent
+    const int dev = current_device();
+    if (dev >= MAX_DEVICES) return 256;
+    int n = cus[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev].store(n, std::memory_order_relaxed);
     }
-    return cus;
+    return n;
+}
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device property of a kernel: raise it once per (kernel, device).
+// `done` is one bit per device id, owned by the call site (one static per kernel instantiation).
+inline bool ensure_dyn_lds(const void* kern, int bytes, std::atomic<uint64_t>& done) {
+    const int dev = current_device();
+    const uint64_t bit = dev < MAX_DEVICES ? (1ull << dev) : 0;
+    if (bit && (done.load(std::memory_order_acquire) & bit)) return true;
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    if (bit) done.fetch_or(bit, std::memory_order_release);
+    return true;
 }
 
 constexpr int GEMV_MAX_M = 16, GEMV_MAX_R = 16;   // decode kernels: <= 16 activation rows per launch; larger batches are chunked
@@ -180,13 +203,8 @@ int launch_gemv_mfma(const Problem& q, const GemvParams& gp) {
     const unsigned lds = 256u * 16u * LC + (unsigned)gp.R * (gemv_kslice_max(16) * 2 + 16);
     auto kw = gemv_mfma_kernel<DT, NM, true, LC>;
     auto kd = gemv_mfma_kernel<DT, NM, false, LC>;
-    static bool attr_set = false;                // benign race: idempotent
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kw, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 16 * LC + 16 * 2064) != hipSuccess ||
-            hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 16 * LC + 16 * 2064) != hipSuccess)
-            return BD_E_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> done_w{0}, done_d{0};
+    if (!ensure_dyn_lds((const void*)(q.W ? kw : kd), 256 * 16 * LC + 16 * 2064, q.W ? done_w : done_d)) return BD_E_LAUNCH;
     if (q.W) hipLaunchKernelGGL(kw, grid, dim3(256), lds, q.st, gp);
     else hipLaunchKernelGGL(kd, grid, dim3(256), lds, q.st, gp);
     return BD_OK;
@@ -212,14 +230,8 @@ int launch_gemv_col16_lc(const Problem& q, const GemvParams& gp) {
     const unsigned lds = 4096u * LC + (unsigned)gp.R * (unsigned)(gp.kslice * 2 + 16);
     auto kw = gemv_col16_kernel<DT, NM, true, LC, PER>;
     auto kd = gemv_col16_kernel<DT, NM, false, LC, PER>;
-    static bool attr_set = false;                // benign race: idempotent
-    if (!attr_set) {
-        const int mx = 160 * 1024 - 16 * 1024 - 256;
-        if (hipFuncSetAttribute((const void*)kw, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
-            hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
-            return BD_E_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> done_w{0}, done_d{0};
+    if (!ensure_dyn_lds((const void*)(q.W ? kw : kd), 160 * 1024 - 16 * 1024 - 256, q.W ? done_w : done_d)) return BD_E_LAUNCH;
     if (q.W) hipLaunchKernelGGL(kw, grid, dim3(512), lds, q.st, gp);
     else hipLaunchKernelGGL(kd, grid, dim3(512), lds, q.st, gp);
     return BD_OK;
@@ -280,12 +292,78 @@ int launch_gemv_col16_chunk(const Problem& q) {
     return launch_status();
 }
 
+// ---- streaming decode kernel (gemv_stream_kernel, variant 600): one 8-wave block per CU, contiguous column range per block
+constexpr int STREAM_MIN_N = 512;
+inline bool stream_ok(const Problem& q, int rows, int nmask) {
+    if (rows > GEMV_MAX_R || nmask > 8 || q.N < STREAM_MIN_N) return false;
+    // 32-bit buffer offsets with an out-of-range sentinel at 2 GiB: every extent must stay below it
+    const int64_t lim = (1ll << 31) - 64;
+    const int64_t xb = ((int64_t)(q.B - 1) * q.sAb + (int64_t)(q.M - 1) * q.sAm + q.K) * 2;
+    const int64_t wb = q.W ? ((int64_t)(q.N - 1) * q.ldw + q.K) * 2 : 0;
+    const int64_t pb = ((int64_t)(nmask - 1) * q.sPb + (int64_t)(q.K / 32) * q.N) * 4;
+    return xb > 0 && xb < lim && wb < lim && pb < lim && q.sAb >= 0 && q.sAm >= 0;
+}
+
+template <int DT, int NM, bool HASW, int NS>
+int launch_stream_inst(const StreamParams& sp, unsigned grid, hipStream_t st) {
+    auto kern = gemv_stream_kernel<DT, NM, HASW, NS>;
+    static std::atomic<uint64_t> lds_done{0};
+    if (!ensure_dyn_lds((const void*)kern, STREAM_LDS_BYTES, lds_done)) return BD_E_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), STREAM_LDS_BYTES, st, sp);
+    return BD_OK;
+}
+
+template <int DT>
+int launch_gemv_stream_chunk(const Problem& q) {
+    StreamParams sp;
+    GemvParams& gp = sp.g;
+    gp.X = (const unsigned short*)q.A;
+    gp.P = (const uint32_t*)q.P;
+    gp.W = (const unsigned short*)q.W;
+    gp.alpha = q.alpha;
+    gp.C = q.C;
+    gp.ws = nullptr; gp.tickets = nullptr;
+    gp.B = q.B; gp.M = q.M; gp.N = q.N; gp.K = q.K; gp.R = q.B * q.M;
+    gp.sXb = q.sAb; gp.sPb = q.sPb; gp.sCb = q.sCb;
+    gp.sXm = (int)q.sAm; gp.sCm = (int)q.sCm; gp.ldw = (int)q.ldw; gp.sAlb = (int)q.sAlb; gp.gsz = q.N / q.G;
+    gp.KS = 1; gp.kslice = q.K;
+    gp.round_mode = q.round_mode; gp.accumulate = q.accumulate; gp.out_f32 = (q.out_dtype == BD_F32);
+    const int nmask = q.sPb == 0 ? 1 : q.B;
+    // columns per block: the whole chip streams one launch, so every CU gets ~N / CUs columns (rounded up to whole sign-word
+    // quads); a few more blocks than CUs would serialise a second, nearly empty round
+    const int cus = num_cus();
+    int cpb = (q.N + cus - 1) / cus;
+    cpb = (cpb + 3) & ~3;
+    if (cpb < 4) cpb = 4;
+    if (g_forced_variant > 600 && g_forced_variant <= 664) cpb = 4 * (g_forced_variant - 600);     // test hook: 600 + cpb/4
+    sp.cpb = cpb;
+    const unsigned grid = (unsigned)((q.N + cpb - 1) / cpb);
+    sp.x_bytes = (uint32_t)(((int64_t)(q.B - 1) * q.sAb + (int64_t)(q.M - 1) * q.sAm + q.K) * 2);
+    sp.w_bytes = q.W ? (uint32_t)(((int64_t)(q.N - 1) * q.ldw + q.K) * 2) : 0u;
+    sp.p_bytes = (uint32_t)(((int64_t)(nmask - 1) * q.sPb + (int64_t)(q.K / 32) * q.N) * 4);
+    int rc;
+    // NS = stages of loads in flight per wave; bounded by the 256-VGPR budget of a 2-waves-per-SIMD block (hipcc spills beyond)
+#define BD_STREAM(NM, NS) rc = q.W ? launch_stream_inst<DT, NM, true, NS>(sp, grid, q.st) : launch_stream_inst<DT, NM, false, NS>(sp, grid, q.st)
+    if (nmask <= 1) BD_STREAM(1, 4);
+    else if (nmask <= 2) BD_STREAM(2, 3);
+    else if (nmask <= 3) BD_STREAM(3, 2);
+    else if (nmask <= 4) BD_STREAM(4, 2);
+    else if (nmask <= 6) BD_STREAM(6, 2);
+    else BD_STREAM(8, 2);
+#undef BD_STREAM
+    if (rc != BD_OK) return rc;
+    return launch_status();
+}
+
 // batches of more than 16 activation rows run as consecutive launches over chunks of floor(16 / M) batch entries (each chunk streams
 // the base weight again; still far cheaper than M = 1 tiles of the MFMA tile kernels, which re-read it once per batch entry)
 template <int DT>
-int launch_gemv(const Problem& q, bool valu_form, bool col16 = false) {
+int launch_gemv(const Problem& q, bool valu_form, bool col16 = false, bool stream = false) {
     const int cb = GEMV_MAX_R / q.M;
-    if (q.B <= cb) return col16 ? launch_gemv_col16_chunk<DT>(q) : launch_gemv_chunk<DT>(q, valu_form);
+    auto one = [&](const Problem& c) {
+        return stream ? launch_gemv_stream_chunk<DT>(c) : col16 ? launch_gemv_col16_chunk<DT>(c) : launch_gemv_chunk<DT>(c, valu_form);
+    };
+    if (q.B <= cb) return one(q);
     const int esz = q.out_dtype == BD_F32 ? 4 : 2;
     for (int b0 = 0; b0 < q.B; b0 += cb) {
         Problem c = q;
@@ -294,7 +372,7 @@ int launch_gemv(const Problem& q, bool valu_form, bool col16 = false) {
         c.P = q.P + (int64_t)b0 * q.sPb;
         c.C = (char*)q.C + (int64_t)b0 * q.sCb * esz;
         if (q.alpha) c.alpha = q.alpha + (int64_t)b0 * q.sAlb;
-        const int rc = col16 ? launch_gemv_col16_chunk<DT>(c) : launch_gemv_chunk<DT>(c, valu_form);
+        const int rc = one(c);
         if (rc != BD_OK) return rc;
     }
     return BD_OK;
@@ -370,7 +448,9 @@ inline GemmParams make_params(const Problem& q, int BM, int BN) {
 }
 
 template <class Cfg, int SCHED> struct TileKernel { static auto get() { return delta_gemm_kernel<Cfg>; } };
+#ifdef BD_AB_VARIANTS
 template <class Cfg> struct TileKernel<Cfg, 1> { static auto get() { return delta_gemm_pp_kernel<Cfg>; } };
+#endif
 template <class Cfg> struct TileKernel<Cfg, 2> { static auto get() { return delta_gemm_pf_kernel<Cfg>; } };
 template <class Cfg> struct TileKernel<Cfg, 3> { static auto get() { return delta_gemm_fx_kernel<Cfg>; } };
 
@@ -380,12 +460,8 @@ template <class Cfg, int SCHED = 0>
 int launch_tile(const Problem& q) {
     const GemmParams p = make_params(q, Cfg::BM, Cfg::BN);
     auto kern = TileKernel<Cfg, SCHED>::get();
-    static bool attr_set = false;   // benign race: idempotent
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess)
-            return BD_E_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_done{0};
+    if (!ensure_dyn_lds((const void*)kern, Cfg::LDS_BYTES, lds_done)) return BD_E_LAUNCH;
     // Experiment kept behind bd_set_launch_chunking(1): issue a multi-round problem as several launches of at most one tile per CU
     // (an mc x nc block of tiles each, via GemmParams::tile_m0 / tile_n0).  Hypothesis: rounds inside one launch drift apart and that
     // is why 8192x4096x4096 runs 10 % below back-to-back 2048-row launches.  Measured (profiles/r01_launch_chunking.txt): no gain
@@ -474,12 +550,8 @@ int launch_fused_splitk(const Problem& q, int KS) {
     GemmParams p = make_params(c, Cfg::BM, Cfg::BN);
     p.ksplit = KS;
     auto kern = delta_gemm_fx_kernel<Cfg>;
-    static bool attr_set = false;   // benign race: idempotent
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess)
-            return BD_E_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_done{0};
+    if (!ensure_dyn_lds((const void*)kern, Cfg::LDS_BYTES, lds_done)) return BD_E_LAUNCH;
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)(q.B * KS));
     hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, q.st, p);
     const long long per = (long long)q.M * q.N / 4;
@@ -496,6 +568,7 @@ int dispatch3(const Problem& q) {
     if (v > 300 && v <= 364) v = 300;        // 300 (+ KS): force the VALU sign-flip decode kernel
     if (v > 400 && v <= 464) v = 400;        // 400 (+ KS): force the MFMA + LUT decode kernel
     if (v > 500 && v <= 564) v = 500;        // 500 (+ KS): force the no-split-k 16-column decode kernel
+    if (v > 600 && v <= 664) v = 600;        // 600 (+ columns per block / 4): force the streaming decode kernel
     if (v < 0) {
         if (gemv_ok(q)) v = 200;
         else if (!fast_ok(q)) v = 100;
@@ -508,20 +581,36 @@ int dispatch3(const Problem& q) {
         else if (q.M > 32) v = 2;
         else v = 3;
     } else {
-        if ((v == 200 || v == 300 || v == 400 || v == 500) && !gemv_ok(q)) return BD_E_BAD_SHAPE;
+        if ((v == 200 || v == 300 || v == 400 || v == 500 || v == 600) && !gemv_ok(q)) return BD_E_BAD_SHAPE;
         if (v >= 0 && v <= 10 && !fast_ok(q)) return BD_E_BAD_SHAPE;
         if ((v == 8 || v == 9 || v == 10) && !FUSED) return BD_E_BAD_SHAPE;
         if (v == 10 && (q.N % 8 || q.sCm % 4 || q.sCb % 4)) return BD_E_BAD_SHAPE;
     }
     t_last_variant = v;
     switch (v) {
+        // Shipped MFMA tile kernels: 0 / 5 = delta-only full-tile ping-pong at 256x256 / 256x128 (bd_gemm_pf.h), 8 / 9 / 10 = one-pass
+        // fused (bd_gemm_fx.h), 1 / 2 / 3 = small-M single-barrier tiles (bd_gemm_mfma.h).  The rejected schedules -- 4 (256x256
+        // single barrier), 6 / 7 (half-tile ping-pong), fused 0 / 5 (two k loops over one accumulator set) -- are compiled only with
+        // -DBD_AB_VARIANTS (the native harness); the shipped library answers BD_E_BAD_SHAPE for them.
         case 0:
-            if constexpr (FUSED) return launch_tile<GemmCfg<DT, 256, 256, 2, 4, 4, FUSED, OUT_F32, 2>, 1>(q);   // 2-slot base ring
-            else return launch_tile<GemmCfg<DT, 256, 256, 2, 4, 4, FUSED, OUT_F32, 1>, 2>(q);    // full-tile ping-pong, LUT sign expansion
+            if constexpr (!FUSED) return launch_tile<GemmCfg<DT, 256, 256, 2, 4, 4, FUSED, OUT_F32, 1>, 2>(q);    // full-tile ping-pong, LUT sign expansion
+#ifdef BD_AB_VARIANTS
+            else return launch_tile<GemmCfg<DT, 256, 256, 2, 4, 4, FUSED, OUT_F32, 2>, 1>(q);   // 2-slot base ring
+#else
+            else return BD_E_BAD_SHAPE;
+#endif
+        case 5:
+            if constexpr (!FUSED) return launch_tile<GemmCfg<DT, 256, 128, 2, 4, 4, FUSED, OUT_F32, 0>, 2>(q);
+#ifdef BD_AB_VARIANTS
+            else return launch_tile<GemmCfg<DT, 256, 128, 2, 4, 4, FUSED, OUT_F32, 0>, 2>(q);
+#else
+            else return BD_E_BAD_SHAPE;
+#endif
+#ifdef BD_AB_VARIANTS
         case 6: return launch_tile<GemmCfg<DT, 256, 256, 2, 4, 4, FUSED, OUT_F32, 2>, 1>(q);      // half-tile ping-pong (A/B reference)
         case 7: return launch_tile<GemmCfg<DT, 256, 128, 2, 4, 4, FUSED, OUT_F32, 2>, 1>(q);      // half-tile ping-pong 256x128 (A/B)
         case 4: return launch_tile<GemmCfg<DT, 256, 256, 2, 4, 4, FUSED, OUT_F32>>(q);   // single-barrier 256x256 (A/B reference)
-        case 5: return launch_tile<GemmCfg<DT, 256, 128, 2, 4, 4, FUSED, OUT_F32, 0>, 2>(q);
+#endif
         case 8:
             if constexpr (FUSED) return launch_tile<FxCfg<DT, 256, 128, 3, OUT_F32, 1>, 3>(q);
             else return BD_E_BAD_SHAPE;
@@ -545,6 +634,8 @@ int dispatch3(const Problem& q) {
         // ... and whenever a mask is shared by >= 2 rows (M > 1 or a broadcast mask): it expands each word once for all rows
         case 200: {
             const int cb = GEMV_MAX_R / q.M, bc = q.B < cb ? q.B : cb, nmask = q.sPb == 0 ? 1 : bc;
+            // streaming kernel: one launch, one block per CU, everything in flight from the first cycle (profiles/r02_decode_*.txt)
+            if (stream_ok(q, bc * q.M, nmask)) { t_last_variant = 600; return launch_gemv<DT>(q, false, false, true); }
             // no-split-k kernel (one launch) when the chunk's activations fit in LDS and there are enough 16-column blocks to fill
             // the chip but not several rounds of them: 4096 < ... <= 8192 columns (+3..10 % over the two-launch kernels there)
             // (all of its N/16 blocks must be resident at once: a second round of 8-wave blocks pays the start-up latency again --
@@ -563,6 +654,11 @@ int dispatch3(const Problem& q) {
         case 300: return launch_gemv<DT>(q, true);
         case 400: return launch_gemv<DT>(q, false);
         case 500: return launch_gemv<DT>(q, false, true);
+        case 600: {
+            const int cb = GEMV_MAX_R / q.M, bc = q.B < cb ? q.B : cb, nmask = q.sPb == 0 ? 1 : bc;
+            if (!stream_ok(q, bc * q.M, nmask)) return BD_E_BAD_SHAPE;
+            return launch_gemv<DT>(q, false, false, true);
+        }
         default: return BD_E_BAD_SHAPE;
     }
 }
@@ -590,10 +686,12 @@ int dispatch(const Problem& q) {
 extern "C" int64_t bd_gemm_workspace_bytes(int B, int M, int N, int K) {
     if (B <= 0 || M <= 0 || N <= 0 || K <= 0) return 0;
     if (M > GEMV_MAX_M || (int64_t)B * M > 4 * GEMV_MAX_R) {
-        // mid-size M: split-k partial slabs of the fused tile kernel (also covers the forced-variant test hook's KS = 2)
+        // mid-size M: split-k partial slabs of the fused tile kernel -- only where the automatic rule really splits (or a test
+        // forces the split-k variant); every other tile-kernel launch needs no scratch at all
         if (M > 16 && M <= 512 && K % 64 == 0 && N % 8 == 0) {
             int ks = splitk_factor(B, M, N, K);
-            if (ks < 2) ks = 2;
+            if (ks < 2 && g_forced_variant == 10) ks = 2;
+            if (ks < 2) return 0;
             const int64_t need = (int64_t)B * ks * M * N * 4;
             return need <= SPLITK_WS_CAP * 2 ? GEMV_TICKET_BYTES + need : 0;
         }
@@ -639,18 +737,83 @@ extern "C" int bd_delta_bmm(const void* A, const int32_t* P, void* C, int B, int
     return dispatch(q);
 }
 
-extern "C" int bd_binary_linear(const void* X, const void* W, const int32_t* P, const float* alpha, void* Y, int B, int M,
-                                int N, int K, int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb, int64_t sAlb, int G,
-                                int64_t sYb, int64_t sYm, int dtype, int out_dtype, void* ws, int64_t ws_bytes,
-                                void* stream) {
+static int binary_linear_impl(const void* X, const void* W, const int32_t* P, const float* alpha, void* Y, int B, int M,
+                              int N, int K, int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb, int64_t sAlb, int G,
+                              int64_t sYb, int64_t sYm, int dtype, int out_dtype, int accumulate, void* ws, int64_t ws_bytes,
+                              void* stream) {
     if (B > 0 && M > 0 && N > 0 && !W) return BD_E_NULL;
     Problem q{};
     q.A = X; q.P = P; q.C = Y; q.W = W; q.alpha = alpha;
     q.B = B; q.M = M; q.N = N; q.K = K;
     q.sAb = sXb; q.sAm = sXm; q.sPb = sPb; q.sCb = sYb; q.sCm = sYm; q.ldw = ldw; q.sAlb = sAlb;
-    q.G = G; q.dtype = dtype; q.out_dtype = out_dtype; q.round_mode = 0; q.accumulate = 0;
+    q.G = G; q.dtype = dtype; q.out_dtype = out_dtype; q.round_mode = 0; q.accumulate = accumulate ? 1 : 0;
     q.ws = ws; q.ws_bytes = ws_bytes; q.st = (hipStream_t)stream;
+    // Y += ... is an epilogue of the decode kernels only (a residual add costs a launch per Linear there; at prefill sizes it is
+    // noise next to the GEMM and stays with the caller)
+    if (q.accumulate && !(gemv_ok(q) && g_forced_variant < 0 || (g_forced_variant >= 200 && gemv_ok(q)))) return BD_E_BAD_SHAPE;
     return dispatch(q);
+}
+
+extern "C" int bd_binary_linear(const void* X, const void* W, const int32_t* P, const float* alpha, void* Y, int B, int M,
+                                int N, int K, int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb, int64_t sAlb, int G,
+                                int64_t sYb, int64_t sYm, int dtype, int out_dtype, void* ws, int64_t ws_bytes,
+                                void* stream) {
+    return binary_linear_impl(X, W, P, alpha, Y, B, M, N, K, sXb, sXm, ldw, sPb, sAlb, G, sYb, sYm, dtype, out_dtype, 0, ws,
+                              ws_bytes, stream);
+}
+
+extern "C" int bd_binary_linear_residual(const void* X, const void* W, const int32_t* P, const float* alpha, void* Y, int B,
+                                         int M, int N, int K, int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb,
+                                         int64_t sAlb, int G, int64_t sYb, int64_t sYm, int dtype, int out_dtype, void* ws,
+                                         int64_t ws_bytes, void* stream) {
+    return binary_linear_impl(X, W, P, alpha, Y, B, M, N, K, sXb, sXm, ldw, sPb, sAlb, G, sYb, sYm, dtype, out_dtype, 1, ws,
+                              ws_bytes, stream);
+}
+
+// ------------------------------------------------------------------ per-tenant dense Linear (serving: lm_head per tenant)
+extern "C" int bd_tenant_linear(const void* X, const void* W, void* Y, int T, int M, int N, int K, int64_t sXt, int64_t sXm,
+                                int64_t sWt, int64_t ldw, int64_t sYt, int64_t sYm, int dtype, int out_dtype, void* stream) {
+    if (T < 0 || M < 0 || N < 0 || K < 0) return BD_E_BAD_SHAPE;
+    if (dtype != BD_F16 && dtype != BD_BF16) return BD_E_BAD_DTYPE;
+    if (out_dtype != dtype && out_dtype != BD_F32) return BD_E_BAD_DTYPE;
+    if (T == 0 || M == 0 || N == 0) return BD_OK;
+    if (!X || !W || !Y) return BD_E_NULL;
+    if (K % 32) return BD_E_K_NOT_MULTIPLE;
+    // decode shapes only (the weight-streaming kernel): larger M is a plain batched GEMM and belongs to the BLAS library
+    if (M > GEMV_MAX_M || T > 65535 || K == 0) return BD_E_BAD_SHAPE;
+    if (!aligned16(X) || !aligned16(W) || sXm % 8 || sXt % 8 || ldw % 8 || sWt % 8) return BD_E_BAD_SHAPE;
+    const int64_t lim = (1ll << 31) - 64;
+    const int64_t xb = ((int64_t)(M - 1) * sXm + K) * 2, wb = ((int64_t)(N - 1) * ldw + K) * 2;
+    if (xb >= lim || wb >= lim || sXm < 0) return BD_E_BAD_SHAPE;
+    StreamParams sp{};
+    GemvParams& gp = sp.g;
+    gp.X = (const unsigned short*)X; gp.W = (const unsigned short*)W; gp.P = nullptr; gp.alpha = nullptr; gp.C = Y;
+    gp.ws = nullptr; gp.tickets = nullptr;
+    gp.B = 1; gp.M = M; gp.N = N; gp.K = K; gp.R = M;
+    gp.sXb = 0; gp.sPb = 0; gp.sCb = 0;
+    gp.sXm = (int)sXm; gp.sCm = (int)sYm; gp.ldw = (int)ldw; gp.sAlb = 0; gp.gsz = N;
+    gp.KS = 1; gp.kslice = K; gp.round_mode = 0; gp.accumulate = 0; gp.out_f32 = (out_dtype == BD_F32);
+    sp.sXt = sXt; sp.sWt = sWt; sp.sCt = sYt;
+    sp.x_bytes = (uint32_t)xb; sp.w_bytes = (uint32_t)wb; sp.p_bytes = 0;
+    int bpt = num_cus() / T;                       // blocks per tenant: all tenants stream concurrently, ~one block per CU in total
+    if (bpt < 1) bpt = 1;
+    int cpb = (N + bpt - 1) / bpt;
+    cpb = (cpb + 3) & ~3;
+    if (cpb < 4) cpb = 4;
+    sp.cpb = cpb;
+    dim3 grid((unsigned)((N + cpb - 1) / cpb), (unsigned)T);
+    hipStream_t st = (hipStream_t)stream;
+    static std::atomic<uint64_t> done_h{0}, done_b{0};
+    if (dtype == BD_BF16) {
+        auto kern = gemv_stream_kernel<DT_BF16, 0, true, 4>;
+        if (!ensure_dyn_lds((const void*)kern, STREAM_LDS_BYTES, done_b)) return BD_E_LAUNCH;
+        hipLaunchKernelGGL(kern, grid, dim3(512), STREAM_LDS_BYTES, st, sp);
+    } else {
+        auto kern = gemv_stream_kernel<DT_F16, 0, true, 4>;
+        if (!ensure_dyn_lds((const void*)kern, STREAM_LDS_BYTES, done_h)) return BD_E_LAUNCH;
+        hipLaunchKernelGGL(kern, grid, dim3(512), STREAM_LDS_BYTES, st, sp);
+    }
+    return launch_status();
 }
 
 // ------------------------------------------------------------------ binarize / merge

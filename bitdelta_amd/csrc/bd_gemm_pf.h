@@ -1,12 +1,12 @@
-// W1A16 binary-delta GEMM, ping-pong schedule with FULL-TILE phases (experimental variant of bd_gemm_pp.h).
+// W1A16 binary-delta GEMM, ping-pong schedule with FULL-TILE phases (successor of the half-tile schedule kept in tests/native/ab/bd_gemm_pp.h).
 //
-// bd_gemm_pp.h alternates half-tile phases (16 MFMAs) and pays ~130-150 ticks of idle matrix pipe at each of its 4 barrier
+// The half-tile schedule alternates half-tile phases (16 MFMAs) and pays ~130-150 ticks of idle matrix pipe at each of its 4 barrier
 // hand-offs per k-tile, plus ~170 ticks in M1 for the expansion fillers.  Here a phase covers a WHOLE k-tile:
 //     L(kt): ds_read all 4 k-steps' X fragments and the tile's sign words, expand ALL sign fragments (VALU), wait for tile kt+1
 //     M(kt): 4*TM*TN MFMAs back to back, with this wave's LDS-DMA pieces of tile kt+NS-1 in their shadow -- nothing else
 // Two barriers per k-tile; group 1 (waves 4-7) runs one phase behind group 0.  Costs 4x the fragment registers (X: 16*TM,
 // S: 16*TN VGPRs) on top of the 128 accumulator registers (242 VGPRs at 256x256, no spills).
-// Measured in the same process as bd_gemm_pp.h (profiles/r01_pf_vs_pp.txt): +8..11 % at 256x256 and 256x128.
+// Measured in the same process as the half-tile schedule (profiles/r01_pf_vs_pp.txt): +8..11 % at 256x256 and 256x128.
 // Fused mode: delta loop -> acc *= alpha -> base loop (X and W tiles by LDS-DMA, 3-slot ring) in the same schedule.
 // Rejected here as well (profiles/r01_pp_timeline.txt): handing the pipe over 2/4/8 MFMAs before the phase end -- fewer ticks in
 // the traced block but 17 % MORE GPU cycles overall (GRBM_GUI_ACTIVE 241 k vs 205 k) and 1110 vs 1240 TF.
@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_pf_kernel(const GemmParams
     constexpr int A_PW = Cfg::A_PW, BW_PW = Cfg::BW_PW, W_PW = Cfg::W_PW;
     static_assert(Cfg::NW == 8 && Cfg::WAVES_M == 2 && NS >= 4, "full-tile ping-pong: 8 waves, two groups");
     static_assert(!Cfg::FUSED || Cfg::NSB >= 3, "fused base loop needs a 3-slot ring in this schedule (256x128 tile); 256x256 fused "
-                                                "stays on bd_gemm_pp.h");
+                                                "stays on the half-tile A/B schedule");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));

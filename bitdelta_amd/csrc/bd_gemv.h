@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(SPEC ? 512 : 256) gemv_kernel(const GemvParams
 #pragma unroll
                 for (int r = 0; r < RMAX; ++r) {
                     const uint32_t w = ~wcur[rb][r];
-                    const uint32_t rlo = (w & 0xffffu) | ((w << 15) & 0x7fff0000u);     // chunk | (chunk>>1)<<16, see bd_gemm_pp.h
+                    const uint32_t rlo = (w & 0xffffu) | ((w << 15) & 0x7fff0000u);     // chunk | (chunk>>1)<<16, the same trick as the MFMA tile kernels
                     const uint32_t rhi = (w >> 16) | ((w >> 1) & 0x7fff0000u);
                     const u32x4_t* xv = (const u32x4_t*)(xs_lds + r * XROW + koff);  // 64 bytes = 16 pairs, same address in every lane
                     u32x4_t x4[4];

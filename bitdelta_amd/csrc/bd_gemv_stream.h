@@ -1,0 +1,279 @@
+// Decode path, streaming form: ONE launch per Linear, one 8-wave block per CU, every weight byte in flight from the first cycle.
+//
+//   y[b,m,:] = x[b,m,:] . W^T + alpha[b] * (x[b,m,:] . S_b)        R = B*M <= 16 activation rows, W optional
+//
+// Reference call sites: DiffCompressModule.forward at decode (demo/demo_backend.py:93-98, M = 1, B = tenants) and
+// BinaryDiff.forward (bitdelta/diff.py:33-39) with a few tokens.
+//
+// Why a third decode kernel (profiles/r01_decode_kernels.txt): gemv_kernel / gemv_mfma_kernel slice k over ~512 blocks and pay a
+// second launch for the reduction; gemv_col16_kernel removed that launch but a wave still ran "stage x -> barrier -> load -> compute"
+// back to back (4 short iterations per wave, one stage of prefetch), so the base stream and the sign work added up instead of
+// overlapping, and a launch cost 4.5 us before the first useful byte.  Here:
+//   * grid = one block of 8 waves per CU; block b owns the contiguous column range [b*cpb, (b+1)*cpb) (cpb ~ N/256, so every CU
+//     streams the same number of bytes whatever N is: 24 columns of a fused q+k+v, 112 of a fused gate+up) and walks it in
+//     16-column MFMA tiles; its 8 waves split k; a wave's (tile, k-iteration) pairs form ONE flat stream that is prefetched NS
+//     stages deep ACROSS tile boundaries, so HBM never sees a per-tile ramp;
+//   * nothing is staged before the weight stream starts: the activation fragments are loaded straight from global memory (L2) into
+//     the MFMA operand layout as part of each stage (R rows x 64 B per load; the whole activation block is <= 0.5 MB and L2-resident),
+//     so there is no "x -> LDS -> barrier" in front of the first weight load and no LDS budget that depends on K;
+//   * every load is a raw buffer load: out-of-range rows / columns / k-groups return zero in hardware, which (a) removes every clamp
+//     and keep-mask from the loop and (b) lets the stream run past its end with loads that touch no memory, so the loop body is
+//     straight-line and hipcc's own s_waitcnt vmcnt(N) counting keeps NS-1 stages in flight while one is consumed;
+//   * an iteration covers 4 word rows (128 k): lane group g = l >> 4 owns word row 4*it + g and MFMA step s covers the k-octets
+//     {32 (4 it + g) + 8 s .. + 7} for every operand (W, x, signs), so a lane loads ONE sign word per mask and 64 contiguous bytes
+//     of its W row and of its x row per iteration, with no cross-lane exchange (same operand mapping as gemv_mfma_kernel);
+//   * sign fragment of step s = LUT[byte s of the word]: 256 entries x 16 B, 16 copies (entry e of copy c at e*256 + c*16, lane
+//     reads copy l & 15) so the 16 lanes of every ds_read_b128 service group hit 16 different 16-byte slots: conflict-free whatever
+//     the bytes are (one copy: ~3-way conflicts on random bytes = the measured 0.65 us per tenant per 4096^2 mask).  64 KiB, built
+//     once per block while the first stages are in flight;
+//   * D[col][row] = v_mfma_f32_16x16x32(W or S fragment, x fragment): one base accumulator + one per distinct mask; at the end of
+//     a tile the 8 waves' partial tiles meet in LDS (double-buffered, one s_barrier per tile, loads stay in flight across it) and
+//     wave (tile & 7) sums them in wave order -- deterministic, no atomics, no workspace, no second launch.
+// Algorithmic bytes per launch: 2*N*K (W) + nmask*N*K/8 (signs) + 2*R*K (x) + out; HBM roofline.
+#pragma once
+#include "bd_gemv.h"
+
+namespace bd {
+
+typedef uint32_t bufrsrc_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+}
+// aux: 0 = default cache policy, 2 = nt (streamed once by ONE CU: the weight and sign streams)
+template <int AUX> __device__ __forceinline__ u32x4_t buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t voff) {
+    return __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, AUX));
+}
+template <int AUX> __device__ __forceinline__ uint32_t buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t voff) {
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, AUX);
+}
+
+constexpr int STREAM_LUT_BYTES = 65536;
+constexpr int STREAM_RED_BYTES = 2 * 8 * 64 * 8 * 4;          // [2 buffers][8 waves][64 lanes][4 base + 4 delta] fp32
+constexpr int STREAM_ALPHA_MAX = 512;                          // (row, scale group) pairs of one block kept in LDS
+constexpr int STREAM_LDS_BYTES = STREAM_LUT_BYTES + STREAM_RED_BYTES + STREAM_ALPHA_MAX * 4;
+constexpr uint32_t STREAM_OOB = 0x80000000u;                   // a byte offset that is out of range for every descriptor (extents are < 2 GiB:
+                                                               // checked on the host) and cannot wrap when an immediate offset is added
+
+struct StreamParams {
+    GemvParams g;
+    int cpb;                 // columns per block (multiple of 4)
+    uint32_t x_bytes, w_bytes, p_bytes;     // descriptor extents (bytes from the base pointers)
+    // per-tenant dense weights (bd_tenant_linear: NM = 0, gridDim.y = tenants): element offsets of tenant blockIdx.y
+    long long sXt, sWt, sCt;
+};
+
+template <int DT, int NM, bool HASW, int NS>
+__global__ void __launch_bounds__(512) gemv_stream_kernel(const StreamParams sp) {
+    GemvParams p = sp.g;
+    if constexpr (NM == 0) {       // blockIdx.y = tenant: its own activation rows, weight matrix and output rows
+        p.X += (long long)blockIdx.y * sp.sXt;
+        p.W += (long long)blockIdx.y * sp.sWt;
+        p.C = (char*)p.C + (long long)blockIdx.y * sp.sCt * (p.out_f32 ? 4 : 2);
+    }
+    constexpr int NMA = NM > 0 ? NM : 1;      // array extent (no zero-length arrays)
+    constexpr int NW = 8;
+    extern __shared__ __attribute__((aligned(256))) char dyn_lds[];     // [64 KiB sign LUT][32 KiB reduction buffers]
+    float* const red = (float*)(dyn_lds + STREAM_LUT_BYTES);
+    float* const a_lds = (float*)(dyn_lds + STREAM_LUT_BYTES + STREAM_RED_BYTES);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);                    // neighbouring column ranges share sign-word lines: same XCD
+    const int c_lo = blk * sp.cpb, c_hi = min(p.N, c_lo + sp.cpb);
+    const int ntile = (c_hi - c_lo + 15) >> 4;
+    const int nrow = p.K >> 5;                                           // word rows
+    const int nit = (nrow + 3) >> 2;                                     // 128-k iterations over all of k
+    const int per = (nit + NW - 1) / NW;
+    const int it_lo = min(wave * per, nit), it_hi = min(it_lo + per, nit);
+    // (a wave whose k range is empty -- K < 1024 -- still walks one all-zero stage per tile, so that every wave meets every barrier)
+    const int nmask = p.sPb == 0 ? 1 : p.B;
+
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.X, sp.x_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(HASW ? (const void*)p.W : (const void*)p.X, HASW ? sp.w_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rp = make_rsrc(NM > 0 ? (const void*)p.P : (const void*)p.X, NM > 0 ? sp.p_bytes : 0u);
+
+    // activation row of MFMA column li (rows >= R: out of range -> zeros; their D columns are never stored)
+    uint32_t x_off;
+    {
+        const int b = li / p.M, m = li - b * p.M;
+        x_off = li < p.R ? (uint32_t)(((long long)b * p.sXb + (long long)m * p.sXm) * 2) : STREAM_OOB;
+    }
+
+    // The scales this block can need -- (row, scale group) for the groups its column range touches -- are fetched by the first threads
+    // BEFORE the stream starts: the oldest entry of the wave's in-order load queue, so waiting for it never drains a weight load.
+    // (A load issued at the end of a tile would be the youngest: s_waitcnt vmcnt(0), the whole prefetch lost once per tile.)
+    const int g0 = c_lo / p.gsz, ng = (c_hi - 1) / p.gsz - g0 + 1;
+    const bool al_lds = p.alpha != nullptr && p.R * ng <= STREAM_ALPHA_MAX;
+    float a_pre = 0.f;
+    if (al_lds) {
+        const int idx = min((int)threadIdx.x, p.R * ng - 1), r = idx / ng, j = idx - r * ng;
+        a_pre = p.alpha[(long long)(r / p.M) * p.sAlb + g0 + j];
+    }
+
+    struct Stage { u32x4_t xf[4]; u32x4_t wf[4]; uint32_t wd[NMA]; };
+    // one stage = (tile, iteration): 4 x 16 B of the lane's x row, 4 x 16 B of its W row, one sign word per mask
+    auto issue = [&](Stage& st, int tile, int it) {
+        const int irow = 4 * it + g;                                     // this lane group's word row
+        const bool krow_ok = tile < ntile && irow < nrow;
+        const int n = c_lo + tile * 16 + li;
+        const bool col_ok = n < c_hi;
+        const uint32_t xo = krow_ok ? x_off + (uint32_t)irow * 64u : STREAM_OOB;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) st.xf[s] = buf_load16<0>(rx, xo + 16u * s);
+        if constexpr (HASW) {
+            const uint32_t wo = (krow_ok && col_ok) ? (uint32_t)n * (uint32_t)p.ldw * 2u + (uint32_t)irow * 64u : STREAM_OOB;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) st.wf[s] = buf_load16<2>(rw, wo + 16u * s);
+        }
+        [[maybe_unused]] const uint32_t po = (krow_ok && col_ok) ? ((uint32_t)irow * (uint32_t)p.N + (uint32_t)n) * 4u : STREAM_OOB;
+#pragma unroll
+        for (int t = 0; t < NM; ++t) {
+            const uint32_t tb = (uint32_t)(min(t, nmask - 1)) * (uint32_t)p.sPb * 4u;
+            st.wd[t] = buf_load4<2>(rp, po == STREAM_OOB ? STREAM_OOB : po + tb);
+        }
+        // the stages must enter the load queue in stream order: without this fence hipcc clusters the loads of ALL prologue stages
+        // by descriptor (every x, then every W, then every sign word), and stage 0 cannot be consumed before nearly all of them land
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // flat (tile, iteration) stream of this wave
+    int ti = 0, ii = it_lo;                                              // next stage to issue
+    auto advance = [&](int& t, int& i) { if (++i >= it_hi) { i = it_lo; ++t; } };
+    Stage st[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        issue(st[u], ti, ii);
+        advance(ti, ii);
+    }
+
+    if constexpr (NM > 0) {   // sign LUT, 16 copies: slot index = 16 e + c is linear in the thread id -> every ds_write_b128 stores 64 consecutive slots
+        constexpr uint32_t POS = One2<DT>::v & 0xffffu, NEG = POS | 0x8000u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int slot = threadIdx.x + 512 * j, ee = slot >> 4;
+            u32x4_t w;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) w[d] = (((ee >> (2 * d)) & 1) ? POS : NEG) | ((((ee >> (2 * d + 1)) & 1) ? POS : NEG) << 16);
+            *(u32x4_t*)(dyn_lds + slot * 16) = w;
+        }
+    }
+    if (al_lds && (int)threadIdx.x < p.R * ng) a_lds[threadIdx.x] = a_pre;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    f32x4_t accB = {0.f, 0.f, 0.f, 0.f}, accD[NMA];
+#pragma unroll
+    for (int t = 0; t < NM; ++t) accD[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const uint32_t copy_off = (uint32_t)li * 16u;
+
+    // LUT address of step s of word w: byte s -> bits 8..15, copy slot -> bits 0..7, i.e. byte * 256 + (l & 15) * 16  (one v_perm_b32)
+    auto lut = [&](uint32_t w, int s) -> u32x4_t {
+        const uint32_t off = __builtin_amdgcn_perm(w, copy_off, 0x0c0c0400u + ((uint32_t)s << 8));
+        return *(const u32x4_t*)(dyn_lds + off);
+    };
+    // The sign fragments are read one MFMA step ahead and the steps are fenced: left alone, hipcc hoists all 4*NM ds_read_b128 of a
+    // stage to its top (16*NM VGPRs of fragments in flight; with NS stages of loads in registers that spilled the in-flight load
+    // destinations to scratch, and scratch traffic shares vmcnt with the weight stream).  One step of NM + 1 MFMAs (>= 110 cycles of
+    // matrix pipe) covers the LDS latency of the next step's reads.
+    auto compute = [&](const Stage& cur) {
+        u32x4_t sf[2][NMA];
+#pragma unroll
+        for (int t = 0; t < NM; ++t) sf[0][t] = lut(cur.wd[t], 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s < 3) {
+#pragma unroll
+                for (int t = 0; t < NM; ++t) sf[(s + 1) & 1][t] = lut(cur.wd[t], s + 1);
+            }
+            if constexpr (HASW) accB = mfma16<DT>(cur.wf[s], cur.xf[s], accB);
+#pragma unroll
+            for (int t = 0; t < NM; ++t) accD[t] = mfma16<DT>(sf[s & 1][t], cur.xf[s], accD[t]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // end of a tile: the 8 partial tiles meet in LDS; wave (tile & 7) sums them in wave order, scales, adds the base, stores
+    auto finish_tile = [&](int tile) {
+        float* const rb = red + (tile & 1) * (NW * 64 * 8);
+        {
+            const int b = min(li, p.R - 1) / p.M;
+            const int bm = p.sPb == 0 ? 0 : b;
+            // this row's accumulator, picked with bit masks (a chain of `if (bm == t) d = accD[t]` is turned into a scratch array
+            // indexed by bm, and scratch traffic shares vmcnt with the weight stream)
+            u32x4_t d = NM > 0 ? __builtin_bit_cast(u32x4_t, accD[0]) : u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int t = 1; t < NM; ++t) {
+                const uint32_t mk = bm == t ? 0xffffffffu : 0u;
+                d = (__builtin_bit_cast(u32x4_t, accD[t]) & u32x4_t{mk, mk, mk, mk}) | (d & ~u32x4_t{mk, mk, mk, mk});
+            }
+            *(f32x4_t*)&rb[(wave * 64 + lane) * 8] = accB;
+            *(u32x4_t*)&rb[(wave * 64 + lane) * 8 + 4] = d;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (wave == (tile & 7) && li < p.R) {
+            const int b = li / p.M;
+            f32x4_t sb = {0.f, 0.f, 0.f, 0.f}, sd = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {                               // fixed wave order: deterministic
+                sb += *(const f32x4_t*)&rb[(w * 64 + lane) * 8];
+                sd += *(const f32x4_t*)&rb[(w * 64 + lane) * 8 + 4];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = c_lo + tile * 16 + 4 * g + e;
+                if (n < c_hi) {
+                    float v = sd[e];
+                    if (al_lds) v *= a_lds[li * ng + (n / p.gsz - g0)];
+                    else if (p.alpha) v *= p.alpha[(long long)b * p.sAlb + n / p.gsz];
+                    if constexpr (HASW) v += sb[e];
+                    store_out<DT>(p, li, n, v);
+                }
+            }
+        }
+        accB = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NM; ++t) accD[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    };
+
+    // Main loop: whole rounds of NS stages.  Its body has no branch around its loads (past the end of the stream they are out of
+    // range and touch no memory) and no exit in the middle, so hipcc's waitcnt pass sees one straight-line stream per round and waits
+    // with vmcnt((NS-1) * loads-per-stage).  (A conditional issue, or an exit test between the stages -- which the structuriser
+    // turns into an edge back to the loop header -- merges "just re-issued" into the header state and every wait of the first stage
+    // becomes vmcnt(0): measured in the ISA, not guessed.)  The last total % NS stages need no new loads: straight-line tail.
+    const int cntb = max(it_hi - it_lo, 1);
+    const int total = ntile * cntb;
+    int tc = 0, ic = it_lo;                                              // stage being consumed
+    int f = 0;
+    for (; f + NS <= total; f += NS) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            compute(st[u]);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(st[u], ti, ii);
+            advance(ti, ii);
+            if (++ic >= it_hi) {
+                finish_tile(tc);
+                ic = it_lo;
+                ++tc;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NS - 1; ++u) {
+        if (f + u < total) {
+            compute(st[u]);
+            if (++ic >= it_hi) {
+                finish_tile(tc);
+                ic = it_lo;
+                ++tc;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the run-ahead (out-of-range) loads of the last round
+}
+
+}  // namespace bd

@@ -1,38 +1,113 @@
 """Multi-tenant serving modules: MI355X counterparts of demo/demo_backend.py:62-179 in the reference.
 
     DiffCompressModule(module, mask_list, coeff_list)    reference :82-98   one base nn.Linear + T stacked 1-bit deltas,
-                                                          batch row i uses delta i
-    DataParallelModule(module, weight_list)              reference :62-79   per-tenant dense weights (embed / norm / lm_head)
-    register_diff_compress / unregister_diff_compress / DiffCompress       reference :107-179
+                                                          batch row i uses delta i: ONE fused HIP launch per forward
+    DataParallelModule(module, weight_list)              reference :62-79   per-tenant dense weights (embedding / norm / lm_head),
+                                                          batch row i uses weight i: here ONE batched op per forward instead of
+                                                          the reference's Python loop that swaps `module.weight` T times
+    register_diff_compress / unregister_diff_compress / DiffCompress        reference :107-179 (module-tree surgery)
 
-DiffCompressModule.forward is ONE fused HIP launch (base GEMM + T delta GEMMs + per-tenant scale + add) instead of the
-reference's Linear + binary_bmm + multiply + add.  The FastAPI/gradio shell around these modules is out of scope.
+The names, constructor arguments and the batch-row-i <-> tenant-i contract are the reference's (they are the drop-in surface of
+its demo); the implementations are this repo's.  The FastAPI / gradio shell around these modules is out of scope.
+BitDelta is Apache-2.0 (FasterDecoding/BitDelta).
 """
 import gc
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
-from .binary_gemm_kernel import binary_linear
+from .binary_gemm_kernel import binary_linear, tenant_linear
 
 
+# ------------------------------------------------------------------------------------------------ per-tenant dense weights
 class DataParallelModule(nn.Module):
+    """Row block i of the batch runs through `module` with tenant i's weight.
+
+    The reference does this with a loop -- assign `module.weight.data`, call the module on `hidden_states[i, None]`, collect -- and
+    pads the results to a common shape with the dtype's most negative value (tenants may differ in vocabulary size, so lm_head
+    outputs can be ragged; demo/demo_backend.py:76-79).  Here the tenants' weights are stacked once at construction and a forward
+    is one batched operation:
+      * nn.Embedding          -> one gather from the [T, vocab, hidden] stack
+      * nn.Linear             -> tenant_linear: one HIP launch streams every tenant's matrix once (decode), torch.bmm at prefill
+      * scale-only norms      -> the module evaluated ONCE with a unit weight, times the [T, 1, hidden] stack (bit-identical to
+        (weight 1-D, no bias)    per-tenant evaluation: the norm's last step is `weight * normalised`)
+      * anything else         -> the reference's per-tenant loop (correct for any leaf module, just slow)
+    Ragged vocabularies are zero-padded in the stack and the padded outputs are filled with finfo.min, which is exactly what the
+    reference's nested-tensor padding produces."""
+
     def __init__(self, module, weight_list):
         super().__init__()
         self.module = module
-        self.weight_list = weight_list
+        self.weight_list = list(weight_list)
         self.original_weight = module.weight.data
+        rows = [w.shape[0] for w in self.weight_list]
+        self.rows = rows
+        self.ragged = len(set(rows)) > 1
+        same_tail = len({tuple(w.shape[1:]) for w in self.weight_list}) == 1
+        self.kind = self._classify(module) if same_tail else "loop"
+        self.stack = None
+        if self.kind != "loop":
+            top = max(rows)
+            dev, dt = self.weight_list[0].device, self.weight_list[0].dtype
+            stack = torch.zeros((len(rows), top) + tuple(self.weight_list[0].shape[1:]), device=dev, dtype=dt)
+            for t, w in enumerate(self.weight_list):
+                stack[t, :w.shape[0]] = w
+            self.stack = stack
+            if self.kind == "scale" and self.ragged:
+                self.kind = "loop"
 
-    def forward(self, hidden_states):
-        # hidden_states: (B, ...); row i runs through tenant i's weights (reference :69-79)
-        outputs = []
-        for i in range(len(self.weight_list)):
-            self.module.weight.data = self.weight_list[i]
-            outputs.append(self.module(hidden_states[i, None]))
-        nt = torch.nested.as_nested_tensor([outputs[i][0] for i in range(len(outputs))])
+    @staticmethod
+    def _classify(module):
+        if isinstance(module, nn.Embedding):
+            return "embedding"
+        if isinstance(module, nn.Linear):
+            return "linear"
+        w = getattr(module, "weight", None)
+        if w is not None and w.dim() == 1 and getattr(module, "bias", None) is None and not isinstance(module, nn.LayerNorm):
+            return "scale"
+        return "loop"
+
+    def _loop(self, hidden_states):
+        outs = []
+        for t, w in enumerate(self.weight_list):
+            self.module.weight.data = w
+            outs.append(self.module(hidden_states[t, None])[0])
+        self.module.weight.data = self.original_weight
+        nt = torch.nested.as_nested_tensor(outs)
         return torch.nested.to_padded_tensor(nt, torch.finfo(nt.dtype).min)
 
+    def forward(self, hidden_states):
+        T = len(self.weight_list)
+        assert hidden_states.shape[0] == T, "batch row i must map to tenant i"
+        if self.kind == "embedding":
+            ids = hidden_states
+            t_idx = torch.arange(T, device=ids.device).view(T, *([1] * (ids.dim() - 1)))
+            return self.stack[t_idx, ids]
+        if self.kind == "linear":
+            x = hidden_states
+            lead = x.shape[1:-1]
+            y = tenant_linear(x.reshape(T, -1, x.shape[-1]), self.stack)
+            if self.module.bias is not None:
+                y = y + self.module.bias
+            if self.ragged:
+                lim = torch.tensor(self.rows, device=y.device).view(T, 1, 1)
+                y = y.masked_fill(torch.arange(y.shape[-1], device=y.device).view(1, 1, -1) >= lim, torch.finfo(y.dtype).min)
+            return y.reshape(T, *lead, y.shape[-1])
+        if self.kind == "scale":
+            unit = getattr(self, "_unit", None)
+            if unit is None or unit.device != hidden_states.device:
+                unit = self._unit = torch.ones_like(self.weight_list[0])
+            self.module.weight.data = unit
+            try:
+                normed = self.module(hidden_states)
+            finally:
+                self.module.weight.data = self.original_weight
+            return self.stack.view(T, *([1] * (normed.dim() - 2)), -1) * normed
+        return self._loop(hidden_states)
 
+
+# ------------------------------------------------------------------------------------------------ base Linear + T 1-bit deltas
 class DiffCompressModule(nn.Module):
     def __init__(self, module, mask_list, coeff_list):
         super().__init__()
@@ -62,52 +137,60 @@ class DiffCompressModule(nn.Module):
         return y
 
 
-# Assume batch size = len(checkpoint_list); sample i uses checkpoint_list[i]  (reference :101-105)
+# ------------------------------------------------------------------------------------------------ module-tree surgery
+# One batch row per checkpoint: sample i runs with checkpoint_list[i] (reference :101-105).  The stacked masks of a Linear are
+# built once per process and cached by module name, because the reference pops them out of the checkpoint dicts to free memory.
 cached_modules = {}
 
 
+def _split(name):
+    parent, _, leaf = name.rpartition(".")
+    return parent, leaf
+
+
 def register_diff_compress(model, checkpoint_list):
-    for name, module in model.named_modules():
-        if len(list(module.named_children())) == 0:
-            if f"{name}.weight" in checkpoint_list[0]:
-                parent = model.get_submodule(".".join(name.split(".")[:-1]))
-                setattr(parent, name.split(".")[-1],
-                        DataParallelModule(module, [ckpt[f"{name}.weight"] for ckpt in checkpoint_list]))
-            elif f"{name}.mask" in checkpoint_list[0] or name in cached_modules:
-                assert isinstance(module, nn.Linear), "Only support linear layer"
-                parent = model.get_submodule(".".join(name.split(".")[:-1]))
-                if name not in cached_modules:
-                    cached_modules[name] = (
-                        torch.stack([ckpt[f"{name}.mask"] for ckpt in checkpoint_list], dim=0).contiguous(),
-                        torch.stack([ckpt[f"{name}.coeff"] for ckpt in checkpoint_list], dim=0),
-                    )
-                    for ckpt in checkpoint_list:
-                        ckpt.pop(f"{name}.mask")
-                        ckpt.pop(f"{name}.coeff")
-                    gc.collect()
-                    torch.cuda.empty_cache()
-                setattr(parent, name.split(".")[-1],
-                        DiffCompressModule(module, cached_modules[name][0], cached_modules[name][1]))
+    first = checkpoint_list[0]
+    leaves = [(name, mod) for name, mod in model.named_modules() if next(mod.children(), None) is None]
+    for name, module in leaves:
+        parent_name, leaf = _split(name)
+        if f"{name}.weight" in first:                      # dense per-tenant tensor (embedding / norm / lm_head)
+            wrapped = DataParallelModule(module, [ckpt[f"{name}.weight"] for ckpt in checkpoint_list])
+        elif f"{name}.mask" in first or name in cached_modules:
+            assert isinstance(module, nn.Linear), "Only support linear layer"
+            if name not in cached_modules:
+                masks = torch.stack([ckpt[f"{name}.mask"] for ckpt in checkpoint_list], dim=0).contiguous()
+                coeffs = torch.stack([ckpt[f"{name}.coeff"] for ckpt in checkpoint_list], dim=0)
+                cached_modules[name] = (masks, coeffs)
+                for ckpt in checkpoint_list:               # the stack is now the only copy
+                    del ckpt[f"{name}.mask"], ckpt[f"{name}.coeff"]
+                gc.collect()
+                torch.cuda.empty_cache()
+            wrapped = DiffCompressModule(module, *cached_modules[name])
+        else:
+            continue
+        setattr(model.get_submodule(parent_name), leaf, wrapped)
 
 
 def unregister_diff_compress(model):
-    for name, module in model.named_modules():
-        if isinstance(module, DataParallelModule):
-            module.module.weight.data = module.original_weight
-            parent = model.get_submodule(".".join(name.split(".")[:-1]))
-            setattr(parent, name.split(".")[-1], module.module)
-        elif isinstance(module, DiffCompressModule):
-            parent = model.get_submodule(".".join(name.split(".")[:-1]))
-            setattr(parent, name.split(".")[-1], module.module)
+    wrapped = [(name, mod) for name, mod in model.named_modules() if isinstance(mod, (DataParallelModule, DiffCompressModule))]
+    for name, mod in wrapped:
+        if isinstance(mod, DataParallelModule):
+            mod.module.weight.data = mod.original_weight
+        parent_name, leaf = _split(name)
+        setattr(model.get_submodule(parent_name), leaf, mod.module)
 
 
 class DiffCompress:
+    """`with DiffCompress(model, checkpoints): ...` -- the model serves the T checkpoints inside the block, the plain base outside."""
+
     def __init__(self, model, checkpoint_list):
         self.model = model
         self.checkpoint_list = checkpoint_list
 
     def __enter__(self):
         register_diff_compress(self.model, self.checkpoint_list)
+        return self.model
 
     def __exit__(self, exc_type, exc_value, traceback):
         unregister_diff_compress(self.model)
+        return False

@@ -2,7 +2,10 @@
  * bitdelta_hip.h -- C ABI of libbitdelta_hip.so: the MI355X (gfx950) implementation of BitDelta's
  * 1-bit-delta Linear hot path.  Plain pointers and sizes only; every pointer is a DEVICE pointer unless
  * noted; `stream` is a hipStream_t passed as void* (NULL = default stream).  All entry points are
- * re-entrant and stateless (the reference's serving threads call without locks, demo/demo_backend.py:261).
+ * re-entrant (the reference's serving threads call without locks, demo/demo_backend.py:261): the only state is
+ * (a) the bd_set_* test / tuning overrides, which are THREAD-LOCAL (a thread that forces a kernel family does not
+ * change what other threads launch), and (b) per-DEVICE caches (CU count, max-dynamic-LDS attribute already
+ * raised) keyed by the current HIP device, so one process may drive several GPUs.
  * Return value: 0 on success, a negative BD_E_* code otherwise (bd_error_string() names it); nothing throws.
  *
  * The reference has no FFI of its own: the interface this library replaces is the Python function surface
@@ -77,6 +80,25 @@ int bd_binary_linear(const void* X, const void* W, const int32_t* P, const float
                      int64_t sYb, int64_t sYm, int dtype, int out_dtype,
                      void* ws, int64_t ws_bytes, void* stream);
 
+/* the same Linear with the residual connection folded into its epilogue:  Y[b] = Y_in[b] + X[b] . W^T + alpha * (X[b] . S[b])
+ * (fp32 sum, one rounding) -- the `hidden = residual + o_proj(...)` / `+ down_proj(...)` of the decoder layers that call the
+ * reference's modules.  Decode shapes only (B*M <= 64 rows, M <= 16: where the add would otherwise be a launch of its own);
+ * anything larger returns BD_E_BAD_SHAPE and the caller adds the residual itself. */
+int bd_binary_linear_residual(const void* X, const void* W, const int32_t* P, const float* alpha, void* Y,
+                              int B, int M, int N, int K,
+                              int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb, int64_t sAlb, int G,
+                              int64_t sYb, int64_t sYm, int dtype, int out_dtype,
+                              void* ws, int64_t ws_bytes, void* stream);
+
+/* per-tenant dense Linear at decode: replaces the weight-swapping loop of DataParallelModule.forward
+ * (demo/demo_backend.py:62-79) for nn.Linear leaves (lm_head): row block t runs through tenant t's OWN weight matrix,
+ *   Y[t] = X[t] . W[t]^T,   X [T, M, K] (strides sXt, sXm), W [T, N, K] (strides sWt, ldw), Y [T, M, N] (strides sYt, sYm),
+ * one launch for all tenants (every weight byte streamed once, fp32 accumulate, one rounding).  M <= 16 only (decode);
+ * larger M returns BD_E_BAD_SHAPE: that is an ordinary batched GEMM, not this library's business. */
+int bd_tenant_linear(const void* X, const void* W, void* Y, int T, int M, int N, int K,
+                     int64_t sXt, int64_t sXm, int64_t sWt, int64_t ldw, int64_t sYt, int64_t sYm,
+                     int dtype, int out_dtype, void* stream);
+
 /* bytes of scratch bd_delta_bmm / bd_binary_linear may need for this problem (split-k partials of the decode path) */
 int64_t bd_gemm_workspace_bytes(int B, int M, int N, int K);
 
@@ -90,15 +112,18 @@ int64_t bd_binarize_workspace_bytes(int64_t N, int64_t K);
 int bd_merge_delta(void* W, int64_t ldw, const int32_t* P, const float* coeff, int64_t N, int64_t K, int dtype,
                    void* stream);
 
-/* tuning / test hook: force a kernel family for bd_delta_bmm / bd_binary_linear.
+/* tuning / test hook (thread-local): force a kernel family for bd_delta_bmm / bd_binary_linear.
  * -1 auto (default); 0..3 MFMA tile configs (256x256 ping-pong, 128x256, 64x256, 32x256); 4 = 256x256 single-barrier schedule;
  * 5 = 256x128 ping-pong (picked automatically when it fills the CUs better); 6 / 7 = the half-tile ping-pong schedule at
  * 256x256 / 256x128 (A/B reference for the shipped full-tile schedule); 8 = one-pass fused 256x128 kernel with two accumulator
  * sets (bd_binary_linear only; the automatic choice for M > 128; 0 / 5 remain as the two-loop A/B references); 9 = the same kernel
  * with a 128x128 tile (picked when 256x128 tiles cannot fill the CUs); 10 = the 128x128 kernel with split-k over blockIdx.y and a
  * reduce launch (automatic for 16 < M <= 512 when the tiles would leave more than half the CUs idle; needs the workspace);
- * 100 generic edge kernel; 200 decode path (200 + KS forces a k-split), which picks between 300 (+ KS) = the VALU sign-flip
- * kernel, 400 (+ KS) = the MFMA + sign-LUT kernel and 500 (+ KS) = the no-split-k kernel (16 columns x all of k per block).
+ * 100 generic edge kernel; 200 decode path (200 + KS forces a k-split), which picks between 600 (+ columns-per-block / 4) = the
+ * streaming kernel (one launch, one 8-wave block per CU, the automatic choice for N >= 512 and <= 8 masks per chunk),
+ * 300 (+ KS) = the VALU sign-flip kernel, 400 (+ KS) = the MFMA + sign-LUT kernel and 500 (+ KS) = the no-split-k kernel
+ * (16 columns x all of k per block).  Variants 4 / 6 / 7 and fused 0 / 5 (rejected schedules kept as A/B references) exist
+ * only in builds with -DBD_AB_VARIANTS (tests/native/bd_harness); the shipped library answers BD_E_BAD_SHAPE for them.
  * A forced variant whose preconditions fail returns BD_E_BAD_SHAPE instead of silently falling back. */
 int bd_set_gemm_variant(int variant);
 /* which family the LAST call on this thread dispatched to (same codes as above) */

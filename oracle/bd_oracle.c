@@ -23,6 +23,7 @@
 #include <stddef.h>
 #include <string.h>
 #include <math.h>
+#include <stdlib.h>
 
 #define BDO_F16 0
 #define BDO_BF16 1
@@ -160,25 +161,32 @@ int bdo_unpack(const void *words, int64_t batch, int64_t KW, int64_t N, int n_bi
 /* ------------------------------------------------------------------ */
 /* binary GEMM        bitdelta/binary_gemm_kernel.py:48-184, :186-335  */
 /* ------------------------------------------------------------------ */
-static inline double delta_dot(const void *A, int64_t a_off, const int32_t *P, int64_t p_off,
-                               int64_t N, int64_t n, int64_t K, int dtype, int acc_mode) {
-    /* S[k,n] = 2*bit - 1 with bit = (word[k/32,n] >> (k%32)) & 1   (:109-111, :128-129, :270-272) */
-    if (acc_mode == 0) {            /* fp32, k ascending (one legal order of tl.dot's fp32 accumulate, :118/:134) */
-        float acc = 0.0f;
+/*
+ * One activation row against every column of one mask:  acc[n] = sum_k (bit[k,n] ? x[k] : -x[k]),  k ASCENDING for every n.
+ * S[k,n] = 2*bit - 1 with bit = (word[k/32,n] >> (k%32)) & 1   (:109-111, :128-129, :270-272).
+ * acc_mode 0: fp32 accumulate (one legal order of tl.dot's fp32 accumulate, :118/:134); 1: double accumulate (exact-sum reference).
+ * The loop nest is k outer / n inner so the packed words are read as contiguous rows; per column the additions happen in the
+ * same k order as a column-at-a-time dot product, so the result is bit-identical to it.
+ */
+static void delta_row(const float *x, const int32_t *P, int64_t N, int64_t K, int acc_mode, double *acc_d, float *acc_f) {
+    if (acc_mode == 0) {
+        for (int64_t n = 0; n < N; ++n) acc_f[n] = 0.0f;
         for (int64_t k = 0; k < K; ++k) {
-            uint32_t w = (uint32_t)P[p_off + (k >> 5) * N + n];
-            float a = load_f(A, a_off + k, dtype);
-            acc += ((w >> (k & 31)) & 1u) ? a : -a;
+            const uint32_t *row = (const uint32_t *)P + (k >> 5) * N;
+            const int sh = (int)(k & 31);
+            const float a = x[k], na = -a;
+            for (int64_t n = 0; n < N; ++n) acc_f[n] += ((row[n] >> sh) & 1u) ? a : na;
         }
-        return (double)acc;
+        for (int64_t n = 0; n < N; ++n) acc_d[n] = (double)acc_f[n];
+        return;
     }
-    double acc = 0.0;               /* exact-sum reference: double accumulate */
+    for (int64_t n = 0; n < N; ++n) acc_d[n] = 0.0;
     for (int64_t k = 0; k < K; ++k) {
-        uint32_t w = (uint32_t)P[p_off + (k >> 5) * N + n];
-        double a = (double)load_f(A, a_off + k, dtype);
-        acc += ((w >> (k & 31)) & 1u) ? a : -a;
+        const uint32_t *row = (const uint32_t *)P + (k >> 5) * N;
+        const int sh = (int)(k & 31);
+        const double a = (double)x[k], na = -a;
+        for (int64_t n = 0; n < N; ++n) acc_d[n] += ((row[n] >> sh) & 1u) ? a : na;
     }
-    return acc;
 }
 
 /*
@@ -191,19 +199,37 @@ static inline double delta_dot(const void *A, int64_t a_off, const int32_t *P, i
  * acc_mode 0: fp32 accumulate k-ascending; 1: double accumulate then one rounding to fp32.
  * Edge semantics: arbitrary M, N; K % 32 == 0 required (pack :13); `activation` is accepted and
  * ignored by the reference (:73, :141-142) so it has no parameter here.
+ * Rows are independent: the (b, m) loop is an OpenMP parallel loop (no reduction crosses threads).
  */
 int bdo_delta_bmm(const void *A, const int32_t *P, void *C, int64_t B, int64_t M, int64_t N, int64_t K,
                   int64_t sAb, int64_t sAm, int64_t sPb, int64_t sCb, int64_t sCm,
                   int dtype_in, int dtype_out, int round_mode, int acc_mode) {
     if (K % 32) return -1;
-    for (int64_t b = 0; b < B; ++b)
-        for (int64_t m = 0; m < M; ++m)
-            for (int64_t n = 0; n < N; ++n) {
-                float acc = (float)delta_dot(A, b * sAb + m * sAm, P, b * sPb, N, n, K, dtype_in, acc_mode);
-                if (round_mode == 1) acc = bdo_f16_to_f32(bdo_f32_to_f16(acc));
-                store_f(C, b * sCb + m * sCm + n, acc, dtype_out);
+    int fail = 0;
+#pragma omp parallel
+    {
+        float *x = (float *)malloc((size_t)(K > 0 ? K : 1) * sizeof(float));
+        float *af = (float *)malloc((size_t)(N > 0 ? N : 1) * sizeof(float));
+        double *ad = (double *)malloc((size_t)(N > 0 ? N : 1) * sizeof(double));
+        if (!x || !af || !ad) {
+#pragma omp atomic write
+            fail = 1;
+        } else {
+#pragma omp for schedule(dynamic, 1)
+            for (int64_t r = 0; r < B * M; ++r) {
+                const int64_t b = r / M, m = r - b * M;
+                for (int64_t k = 0; k < K; ++k) x[k] = load_f(A, b * sAb + m * sAm + k, dtype_in);
+                delta_row(x, P + b * sPb, N, K, acc_mode, ad, af);
+                for (int64_t n = 0; n < N; ++n) {
+                    float acc = (float)ad[n];
+                    if (round_mode == 1) acc = bdo_f16_to_f32(bdo_f32_to_f16(acc));
+                    store_f(C, b * sCb + m * sCm + n, acc, dtype_out);
+                }
             }
-    return 0;
+        }
+        free(x); free(af); free(ad);
+    }
+    return fail ? -9 : 0;
 }
 
 /* ------------------------------------------------------------------ */
@@ -223,6 +249,7 @@ int bdo_delta_bmm(const void *A, const int32_t *P, void *C, int64_t B, int64_t M
  *                                               the scalar tensor to the common dtype first)
  *     y  = round_in(t1 + t3)
  *   demo_backend.py:95-98 is the same chain with per-tenant fp16 coeff.
+ * Both contractions accumulate in double, k ascending.  W is converted to fp32 once (exact), rows run in parallel (OpenMP).
  */
 int bdo_binary_linear(const void *X, const void *W, const int32_t *P, const float *alpha, void *Y,
                       int64_t B, int64_t M, int64_t N, int64_t K,
@@ -230,27 +257,57 @@ int bdo_binary_linear(const void *X, const void *W, const int32_t *P, const floa
                       int64_t sYb, int64_t sYm, int dtype_in, int dtype_out, int round_mode) {
     if (K % 32) return -1;
     if (G < 1 || N % G) return -3;
-    int64_t gsz = N / G;
-    for (int64_t b = 0; b < B; ++b)
-        for (int64_t m = 0; m < M; ++m)
-            for (int64_t n = 0; n < N; ++n) {
-                double base = 0.0;
-                for (int64_t k = 0; k < K; ++k)
-                    base += (double)load_f(X, b * sXb + m * sXm + k, dtype_in) * (double)load_f(W, n * ldw + k, dtype_in);
-                double dl = delta_dot(X, b * sXb + m * sXm, P, b * sPb, N, n, K, dtype_in, 1);
-                float al = alpha[b * sAlb + n / gsz];
-                float y;
-                if (round_mode == 0) {
-                    y = (float)(base + (double)al * dl);
-                } else {
-                    float t1 = round_f((float)base, dtype_in);
-                    float t2 = round_f(bdo_f16_to_f32(bdo_f32_to_f16((float)dl)), dtype_in);
-                    float t3 = round_f(round_f(al, dtype_in) * t2, dtype_in);
-                    y = round_f(t1 + t3, dtype_in);
+    const int64_t gsz = N / G;
+    float *Wf = (float *)malloc((size_t)(N * K > 0 ? N * K : 1) * sizeof(float));
+    if (!Wf) return -9;
+#pragma omp parallel for schedule(static)
+    for (int64_t n = 0; n < N; ++n)
+        for (int64_t k = 0; k < K; ++k) Wf[n * K + k] = load_f(W, n * ldw + k, dtype_in);
+    int fail = 0;
+    /* few rows (decode): parallel over columns inside a row; many rows: parallel over rows */
+    const int by_rows = (B * M >= 8);
+#pragma omp parallel if (by_rows)
+    {
+        float *x = (float *)malloc((size_t)(K > 0 ? K : 1) * sizeof(float));
+        float *af = (float *)malloc((size_t)(N > 0 ? N : 1) * sizeof(float));
+        double *ad = (double *)malloc((size_t)(N > 0 ? N : 1) * sizeof(double));
+        double *bs = (double *)malloc((size_t)(N > 0 ? N : 1) * sizeof(double));
+        if (!x || !af || !ad || !bs) {
+#pragma omp atomic write
+            fail = 1;
+        } else {
+#pragma omp for schedule(dynamic, 1)
+            for (int64_t r = 0; r < B * M; ++r) {
+                const int64_t b = r / M, m = r - b * M;
+                for (int64_t k = 0; k < K; ++k) x[k] = load_f(X, b * sXb + m * sXm + k, dtype_in);
+#pragma omp parallel for schedule(static) if (!by_rows)
+                for (int64_t n = 0; n < N; ++n) {
+                    double base = 0.0;
+                    const float *wr = Wf + n * K;
+                    for (int64_t k = 0; k < K; ++k) base += (double)x[k] * (double)wr[k];
+                    bs[n] = base;
                 }
-                store_f(Y, b * sYb + m * sYm + n, y, dtype_out);
+                delta_row(x, P + b * sPb, N, K, 1, ad, af);
+                for (int64_t n = 0; n < N; ++n) {
+                    const double base = bs[n], dl = ad[n];
+                    const float al = alpha[b * sAlb + n / gsz];
+                    float y;
+                    if (round_mode == 0) {
+                        y = (float)(base + (double)al * dl);
+                    } else {
+                        float t1 = round_f((float)base, dtype_in);
+                        float t2 = round_f(bdo_f16_to_f32(bdo_f32_to_f16((float)dl)), dtype_in);
+                        float t3 = round_f(round_f(al, dtype_in) * t2, dtype_in);
+                        y = round_f(t1 + t3, dtype_in);
+                    }
+                    store_f(Y, b * sYb + m * sYm + n, y, dtype_out);
+                }
             }
-    return 0;
+        }
+        free(x); free(af); free(ad); free(bs);
+    }
+    free(Wf);
+    return fail ? -9 : 0;
 }
 
 /* ------------------------------------------------------------------ */

@@ -22,8 +22,9 @@
 // barrier 2kt+3.  The refill of that slot (tile kt+NS) is issued in M0 of tile kt+1 = M(2kt+3), which both groups enter after
 // barrier 2kt+3.  Tile kt+1 is first read (its words) in L(2kt+2), by group 1 right after barrier 2kt+1; every wave waits
 // vmcnt((NS-3)*DPW) for its pieces of tile kt+1 in L(2kt) = L1 of tile kt-1, which both groups finish before barrier 2kt+1.
+// A/B REFERENCE ONLY: compiled into tests/native/bd_harness (-DBD_AB_VARIANTS), never into libbitdelta_hip.so.
 #pragma once
-#include "bd_gemm_mfma.h"
+#include "../../../bitdelta_amd/csrc/bd_gemm_mfma.h"
 
 namespace bd {
 

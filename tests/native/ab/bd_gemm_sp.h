@@ -9,8 +9,9 @@
 // Ring safety (NS slots): the barrier at step 2 of tile kt is passed only after every wave finished step 3 of tile kt-1,
 // i.e. all reads of tile kt-1's slot have been consumed; refills of that slot (tile kt+NS-1) are issued after it.  Before the
 // barrier every wave waits vmcnt((NS-3)*DPW) = its own pieces of tile kt+1, whose first read (the sign words) follows it.
+// A/B REFERENCE ONLY: compiled into tests/native/bd_harness (-DBD_AB_VARIANTS), never into libbitdelta_hip.so.
 #pragma once
-#include "bd_gemm_mfma.h"
+#include "../../../bitdelta_amd/csrc/bd_gemm_mfma.h"
 
 namespace bd {
 

@@ -15,8 +15,8 @@
 #include <vector>
 
 #include "../../bitdelta_amd/csrc/bd_gemm_mfma.h"
-#include "../../bitdelta_amd/csrc/bd_gemm_pp.h"
-#include "../../bitdelta_amd/csrc/bd_gemm_sp.h"
+#include "ab/bd_gemm_pp.h"
+#include "ab/bd_gemm_sp.h"
 #include "../../bitdelta_amd/csrc/bd_gemm_pf.h"
 #include "../../bitdelta_amd/csrc/bd_gemm_fx.h"
 #include "../../include/bitdelta_hip.h"
@@ -388,6 +388,52 @@ static void bits_bench() {
     hipFree(dbits); hipFree(dbits2); hipFree(dwords); hipFree(dW); hipFree(dF); hipFree(dcoeff); hipFree(dws);
 }
 
+// Decode timing with COLD weights: the same problem over `nset` device copies of W and P (nset * bytes > 2 x the 256 MB Infinity
+// Cache), launched round-robin, so every launch streams its weights from HBM as a decode step of a real model does.  (run_case's
+// loop re-reads one 46 MB problem from the Infinity Cache and flatters HBM-bound kernels.)  Prints warm and cold us per launch.
+static int run_decode_cold(const char* tag, int B, int M, int N, int K, int dt, int fused, int variant, int iters) {
+    Problem q{B, M, N, K, dt, dt, fused, B};
+    make_problem(q);
+    bd_set_gemm_variant(variant);
+    int rc = call_api(q, 0);
+    hipError_t herr = hipDeviceSynchronize();
+    const int used = bd_last_gemm_variant();
+    int bad = -1;
+    double max_err = 0, max_ulp = 0;
+    if (rc == 0 && herr == hipSuccess) {
+        std::vector<uint8_t> hC(q.c_elems() * 2);
+        HIPCHECK(hipMemcpy(hC.data(), q.dC, hC.size(), hipMemcpyDeviceToHost));
+        bad = check_output(q, hC.data(), 2048, &max_err, &max_ulp);
+    }
+    const double wbytes = fused ? 2.0 * N * K : 0.0, pbytes = (double)B * K * N / 8;
+    const double bytes = 2.0 * B * M * K + pbytes + 2.0 * B * M * N + wbytes;
+    int nset = (int)(600e6 / (wbytes + pbytes)) + 1;
+    if (nset < 2) nset = 2;
+    if (nset > 24) nset = 24;
+    std::vector<void*> Ws(nset, nullptr), Ps(nset, nullptr);
+    for (int i = 0; i < nset; ++i) {
+        if (fused) { HIPCHECK(hipMalloc(&Ws[i], (size_t)wbytes)); HIPCHECK(hipMemcpy(Ws[i], q.dW, (size_t)wbytes, hipMemcpyDeviceToDevice)); }
+        HIPCHECK(hipMalloc(&Ps[i], (size_t)pbytes)); HIPCHECK(hipMemcpy(Ps[i], q.dP, (size_t)pbytes, hipMemcpyDeviceToDevice));
+    }
+    double warm = 0, cold = 0;
+    if (rc == 0 && herr == hipSuccess && bad == 0) {
+        warm = time_ms([&] { call_api(q, 0); }, 5, iters) * 1e3;
+        int idx = 0;
+        Problem c = q;
+        cold = time_ms([&] { c.dW = Ws[idx]; c.dP = Ps[idx]; idx = (idx + 1) % nset; call_api(c, 0); }, nset, iters) * 1e3;
+    }
+    printf("{\"tag\":\"%s\",\"B\":%d,\"M\":%d,\"N\":%d,\"K\":%d,\"dt\":\"%s\",\"fused\":%d,\"variant\":%d,\"used\":%d,\"rc\":%d,"
+           "\"bad\":%d,\"max_ulp\":%.3g,\"MB\":%.1f,\"nset\":%d,\"warm_us\":%.2f,\"warm_gbps\":%.0f,\"cold_us\":%.2f,\"cold_gbps\":%.0f}\n",
+           tag, B, M, N, K, dtn(dt), fused, variant, used, rc, bad, max_ulp, bytes * 1e-6, nset, warm, warm > 0 ? bytes / warm * 1e-3 : 0.0,
+           cold, cold > 0 ? bytes / cold * 1e-3 : 0.0);
+    fflush(stdout);
+    bd_set_gemm_variant(-1);
+    for (int i = 0; i < nset; ++i) { if (Ws[i]) hipFree(Ws[i]); hipFree(Ps[i]); }
+    free_problem(q);
+    if (herr != hipSuccess) exit(3);
+    return (rc != 0 || bad != 0) ? 1 : 0;
+}
+
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "check";
     hipDeviceProp_t prop;
@@ -558,6 +604,33 @@ int main(int argc, char** argv) {
                 fails += run_case(tg, 4, 4, 4096, 4096, BD_BF16, BD_BF16, 1, 4, 500, 50, 2048);
             }
         bd_set_decode_small_lut(-1); bd_set_decode_generic_loop(0);
+    } else if (mode == "dec600") {
+        // streaming decode kernel (600, the automatic choice) vs the round-1 kernels (300 wave-specialised VALU, 500 one-launch col16),
+        // warm (Infinity-Cache resident) and cold (HBM) weights.  argv[2] = "quick" -> headline shapes only
+        const bool quick = argc > 2 && std::string(argv[2]) == "quick";
+        for (int v : {600, 300, 500}) {
+            for (int T : {1, 4, 6, 8}) {
+                if (quick && T != 6 && T != 1) continue;
+                fails += run_decode_cold("dec_4096sq", T, 1, 4096, 4096, BD_F16, 1, v, 200);
+                if (!quick) fails += run_decode_cold("dec_4096sq_delta", T, 1, 4096, 4096, BD_F16, 0, v, 200);
+            }
+            fails += run_decode_cold("dec_qkv6144", 6, 1, 6144, 4096, BD_F16, 1, v, 200);
+            fails += run_decode_cold("dec_gateup28672", 6, 1, 28672, 4096, BD_F16, 1, v, 100);
+            fails += run_decode_cold("dec_down14336", 6, 1, 4096, 14336, BD_F16, 1, v, 100);
+            if (!quick) {
+                fails += run_decode_cold("dec_gate14336", 6, 1, 14336, 4096, BD_F16, 1, v, 100);
+                fails += run_decode_cold("dec_kv1024", 6, 1, 1024, 4096, BD_F16, 1, v, 200);
+                fails += run_decode_cold("dec_gate11008", 1, 1, 11008, 4096, BD_BF16, 1, v, 100);
+                fails += run_decode_cold("dec_m4_t4", 4, 4, 4096, 4096, BD_BF16, 1, v, 200);
+                fails += run_decode_cold("dec_70b_gateup_shard", 1, 1, 7168, 8192, BD_BF16, 1, v, 100);
+            }
+        }
+    } else if (mode == "dec600_pmc") {
+        // few launches of the headline decode shapes for rocprofv3 --kernel-trace / --pmc passes
+        for (int v : {600, 500, 300})
+            for (int T : {1, 6}) fails += run_decode_cold("pmc_4096sq", T, 1, 4096, 4096, BD_F16, 1, v, 20);
+        fails += run_decode_cold("pmc_gateup28672", 6, 1, 28672, 4096, BD_F16, 1, 600, 20);
+        fails += run_decode_cold("pmc_down14336", 6, 1, 4096, 14336, BD_F16, 1, 600, 20);
     } else if (mode == "notebook") {
         // the shapes the reference's notebook publishes (fp16, FLOP = 2*B*M*N*K, delta-only kernels)
         for (int NK : {4096, 8192}) {

@@ -5,7 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
-#include "../../bitdelta_amd/csrc/bd_gemm_pp.h"
+#include "ab/bd_gemm_pp.h"
 #include "../../bitdelta_amd/csrc/bd_gemm_pf.h"
 using namespace bd;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("hip error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(2);} } while (0)

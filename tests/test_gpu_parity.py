@@ -168,7 +168,7 @@ SHAPES = [
     (16, 128, 512, 1024, 16, None),                                                    # notebook check shape (ipynb:519-531)
     (1, 512, 512, 512, 1, None),                                                       # notebook 2-D check (ipynb:281-292)
     (2, 200, 256, 520, 2, 0), (2, 200, 256, 520, 2, 1), (2, 200, 256, 520, 2, 2), (2, 200, 256, 520, 2, 3),
-    (2, 200, 256, 520, 2, 4), (2, 200, 256, 520, 2, 5), (2, 200, 256, 520, 2, 6), (2, 200, 256, 520, 2, 7), (2, 200, 256, 520, 2, 100),
+    (2, 200, 256, 520, 2, 5), (2, 200, 256, 520, 2, 100),        # (4 / 6 / 7: rejected schedules, harness-only build)
     (3, 130, 128, 300, 1, 0),                                                          # broadcast mask
     (1, 70, 64, 77, 1, None),                                                          # odd N
     (6, 1, 1024, 1000, 6, None), (3, 2, 512, 512, 3, None), (16, 1, 2048, 256, 1, None), (1, 1, 4096, 4096, 1, None),  # decode
@@ -179,6 +179,11 @@ SHAPES = [
     (6, 1, 1024, 1000, 6, 400), (3, 2, 512, 512, 1, 400), (4, 4, 160, 200, 4, 400), (5, 1, 1536, 300, 5, 403),   # forced: MFMA + LUT decode kernel
     (6, 1, 1024, 1000, 6, 500), (3, 2, 512, 512, 1, 500), (4, 4, 160, 200, 4, 500), (5, 1, 1536, 300, 5, 503),   # forced: no-split-k 16-column kernel
     (16, 1, 8192, 72, 16, 500), (1, 16, 512, 300, 1, 500), (40, 1, 256, 200, 40, 500),
+    # forced: streaming decode kernel (600 + columns-per-block / 4).  Ragged N, K % 128 != 0, K < 1024 (waves with an empty k range),
+    # M > 1, a broadcast mask shared by 16 rows, 8 masks, several 16-column tiles per block (640: 160 columns), 4-column blocks (601)
+    (6, 1, 1024, 1000, 6, 600), (3, 2, 512, 512, 1, 600), (4, 4, 160, 520, 4, 600), (5, 1, 1536, 700, 5, 601),
+    (8, 1, 2048, 1024, 8, 600), (1, 16, 512, 600, 1, 600), (6, 1, 1184, 1000, 6, 640), (2, 1, 4096, 1040, 2, 610),
+    (1, 1, 4096, 4096, 1, 600), (3, 1, 8192, 520, 3, 603), (6, 2, 2176, 777, 6, 605),
 ]
 
 
@@ -208,7 +213,9 @@ def test_delta_bmm_vs_oracle(bd, oracle, dtype, shape):
 
 
 # the one-pass fused kernel (variant 8, bd_binary_linear only): multi-tenant, ragged M/N, k shorter than its 3-slot ring
-LINEAR_SHAPES = SHAPES + [(2, 200, 256, 520, 2, 8), (1, 257, 64, 136, 1, 8), (3, 300, 128, 264, 1, 8), (1, 512, 1024, 384, 1, 8),
+# fused launches: forced 0 / 5 are the two-loop A/B references (harness-only build) -> the shipped library refuses them (tested below)
+LINEAR_SHAPES = [sh for sh in SHAPES if not (sh[5] in (0, 5))] + [(3, 130, 128, 300, 1, None),
+                          (2, 200, 256, 520, 2, 8), (1, 257, 64, 136, 1, 8), (3, 300, 128, 264, 1, 8), (1, 512, 1024, 384, 1, 8),
                           (2, 200, 256, 520, 2, 9), (1, 257, 64, 136, 1, 9), (3, 300, 128, 264, 1, 9), (1, 512, 1024, 384, 1, 9),   # 9 = 128x128 tile
                           (2, 200, 256, 520, 2, 10), (1, 128, 512, 384, 1, 10), (1, 40, 1024, 264, 1, None), (3, 33, 2048, 1024, 3, None),  # split-k (mid M)
                           (1, 96, 4096, 1024, 1, None)]
@@ -240,6 +247,23 @@ def test_binary_linear_vs_oracle(bd, oracle, dtype, shape):
     assert fro16 <= relerr(ref_chain, ref32)[0] * 1.05 + 1e-7
 
 
+def test_pruned_ab_variants_are_refused_not_silently_replaced(bd):
+    """The shipped library holds only dispatched kernels; a forced A/B-only variant answers BD_E_BAD_SHAPE, never a fallback."""
+    from bitdelta_amd import _lib
+    L = _lib.lib()
+    a, p, w, alpha = rand_problem(1, 200, 256, 520, torch.bfloat16, 1, seed=3)
+    for variant, fused in ((4, False), (6, False), (7, True), (0, True), (5, True)):
+        L.bd_set_gemm_variant(variant)
+        try:
+            with pytest.raises(_lib.BitDeltaHipError):
+                if fused:
+                    bd.binary_linear(dev(a), dev(w), dev(p), dev(alpha))
+                else:
+                    bd.delta_bmm(dev(a), dev(p))
+        finally:
+            L.bd_set_gemm_variant(-1)
+
+
 def test_decode_in_launch_reduction_matches_two_launch_form(bd):
     """Split-k partials are summed in k-slice order by whichever block arrives last (ticket) -- bit-identical to the two-launch
     reduce kernel, on every repeat (the ticket area of the persistent workspace is handed back zeroed)."""
@@ -248,15 +272,17 @@ def test_decode_in_launch_reduction_matches_two_launch_form(bd):
     a, p, w, alpha = rand_problem(6, 1, 4096, 1024, torch.float16, 6, seed=21)
     a, p, w, alpha = dev(a), dev(p), dev(w), dev(alpha)
     try:
+        L.bd_set_gemm_variant(300)             # the split-k VALU decode kernel (the automatic choice here is the streaming kernel)
         L.bd_set_decode_two_launch(1)
         ref = bd.binary_linear(a, w, p, alpha).clone()
         L.bd_set_decode_two_launch(0)
         for _ in range(5):
             got = bd.binary_linear(a, w, p, alpha)
-            assert L.bd_last_gemm_variant() == 200
+            assert L.bd_last_gemm_variant() == 300
             assert torch.equal(got, ref)
     finally:
         L.bd_set_decode_two_launch(1)          # library default
+        L.bd_set_gemm_variant(-1)
 
 
 def test_delta_bmm_alpha_accumulate_and_groups(bd, oracle):
@@ -274,6 +300,32 @@ def test_delta_bmm_alpha_accumulate_and_groups(bd, oracle):
     assert relerr(y.cpu(), yo)[0] <= 1e-5
     z = bd.delta_bmm(dev(a), dev(p), alpha=dev(alpha), groups=4, out_dtype=torch.float32)
     assert relerr(z.cpu(), scale * ref)[0] <= 1e-5
+
+
+def test_decode_stream_kernel_groups_accumulate_and_determinism(bd, oracle):
+    """Streaming decode kernel: several scale groups inside one block's column range (scales come from its LDS table), the
+    `C += alpha * acc` epilogue, and run-to-run determinism (fixed wave-order reduction, no atomics)."""
+    from bitdelta_amd import _lib
+    L = _lib.lib()
+    a, p, w, _ = rand_problem(3, 2, 640, 1024, torch.float16, 3, seed=31)
+    alpha = (torch.rand(3, 8) * 4e-4 + 2e-4).float()                    # 8 groups of 128 columns
+    for variant in (640, 601):                                          # 160-column blocks span two groups; 4-column blocks one
+        L.bd_set_gemm_variant(variant)
+        try:
+            y = bd.binary_linear(dev(a), dev(w), dev(p), dev(alpha), groups=8, out_dtype=torch.float32)
+            assert L.bd_last_gemm_variant() == 600
+            y2 = bd.binary_linear(dev(a), dev(w), dev(p), dev(alpha), groups=8, out_dtype=torch.float32)
+            base = (a.float() @ w.float().T).half()
+            out = dev(base.clone())
+            bd.delta_bmm(dev(a), dev(p), out=out, alpha=dev(alpha), accumulate=True, groups=8)
+        finally:
+            L.bd_set_gemm_variant(-1)
+        assert torch.equal(y, y2)
+        yo = oracle.binary_linear(a, w, p, alpha, G=8, out_dtype=torch.float32)
+        assert relerr(y.cpu(), yo)[0] <= 1e-5
+        ref = oracle.delta_bmm(a, p, out_dtype=torch.float32, round_mode=0)
+        want = (base.float() + alpha.repeat_interleave(128, dim=1)[:, None, :] * ref).half()
+        assert ulp_diff(out.cpu(), want).max().item() <= 1
 
 
 # ------------------------------------------------------------------ module forward / multi-tenant
