@@ -3,16 +3,22 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-Workload (BASELINE.json configs[1]): Llama-2-7B base + one 1-bit delta (Vicuna-7B-v1.5 shapes), prefill of one
-2048-token sequence per GPU, synthetic weights/activations (SURVEY.md 8d recipe).  A "step" is one full prefill
-forward: 32 layers x 7 fused BinaryDiff projections (the hot path, hand-written HIP) + attention/norm/embedding/lm_head
-(stock torch, the callers of the path).  N GPUs = N independent replicas (weak scaling, no data-path collective).
+Workload of `value` (BASELINE.json configs[1]): Llama-2-7B base + one 1-bit delta (Vicuna-7B-v1.5 shapes), prefill of one
+2048-token sequence per GPU, synthetic weights/activations (SURVEY.md 8d recipe).  A "step" is one full prefill forward:
+32 layers x 7 fused BinaryDiff projections (the hot path, hand-written HIP) + attention/norm/embedding/lm_head (stock torch,
+the callers of the path).  N GPUs = N independent replicas (weak scaling, no data-path collective).
 
 Prints ONE JSON line (rank 0) with the driver contract fields plus
-  roofline      the dominant kernel (fused base+delta MFMA GEMM): algorithmic FLOPs of its launches / their summed
-                durations, measured live with HIP events on the launch stream inside the timed region
+  roofline      the dominant kernel (fused base+delta MFMA GEMM): algorithmic FLOPs of its launches / their summed durations,
+                measured live with HIP events on the launch stream inside the timed region.  `traffic` is null unless THIS run
+                measured it (PMC counters cannot be read in-process; the rocprofv3 passes live under profiles/)
   delta_gemm    the W1A16 delta-GEMM alone at 4096x4096, M = 4096 (the north star's 70 %-of-peak target), same method
-  cpu_baseline  the reference's CPU-executable form of the same projections (oracle/torch_port.py), bounded sample
+  mt_decode     BASELINE.json configs[2] in the same run: Mistral-7B base + 6 tenant deltas, batched greedy decode through the
+                serving loop (fused q+k+v / gate+up launches, per-tenant embedding / norms / lm_head, argmax feedback, KV cache),
+                eager and as a hipGraph replay; HBM roofline of its Linear launches
+  cpu_baseline  the reference's CPU-executable form of the same projections (oracle/torch_port.py) on all host cores: variant 1
+                (unpack inside the timed region) and variant 2 (pre-unpacked torch.matmul), bounded sample
+Other workloads: --workload mt-decode (configs[2] / [4] as the main line), --workload tp70b (configs[3], needs --gpus 8).
 """
 import argparse
 import json
@@ -42,6 +48,7 @@ class LaunchTimer:
         import bitdelta_amd.binary_gemm_kernel as k
         import bitdelta_amd.diff as d
         import bitdelta_amd.serving as s
+        import bitdelta_amd.serving_loop as sl
         orig = k.binary_linear
         timer = self
 
@@ -57,7 +64,10 @@ class LaunchTimer:
             nbytes = 2.0 * B * M * K + 2.0 * N * K + mask.shape[0] * K * N / 8.0 + 4.0 * mask.shape[0] + 2.0 * B * M * N
             timer.records.append((e0, e1, 4.0 * B * M * K * N, nbytes))
             return y
-        k.binary_linear = d.binary_linear = s.binary_linear = timed
+        k.binary_linear = d.binary_linear = s.binary_linear = sl.binary_linear = timed
+
+    def reset(self):
+        self.records = []
 
     def summary(self):
         ms = sum(a.elapsed_time(b) for a, b, _, _ in self.records)
@@ -67,9 +77,13 @@ class LaunchTimer:
 
 
 def cpu_baseline(seq=128):
-    """Reference-equivalent CPU path (oracle/torch_port.py) for ONE decoder layer's 7 projections (Llama-2-7B shapes) at
-    `seq` tokens, all host threads; extrapolated x32 layers to tokens/s.  Attention/norms are excluded (GPU side: <5 %)."""
+    """Reference-equivalent CPU path (oracle/torch_port.py) for ONE decoder layer's 7 projections (Llama-2-7B shapes) at `seq`
+    tokens on ALL host threads (torch.set_num_threads(os.cpu_count())), extrapolated x32 layers to tokens/s.
+    Variant 1 unpacks the masks inside the timed region (what a CPU run of the reference does); variant 2 is the pure
+    torch.matmul baseline with pre-unpacked signs.  Attention/norms are excluded (GPU side: < 5 % of the step)."""
     from oracle import torch_port as tp
+    ncpu = os.cpu_count() or 1
+    torch.set_num_threads(ncpu)
     torch.manual_seed(0)
     hid, inter = 4096, 11008
     shapes = [(hid, hid)] * 4 + [(inter, hid)] * 2 + [(hid, inter)]
@@ -79,18 +93,28 @@ def cpu_baseline(seq=128):
         mask = torch.randint(-2 ** 31, 2 ** 31 - 1, (n_in // 32, n_out), dtype=torch.int64).to(torch.int32)
         layers.append((w, mask, torch.tensor(4e-4)))
     xs = {n_in: torch.randn(1, seq, n_in).bfloat16() for n_in in (hid, inter)}
-    def one_layer():
+
+    def timeit(fn, budget):
+        fn()                                   # warm-up
+        t0 = time.perf_counter()
+        reps = 0
+        while reps < 3 or time.perf_counter() - t0 < budget:
+            fn()
+            reps += 1
+            if time.perf_counter() - t0 > 2.5 * budget:
+                break
+        return (time.perf_counter() - t0) / reps, reps
+
+    def v1():
         for w, mask, c in layers:
             tp.forward_unpack_in_loop(xs[w.shape[1]], w, mask, c)
-    one_layer()                                   # warm-up
-    t0 = time.perf_counter()
-    reps = 0
-    while reps < 3 or time.perf_counter() - t0 < 10.0:
-        one_layer()
-        reps += 1
-        if time.perf_counter() - t0 > 30.0:
-            break
-    t = (time.perf_counter() - t0) / reps
+    t1, r1 = timeit(v1, 8.0)
+    signs = [(tp.unpack32(mask) * 2 - 1).to(torch.bfloat16) for _, mask, _ in layers]
+
+    def v2():
+        for (w, _, c), s in zip(layers, signs):
+            tp.forward_preunpacked(xs[w.shape[1]], w, s, c)
+    t2, r2 = timeit(v2, 4.0)
     cpu = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -99,10 +123,13 @@ def cpu_baseline(seq=128):
                 break
     except OSError:
         pass
-    return {"value": seq / (32 * t), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 of 32 decoder layers' 7 BinaryDiff projections (Llama-2-7B shapes) at seq {seq}, unpack inside the "
-                      f"timed region (BASELINE.md 3, variant 1), {reps} reps x {t * 1e3:.0f} ms, extrapolated x32 layers; "
-                      f"host: {cpu}, os.cpu_count()={os.cpu_count()}"}
+    return {"value": seq / (32 * t1), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "matmul_only": {"value": seq / (32 * t2), "unit": "tokens/s",
+                            "what": "variant 2 of BASELINE.md 3: pre-unpacked signs, torch.matmul only (x@W.T + coeff*(x@S))",
+                            "reps": r2, "ms_per_layer": t2 * 1e3},
+            "sample": f"1 of 32 decoder layers' 7 BinaryDiff projections (Llama-2-7B shapes) at seq {seq}; value = variant 1 (unpack "
+                      f"inside the timed region, the reference's CPU-executable path), {r1} reps x {t1 * 1e3:.0f} ms, extrapolated x32 "
+                      f"layers; host: {cpu}, os.cpu_count()={ncpu}, torch threads={torch.get_num_threads()}, torch {torch.__version__}"}
 
 
 def delta_gemm_microbench(dev, M=4096, N=4096, K=4096, iters=30):
@@ -129,20 +156,92 @@ def delta_gemm_microbench(dev, M=4096, N=4096, K=4096, iters=30):
             "bytes_per_launch": 2.0 * M * K + K * N / 8 + 2.0 * M * N}
 
 
+def run_mt_decode(dev, timer, model_name, tenants, kv_len, steps, warmup, layers=None, seed=4321):
+    """configs[2] / [4]: one base + `tenants` 1-bit deltas, greedy decode steps at cache length ~kv_len through the serving loop.
+    Returns a dict of eager / hipGraph step times and the HBM roofline of the Linear launches."""
+    from bitdelta_amd import dist as bdd
+    from bitdelta_amd.serving_loop import TenantDecoder
+    dec = TenantDecoder.synthetic(model_name, tenants, dev, dtype=torch.float16, seed=seed, layers=layers,
+                                  max_len=kv_len + steps + warmup + 16)
+    vocab = dec.cfg[5]
+    g = torch.Generator().manual_seed(seed)
+    prompts = [torch.randint(1, vocab, (kv_len,), generator=g).tolist() for _ in range(tenants)]
+    ids, am = dec.prepare(prompts)                       # kv_len is a power of two >= 64: no padding
+    cache = dec.new_cache()
+    logits = dec.prefill(ids, am, cache)
+    first = torch.argmax(logits, dim=-1)
+    L = ids.shape[1]
+    st = {"cache": cache, "tok": first[:, None].clone(), "pos": torch.tensor([L], device=dev),
+          "step": torch.tensor([1], device=dev), "stop_ids": torch.full((tenants, 1), -1, dtype=torch.long, device=dev),
+          "out": torch.zeros(tenants, steps * 2 + warmup * 2 + 8, dtype=torch.long, device=dev),
+          "stopped": torch.zeros(tenants, dtype=torch.bool, device=dev)}
+    snap = {k: v.clone() for k, v in st.items() if torch.is_tensor(v)}
+    valid0 = cache["valid"].clone()
+
+    def restore():
+        for k, v in snap.items():
+            st[k].copy_(v)
+        cache["valid"].copy_(valid0)
+
+    for _ in range(warmup):
+        dec._decode_step(st)
+    timer.reset()
+    timer.enabled = True
+    eager_s = bdd.timed_region(lambda: dec._decode_step(st), steps, device_sync=torch.cuda.synchronize)
+    timer.enabled = False
+    torch.cuda.synchronize()
+    n_launch, k_ms, _, k_bytes = timer.summary()
+    restore()
+    graph_ms, graph_err = None, None
+    try:
+        replay = dec._graph_runner(st)
+        for _ in range(warmup):
+            replay()
+        restore()
+        graph_s = bdd.timed_region(replay, steps, device_sync=torch.cuda.synchronize)
+        graph_ms = graph_s / steps * 1e3
+    except Exception as e:          # report, never hide
+        graph_err = f"{type(e).__name__}: {e}"
+    lin_bytes, head_bytes = dec.linear_bytes_per_step()
+    best_ms = graph_ms if graph_ms is not None else eager_s / steps * 1e3
+    out = {
+        "workload": f"{model_name} base + {tenants} tenant deltas, greedy decode at kv length {kv_len}, one token per tenant per step; "
+                    f"{len(dec.layers)} layers x 4 fused delta-Linear launches (q+k+v, o, gate+up, down) + per-tenant embedding / "
+                    "norms / lm_head; argmax fed back on the device",
+        "tenants": tenants, "steps": steps, "valid": layers is None,
+        "eager_ms_per_step": eager_s / steps * 1e3, "hipgraph_ms_per_step": graph_ms, "hipgraph_error": graph_err,
+        "tokens_per_s": tenants / (best_ms * 1e-3),
+        "delta_linear_bytes_per_step": lin_bytes, "lm_head_bytes_per_step": head_bytes,
+        "delta_linear_launches": n_launch, "delta_linear_ms_total_eager": k_ms,
+        # event-timed Linear launches of the eager loop: algorithmic bytes / their summed durations
+        "linear_gbs": k_bytes / k_ms * 1e-6 if k_ms > 0 else None,
+        "linear_frac_of_hbm_peak": (k_bytes / k_ms * 1e-6 / PEAK_HBM_GBS) if k_ms > 0 else None,
+        # the whole step against the bytes its Linears must stream (everything else counted as overhead)
+        "step_gbs": (lin_bytes + head_bytes) / (best_ms * 1e-3) * 1e-9,
+        "step_frac_of_hbm_peak": (lin_bytes + head_bytes) / (best_ms * 1e-3) * 1e-9 / PEAK_HBM_GBS,
+        "peak_gbs": PEAK_HBM_GBS,
+    }
+    del dec, cache, st
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="prefill", choices=["prefill", "mt-decode"],
-                    help="prefill = BASELINE configs[1] (default, the bench line the driver records); mt-decode = configs[2]: "
-                         "Mistral-7B base + T tenant deltas, batched decode steps (HBM-bound), reported for DESIGN.md")
+    ap.add_argument("--workload", default="prefill", choices=["prefill", "mt-decode", "tp70b"],
+                    help="prefill = BASELINE configs[1] (default, the bench line the driver records; carries mt_decode as an extra key); "
+                         "mt-decode = configs[2] / [4]: Mistral-7B base + T tenant deltas per GPU, batched greedy decode; "
+                         "tp70b = configs[3]: Llama-2-70B shapes, tensor parallel over all ranks, RCCL all-reduce")
     ap.add_argument("--model", default=None)
-    ap.add_argument("--tenants", type=int, default=6)
+    ap.add_argument("--tenants", type=int, default=None)
     ap.add_argument("--kv-len", type=int, default=512)
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result is then marked invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mt-decode", action="store_true", help="skip the configs[2] leg of the default run")
     args = ap.parse_args()
 
     from bitdelta_amd import dist as bdd
@@ -155,35 +254,46 @@ def main():
 
     from bitdelta_amd import _lib
     _lib.lib()                                   # fail loudly if the HIP library is missing
-    from bench_model import Decoder
-
     timer = LaunchTimer()
     timer.install()
-    decode = args.workload == "mt-decode"
-    args.model = args.model or ("mistral-7b" if decode else "llama-2-7b")
-    if decode:
-        T = len(bdd.tenants_for_rank(args.tenants * world, rank, world))      # tenants are partitioned across ranks
-        model = Decoder(args.model, dev, dtype=torch.float16, tenants=T, layers=args.layers, seed=1234 + rank)
-        cache = model.new_cache(T, args.kv_len + args.steps + args.warmup + 8)
-        model(torch.randint(0, model.cfg[5], (T, args.kv_len), device=dev), pos0=0, cache=cache)     # prefill the cache
-        tok = torch.randint(0, model.cfg[5], (T, 1), device=dev)
-        pos = [args.kv_len]
 
-        def step():
-            out = model(tok, pos0=pos[0], cache=cache)
-            pos[0] += 1
-            return out
+    if args.workload == "tp70b":
+        from bitdelta_amd.tp import bench_tp70b
+        out = bench_tp70b(args, dev, rank, world, timer)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        return
 
-        def step_fixed():           # same work at a fixed position (static shapes): what the hipGraph replays
-            for c in cache:
-                c[2] = args.kv_len
-            return model(tok, pos0=args.kv_len, cache=cache)
-    else:
-        model = Decoder(args.model, dev, layers=args.layers, seed=1234 + rank)
-        ids = torch.randint(0, model.cfg[5], (1, args.seq), device=dev)
+    if args.workload == "mt-decode":
+        tenants = args.tenants or 6
+        model = args.model or "mistral-7b"
+        d = run_mt_decode(dev, timer, model, tenants, args.kv_len, args.steps, args.warmup, layers=args.layers, seed=4321 + rank)
+        ms = d["hipgraph_ms_per_step"] or d["eager_ms_per_step"]      # already the MAX over ranks (dist.timed_region)
+        if rank != 0:
+            return
+        out = {
+            "metric": "multi-tenant batched decode tokens/s (BASELINE.json configs[2] / configs[4]: Mistral-7B base + T 1-bit deltas per GPU)",
+            "value": tenants * world / (ms * 1e-3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": d["workload"], "tenants_per_gpu": tenants,
+                       "parallelism": f"tenants partitioned over {world} rank(s) ({tenants} per GPU), base replicated, no collective",
+                       "valid": args.layers is None},
+            "roofline": {"bound": "hbm", "achieved": d["linear_gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": d["linear_frac_of_hbm_peak"], "traffic": None,
+                         "kernel": "bd::gemv_stream_kernel via bd_binary_linear (event-timed in the eager loop)",
+                         "launches": d["delta_linear_launches"], "step_frac_of_hbm_peak": d["step_frac_of_hbm_peak"]},
+            "mt_decode": d,
+        }
+        print(json.dumps(out), flush=True)
+        return
 
-        def step():
-            return model(ids)
+    from bench_model import Decoder
+    args.model = args.model or "llama-2-7b"
+    model = Decoder(args.model, dev, layers=args.layers, seed=1234 + rank)
+    ids = torch.randint(0, model.cfg[5], (1, args.seq), device=dev)
+
+    def step():
+        return model(ids)
 
     for _ in range(args.warmup):
         step()
@@ -192,66 +302,16 @@ def main():
     timer.enabled = False
     torch.cuda.synchronize()
     n_launch, k_ms, k_flops, k_bytes = timer.summary()
-
-    tokens = (args.tenants if decode else args.seq) * args.steps * world
+    tokens = args.seq * args.steps * world
     value = tokens / dt
-    graph_ms = None
-    if decode:
-        # launch-bound loop -> hipGraph: capture one decode step (448 kernel launches + glue) and replay it
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    step_fixed()
-            torch.cuda.current_stream().wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                step_fixed()
-            for _ in range(3):
-                g.replay()
-            graph_s = bdd.timed_region(g.replay, args.steps, device_sync=torch.cuda.synchronize)
-            graph_ms = graph_s / args.steps * 1e3
-        except Exception as e:          # report, never hide
-            graph_ms = f"capture failed: {type(e).__name__}: {e}"
+    n_layers = len(model.layers)
+    lin_params = model.linear_param_count()
+    del model
+    torch.cuda.empty_cache()
     if rank != 0:
-        return
-    if decode:
-        gbs = k_bytes / k_ms * 1e-6 if k_ms > 0 else 0.0
-        out = {
-            "metric": "multi-tenant batched decode tokens/s (BASELINE.json configs[2]: Mistral-7B base + T 1-bit deltas)",
-            "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"{args.model} base + {args.tenants} tenant deltas per GPU, decode step at kv length "
-                                   f"{args.kv_len}, one token per tenant; {len(model.layers)} layers x 7 fused DiffCompressModule "
-                                   "projections", "tenants_per_gpu": args.tenants, "parallelism": f"tenants partitioned over {world} rank(s), base replicated, no collective",
-                       "valid": args.layers is None},
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                         "traffic": None, "kernel": "bd::gemv_kernel (+ gemv_reduce_kernel) via bd_binary_linear",
-                         "launches": n_launch, "kernel_ms_total": k_ms, "algorithmic_bytes_total": k_bytes,
-                         "share_of_step_time": (k_ms / 1e3) / dt if dt > 0 else None},
-            "eager_ms_per_step": dt / args.steps * 1e3,
-            "hipgraph_ms_per_step": graph_ms,
-        }
-        if isinstance(graph_ms, float):        # the graph replay is the serving-relevant number: value reports it
-            out["value"] = args.tenants * world / (graph_ms * 1e-3)
-            out["ms_per_step"] = graph_ms
-            lin_bytes = k_bytes / args.steps
-            out["roofline"]["step_linear_bytes"] = lin_bytes
-            out["roofline"]["whole_step_gbs_if_only_linears"] = lin_bytes / (graph_ms * 1e-3) * 1e-9
-        if rank == 0:
-            print(json.dumps(out), flush=True)
         return
     mb = delta_gemm_microbench(dev)
     achieved = k_flops / k_ms * 1e-9 if k_ms > 0 else 0.0
-    traffic = None
-    try:    # PMC counters cannot be read from inside the process: the per-launch figure comes from the committed rocprofv3 passes
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        traffic = tj["fused_gemm"]["traffic_bytes_per_launch"]
-        mb["traffic_bytes_per_launch"] = tj["delta_gemm_4096"]["traffic_bytes_per_launch"]
-    except Exception:
-        pass
     out = {
         "metric": "W1A16 binary-delta GEMM TFLOP/s + tokens/s, Llama-2-7B+Vicuna delta, 1/2/4/8 MI355X "
                   "(value = end-to-end prefill tokens/s; delta_gemm.tflops = the GEMM figure)",
@@ -259,24 +319,28 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{args.model} base + one 1-bit delta, prefill seq {args.seq}, batch 1 per GPU "
-                               f"(BASELINE.json configs[1]); {len(model.layers)} layers x 7 fused BinaryDiff projections",
+                               f"(BASELINE.json configs[1]); {n_layers} layers x 7 fused BinaryDiff projections",
                    "seq_len": args.seq, "global_batch": world, "parallelism": f"dp{world} independent replicas, no collective",
                    "valid": args.layers is None},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
-                     "traffic_note": "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes "
-                                     "(profiles/r01_traffic.json); algorithmic bytes per launch = algorithmic_bytes_total / launches",
+                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                     "traffic_note": "not measured by this run (PMC counters need a rocprofv3 pass): see profiles/ for the per-launch "
+                                     "FETCH_SIZE / WRITE_SIZE tables; algorithmic bytes per launch = algorithmic_bytes_total / launches",
                      "algorithmic_bytes_total": k_bytes,
                      "kernel": "bd::delta_gemm_fx_kernel<bf16, 256x128 tile> (one-pass fused, two accumulator sets, full-tile ping-pong; x.W^T + alpha*(x.S), 4*M*N*K flop/launch)",
                      "launches": n_launch, "kernel_ms_total": k_ms, "algorithmic_flops_total": k_flops,
                      "share_of_step_time": (k_ms / 1e3) / dt if dt > 0 else None},
         "delta_gemm": mb,
-        "linear_params": model.linear_param_count(),
+        "linear_params": lin_params,
     }
+    if world == 1 and not args.no_mt_decode:
+        try:
+            out["mt_decode"] = run_mt_decode(dev, timer, "mistral-7b", args.tenants or 6, args.kv_len, 20, 3, layers=args.layers)
+        except Exception as e:
+            out["mt_decode"] = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
-    if rank == 0:                       # one JSON line per job (the contract); other ranks only contributed to the MAX time
-        print(json.dumps(out), flush=True)
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -41,6 +41,7 @@ SIGNATURES = {
     "bd_set_decode_two_launch": (_ci, [_ci]),
     "bd_set_decode_wave_spec": (_ci, [_ci]),
     "bd_set_decode_small_lut": (_ci, [_ci]),
+    "bd_set_stream_tuning": (_ci, [_ci]),
     "bd_set_decode_generic_loop": (_ci, [_ci]),
 }
 

@@ -28,6 +28,7 @@ static thread_local int g_gemv_wave_spec = 1;        // 1 = fused launches of th
 static thread_local int g_gemv_two_launch = 1;       // 1 (default) = split-k partials are summed by gemv_reduce_kernel; 0 = in-launch tickets
                                         // (measured slower: the last-arriver tail is serial inside every tile; bd_gemv.h)
 static thread_local int g_gemv_target_blocks = 512;
+static thread_local int g_stream_tune = 0;            // A/B hook (harness build): bit 0 = natural-order W, bit 1 = default cache policy, bit 2 = 4-wave blocks
 static thread_local int t_last_variant = -1;
 
 extern "C" int bd_version(void) { return 1; }
@@ -38,6 +39,7 @@ extern "C" int bd_set_decode_two_launch(int on) { g_gemv_two_launch = on ? 1 : 0
 extern "C" int bd_set_decode_wave_spec(int on) { g_gemv_wave_spec = on ? 1 : 0; return BD_OK; }
 extern "C" int bd_set_launch_chunking(int on) { g_launch_chunking = on ? 1 : 0; return BD_OK; }
 extern "C" int bd_set_decode_generic_loop(int on) { g_col16_no_per4 = on ? 1 : 0; return BD_OK; }
+extern "C" int bd_set_stream_tuning(int flags) { g_stream_tune = flags; return BD_OK; }
 extern "C" int bd_set_decode_small_lut(int mode) { g_col16_small_lut = mode < 0 ? -1 : (mode ? 1 : 0); return BD_OK; }
 
 extern "C" const char* bd_error_string(int code) {
@@ -304,13 +306,35 @@ inline bool stream_ok(const Problem& q, int rows, int nmask) {
     return xb > 0 && xb < lim && wb < lim && pb < lim && q.sAb >= 0 && q.sAm >= 0;
 }
 
-template <int DT, int NM, bool HASW, int NS>
-int launch_stream_inst(const StreamParams& sp, unsigned grid, hipStream_t st) {
-    auto kern = gemv_stream_kernel<DT, NM, HASW, NS>;
+template <int DT, int NM, bool HASW, int NS, int NW = 8, int WNAT = 0, int AUX = 2>
+int launch_stream_inst(const StreamParams& sp, dim3 grid, hipStream_t st) {
+    auto kern = gemv_stream_kernel<DT, NM, HASW, NS, NW, WNAT, AUX>;
     static std::atomic<uint64_t> lds_done{0};
     if (!ensure_dyn_lds((const void*)kern, STREAM_LDS_BYTES, lds_done)) return BD_E_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), STREAM_LDS_BYTES, st, sp);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), STREAM_LDS_BYTES, st, sp);
     return BD_OK;
+}
+
+// NS8 = stages of loads in flight per wave (8-wave blocks); bounded by the 256-VGPR budget of two waves per SIMD.
+// Harness builds (-DBD_AB_VARIANTS) add the A/B matrix selected by bd_set_stream_tuning: bit 0 natural-order W, bit 1 default cache
+// policy, bit 2 4-wave blocks (one wave per SIMD, NS4 stages), bit 3 the deeper of two prefetch depths.
+template <int DT, int NM, bool HASW, int NS8>
+int launch_stream_tuned(const StreamParams& sp, dim3 grid, hipStream_t st) {
+#ifdef BD_AB_VARIANTS
+    if constexpr (DT == DT_F16 && HASW && (NM == 0 || NM == 1 || NM == 6)) {
+        constexpr int A8 = NM == 6 ? 2 : 4, B8 = NM == 6 ? 3 : 6;          // 8-wave blocks: base / deeper
+        constexpr int A4 = NM == 6 ? 4 : 8, B4 = NM == 6 ? 6 : 12;         // 4-wave blocks
+        switch (g_stream_tune & 15) {
+#define BD_T(code, NS, NW, WN, AX) case code: return launch_stream_inst<DT, NM, HASW, NS, NW, WN, AX>(sp, grid, st)
+            BD_T(0, A8, 8, 0, 2); BD_T(1, A8, 8, 1, 2); BD_T(2, A8, 8, 0, 0); BD_T(3, A8, 8, 1, 0);
+            BD_T(4, A4, 4, 0, 2); BD_T(5, A4, 4, 1, 2); BD_T(6, A4, 4, 0, 0); BD_T(7, A4, 4, 1, 0);
+            BD_T(8, B8, 8, 0, 2); BD_T(9, B8, 8, 1, 2); BD_T(10, B8, 8, 0, 0); BD_T(11, B8, 8, 1, 0);
+            BD_T(12, B4, 4, 0, 2); BD_T(13, B4, 4, 1, 2); BD_T(14, B4, 4, 0, 0); BD_T(15, B4, 4, 1, 0);
+#undef BD_T
+        }
+    }
+#endif
+    return launch_stream_inst<DT, NM, HASW, NS8>(sp, grid, st);
 }
 
 template <int DT>
@@ -343,9 +367,10 @@ int launch_gemv_stream_chunk(const Problem& q) {
     sp.p_bytes = (uint32_t)(((int64_t)(nmask - 1) * q.sPb + (int64_t)(q.K / 32) * q.N) * 4);
     int rc;
     // NS = stages of loads in flight per wave; bounded by the 256-VGPR budget of a 2-waves-per-SIMD block (hipcc spills beyond)
-#define BD_STREAM(NM, NS) rc = q.W ? launch_stream_inst<DT, NM, true, NS>(sp, grid, q.st) : launch_stream_inst<DT, NM, false, NS>(sp, grid, q.st)
+#define BD_STREAM(NM, NS8) rc = q.W ? launch_stream_tuned<DT, NM, true, NS8>(sp, dim3(grid), q.st) \
+                                     : launch_stream_tuned<DT, NM, false, NS8>(sp, dim3(grid), q.st)
     if (nmask <= 1) BD_STREAM(1, 4);
-    else if (nmask <= 2) BD_STREAM(2, 3);
+    else if (nmask <= 2) BD_STREAM(2, 4);
     else if (nmask <= 3) BD_STREAM(3, 2);
     else if (nmask <= 4) BD_STREAM(4, 2);
     else if (nmask <= 6) BD_STREAM(6, 2);
@@ -803,16 +828,9 @@ extern "C" int bd_tenant_linear(const void* X, const void* W, void* Y, int T, in
     sp.cpb = cpb;
     dim3 grid((unsigned)((N + cpb - 1) / cpb), (unsigned)T);
     hipStream_t st = (hipStream_t)stream;
-    static std::atomic<uint64_t> done_h{0}, done_b{0};
-    if (dtype == BD_BF16) {
-        auto kern = gemv_stream_kernel<DT_BF16, 0, true, 4>;
-        if (!ensure_dyn_lds((const void*)kern, STREAM_LDS_BYTES, done_b)) return BD_E_LAUNCH;
-        hipLaunchKernelGGL(kern, grid, dim3(512), STREAM_LDS_BYTES, st, sp);
-    } else {
-        auto kern = gemv_stream_kernel<DT_F16, 0, true, 4>;
-        if (!ensure_dyn_lds((const void*)kern, STREAM_LDS_BYTES, done_h)) return BD_E_LAUNCH;
-        hipLaunchKernelGGL(kern, grid, dim3(512), STREAM_LDS_BYTES, st, sp);
-    }
+    const int rc = dtype == BD_BF16 ? launch_stream_tuned<DT_BF16, 0, true, 4>(sp, grid, st)
+                                    : launch_stream_tuned<DT_F16, 0, true, 4>(sp, grid, st);
+    if (rc != BD_OK) return rc;
     return launch_status();
 }
 

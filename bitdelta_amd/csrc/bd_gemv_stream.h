@@ -49,7 +49,7 @@ template <int AUX> __device__ __forceinline__ uint32_t buf_load4(__amdgpu_buffer
 }
 
 constexpr int STREAM_LUT_BYTES = 65536;
-constexpr int STREAM_RED_BYTES = 2 * 8 * 64 * 8 * 4;          // [2 buffers][8 waves][64 lanes][4 base + 4 delta] fp32
+constexpr int STREAM_RED_BYTES = 2 * 8 * 64 * 8 * 4;          // [2 buffers][<= 8 waves][64 lanes][4 base + 4 delta] fp32
 constexpr int STREAM_ALPHA_MAX = 512;                          // (row, scale group) pairs of one block kept in LDS
 constexpr int STREAM_LDS_BYTES = STREAM_LUT_BYTES + STREAM_RED_BYTES + STREAM_ALPHA_MAX * 4;
 constexpr uint32_t STREAM_OOB = 0x80000000u;                   // a byte offset that is out of range for every descriptor (extents are < 2 GiB:
@@ -63,8 +63,15 @@ struct StreamParams {
     long long sXt, sWt, sCt;
 };
 
-template <int DT, int NM, bool HASW, int NS>
-__global__ void __launch_bounds__(512) gemv_stream_kernel(const StreamParams sp) {
+// NW = waves per block (8: two per SIMD, 256 VGPRs each; 4: one per SIMD, the whole register file, deeper prefetch).
+// WNAT = 1: the base weight and its activation fragments use the NATURAL k order -- MFMA step s of lane group g covers
+//   k = 128 it + 32 s + 8 g .. + 7, so one W load instruction reads 16 rows x 64 contiguous bytes (every 64-byte sector fetched by
+//   exactly one instruction); the sign operand keeps the word-row order (a lane's word is 32 consecutive k), which needs its own
+//   activation fragments: x is loaded in both orders (L2 hits).  WNAT = 0: one activation fragment set, W in the word-row order
+//   (each W instruction touches 64 sectors and uses 16 bytes of each; the 4 instructions of a stage complete them).
+// AUX = cache policy of the weight / sign streams (2 = nt, 0 = default).
+template <int DT, int NM, bool HASW, int NS, int NW = 8, int WNAT = 0, int AUX = 2>
+__global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams sp) {
     GemvParams p = sp.g;
     if constexpr (NM == 0) {       // blockIdx.y = tenant: its own activation rows, weight matrix and output rows
         p.X += (long long)blockIdx.y * sp.sXt;
@@ -72,7 +79,8 @@ __global__ void __launch_bounds__(512) gemv_stream_kernel(const StreamParams sp)
         p.C = (char*)p.C + (long long)blockIdx.y * sp.sCt * (p.out_f32 ? 4 : 2);
     }
     constexpr int NMA = NM > 0 ? NM : 1;      // array extent (no zero-length arrays)
-    constexpr int NW = 8;
+    constexpr bool XP = NM > 0 || !(HASW && WNAT);      // activation fragments in word-row order (sign operand; W too unless WNAT)
+    constexpr bool XN = HASW && WNAT;                    // activation fragments in natural order (W operand)
     extern __shared__ __attribute__((aligned(256))) char dyn_lds[];     // [64 KiB sign LUT][32 KiB reduction buffers]
     float* const red = (float*)(dyn_lds + STREAM_LUT_BYTES);
     float* const a_lds = (float*)(dyn_lds + STREAM_LUT_BYTES + STREAM_RED_BYTES);
@@ -104,33 +112,46 @@ __global__ void __launch_bounds__(512) gemv_stream_kernel(const StreamParams sp)
     // BEFORE the stream starts: the oldest entry of the wave's in-order load queue, so waiting for it never drains a weight load.
     // (A load issued at the end of a tile would be the youngest: s_waitcnt vmcnt(0), the whole prefetch lost once per tile.)
     const int g0 = c_lo / p.gsz, ng = (c_hi - 1) / p.gsz - g0 + 1;
-    const bool al_lds = p.alpha != nullptr && p.R * ng <= STREAM_ALPHA_MAX;
+    const bool al_lds = p.alpha != nullptr && p.R * ng <= (STREAM_ALPHA_MAX < 64 * NW ? STREAM_ALPHA_MAX : 64 * NW);
     float a_pre = 0.f;
     if (al_lds) {
         const int idx = min((int)threadIdx.x, p.R * ng - 1), r = idx / ng, j = idx - r * ng;
         a_pre = p.alpha[(long long)(r / p.M) * p.sAlb + g0 + j];
     }
 
-    struct Stage { u32x4_t xf[4]; u32x4_t wf[4]; uint32_t wd[NMA]; };
+    struct Stage { u32x4_t xf[XP ? 4 : 1]; u32x4_t xn[XN ? 4 : 1]; u32x4_t wf[4]; uint32_t wd[NMA]; };
     // one stage = (tile, iteration): 4 x 16 B of the lane's x row, 4 x 16 B of its W row, one sign word per mask
     auto issue = [&](Stage& st, int tile, int it) {
         const int irow = 4 * it + g;                                     // this lane group's word row
         const bool krow_ok = tile < ntile && irow < nrow;
         const int n = c_lo + tile * 16 + li;
         const bool col_ok = n < c_hi;
-        const uint32_t xo = krow_ok ? x_off + (uint32_t)irow * 64u : STREAM_OOB;
+        if constexpr (XP) {
+            const uint32_t xo = krow_ok ? x_off + (uint32_t)irow * 64u : STREAM_OOB;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) st.xf[s] = buf_load16<0>(rx, xo + 16u * s);
-        if constexpr (HASW) {
+            for (int s = 0; s < 4; ++s) st.xf[s] = buf_load16<0>(rx, xo + 16u * s);
+        }
+        if constexpr (XN) {
+            // natural order: step s, lane group g -> k = 128 it + 32 s + 8 g; a k-octet past K is out of range by itself
+            // (the row extents of x and W end at K), except that x rows are contiguous: guard the octet explicitly
+            const int k0 = 128 * it + 8 * g;
+            const bool it_ok = tile < ntile;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bool ok = it_ok && (k0 + 32 * s < p.K);
+                st.xn[s] = buf_load16<0>(rx, ok ? x_off + (uint32_t)(k0 + 32 * s) * 2u : STREAM_OOB);
+                st.wf[s] = buf_load16<AUX>(rw, (ok && col_ok) ? (uint32_t)n * (uint32_t)p.ldw * 2u + (uint32_t)(k0 + 32 * s) * 2u : STREAM_OOB);
+            }
+        } else if constexpr (HASW) {
             const uint32_t wo = (krow_ok && col_ok) ? (uint32_t)n * (uint32_t)p.ldw * 2u + (uint32_t)irow * 64u : STREAM_OOB;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) st.wf[s] = buf_load16<2>(rw, wo + 16u * s);
+            for (int s = 0; s < 4; ++s) st.wf[s] = buf_load16<AUX>(rw, wo + 16u * s);
         }
         [[maybe_unused]] const uint32_t po = (krow_ok && col_ok) ? ((uint32_t)irow * (uint32_t)p.N + (uint32_t)n) * 4u : STREAM_OOB;
 #pragma unroll
         for (int t = 0; t < NM; ++t) {
             const uint32_t tb = (uint32_t)(min(t, nmask - 1)) * (uint32_t)p.sPb * 4u;
-            st.wd[t] = buf_load4<2>(rp, po == STREAM_OOB ? STREAM_OOB : po + tb);
+            st.wd[t] = buf_load4<AUX>(rp, po == STREAM_OOB ? STREAM_OOB : po + tb);
         }
         // the stages must enter the load queue in stream order: without this fence hipcc clusters the loads of ALL prologue stages
         // by descriptor (every x, then every W, then every sign word), and stage 0 cannot be consumed before nearly all of them land
@@ -150,8 +171,8 @@ __global__ void __launch_bounds__(512) gemv_stream_kernel(const StreamParams sp)
     if constexpr (NM > 0) {   // sign LUT, 16 copies: slot index = 16 e + c is linear in the thread id -> every ds_write_b128 stores 64 consecutive slots
         constexpr uint32_t POS = One2<DT>::v & 0xffffu, NEG = POS | 0x8000u;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int slot = threadIdx.x + 512 * j, ee = slot >> 4;
+        for (int j = 0; j < 4096 / (64 * NW); ++j) {
+            const int slot = threadIdx.x + 64 * NW * j, ee = slot >> 4;
             u32x4_t w;
 #pragma unroll
             for (int d = 0; d < 4; ++d) w[d] = (((ee >> (2 * d)) & 1) ? POS : NEG) | ((((ee >> (2 * d + 1)) & 1) ? POS : NEG) << 16);
@@ -178,18 +199,27 @@ __global__ void __launch_bounds__(512) gemv_stream_kernel(const StreamParams sp)
     // destinations to scratch, and scratch traffic shares vmcnt with the weight stream).  One step of NM + 1 MFMAs (>= 110 cycles of
     // matrix pipe) covers the LDS latency of the next step's reads.
     auto compute = [&](const Stage& cur) {
-        u32x4_t sf[2][NMA];
+        constexpr bool SFDB = !(WNAT && NW == 8);       // sign fragments double-buffered across MFMA steps (not when the second
+                                                         // activation fragment set already fills the 256-VGPR budget)
+        u32x4_t sf[SFDB ? 2 : 1][NMA];
+        if constexpr (SFDB) {
 #pragma unroll
-        for (int t = 0; t < NM; ++t) sf[0][t] = lut(cur.wd[t], 0);
+            for (int t = 0; t < NM; ++t) sf[0][t] = lut(cur.wd[t], 0);
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            if (s < 3) {
+            if constexpr (SFDB) {
+                if (s < 3) {
 #pragma unroll
-                for (int t = 0; t < NM; ++t) sf[(s + 1) & 1][t] = lut(cur.wd[t], s + 1);
+                    for (int t = 0; t < NM; ++t) sf[(s + 1) & 1][t] = lut(cur.wd[t], s + 1);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NM; ++t) sf[0][t] = lut(cur.wd[t], s);
             }
-            if constexpr (HASW) accB = mfma16<DT>(cur.wf[s], cur.xf[s], accB);
+            if constexpr (HASW) accB = mfma16<DT>(cur.wf[s], XN ? cur.xn[s] : cur.xf[s], accB);
 #pragma unroll
-            for (int t = 0; t < NM; ++t) accD[t] = mfma16<DT>(sf[s & 1][t], cur.xf[s], accD[t]);
+            for (int t = 0; t < NM; ++t) accD[t] = mfma16<DT>(sf[SFDB ? (s & 1) : 0][t], cur.xf[s], accD[t]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -214,7 +244,7 @@ __global__ void __launch_bounds__(512) gemv_stream_kernel(const StreamParams sp)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (wave == (tile & 7) && li < p.R) {
+        if (wave == (tile & (NW - 1)) && li < p.R) {
             const int b = li / p.M;
             f32x4_t sb = {0.f, 0.f, 0.f, 0.f}, sd = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -239,40 +269,32 @@ __global__ void __launch_bounds__(512) gemv_stream_kernel(const StreamParams sp)
         for (int t = 0; t < NM; ++t) accD[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     };
 
-    // Main loop: whole rounds of NS stages.  Its body has no branch around its loads (past the end of the stream they are out of
-    // range and touch no memory) and no exit in the middle, so hipcc's waitcnt pass sees one straight-line stream per round and waits
-    // with vmcnt((NS-1) * loads-per-stage).  (A conditional issue, or an exit test between the stages -- which the structuriser
-    // turns into an edge back to the loop header -- merges "just re-issued" into the header state and every wait of the first stage
-    // becomes vmcnt(0): measured in the ISA, not guessed.)  The last total % NS stages need no new loads: straight-line tail.
+    // Main loop: whole rounds of NS stages, at least one round.  Its body has no branch around its loads (past the end of the stream
+    // they are out of range and touch no memory) and no exit in the middle, so hipcc's waitcnt pass sees one straight-line stream per
+    // round and waits with vmcnt((NS-1) * loads-per-stage).  (A conditional issue, or an exit test between the stages -- which the
+    // structuriser turns into an edge back to the loop header -- merges "just re-issued" into the header state and every wait of
+    // the first stage becomes vmcnt(0); a separate tail after a possibly zero-trip loop makes the register allocator keep the
+    // prologue's load destinations alive across the loop and spill them, i.e. wait for them, before the first round.  Both were
+    // read in the ISA, not guessed.)  The last round is padded with all-zero stages: <= NS-1 stages of MFMAs on zeros per wave.
     const int cntb = max(it_hi - it_lo, 1);
     const int total = ntile * cntb;
     int tc = 0, ic = it_lo;                                              // stage being consumed
     int f = 0;
-    for (; f + NS <= total; f += NS) {
+    do {
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
             compute(st[u]);
             __builtin_amdgcn_sched_barrier(0);
             issue(st[u], ti, ii);
             advance(ti, ii);
-            if (++ic >= it_hi) {
+            if (++ic >= it_hi && tc < ntile) {
                 finish_tile(tc);
                 ic = it_lo;
                 ++tc;
             }
         }
-    }
-#pragma unroll
-    for (int u = 0; u < NS - 1; ++u) {
-        if (f + u < total) {
-            compute(st[u]);
-            if (++ic >= it_hi) {
-                finish_tile(tc);
-                ic = it_lo;
-                ++tc;
-            }
-        }
-    }
+        f += NS;
+    } while (f < total);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the run-ahead (out-of-range) loads of the last round
 }
 

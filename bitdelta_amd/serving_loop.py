@@ -1,0 +1,302 @@
+"""Multi-tenant greedy decoding without HF: SURVEY.md section 8(f) row 3, the caller of the batched 1-bit-delta Linear.
+
+What the reference's demo does around the hot path (demo/demo_backend.py), restated for one process and one GPU:
+  * one 16-bit base model + T fine-tunes, each a set of 1-bit deltas for the `*proj*` Linears plus its OWN dense embedding, norms
+    and lm_head (register_diff_compress, :107-153); batch row t is tenant t (:182, :192);
+  * a request is T prompts, left-padded with token 0 to max(2^ceil(log2(len)), 64) and refused beyond 1024 (:297-302);
+  * prefill `model(input_ids, attention_mask)`, then greedy `argmax(logits[:, -1])` fed back one token per tenant with the KV cache
+    until every tenant has produced a stop token or max_new_tokens is reached (:190-258).  Positions are the raw indices of the
+    padded sequence (transformers 4.31's LlamaModel numbers positions from the cache length when none are passed).
+
+This module is plumbing in PyTorch around the HIP ops -- attention, RoPE and norms are stock torch -- with three differences from
+running the reference's modules under HF, all of them launch-count / traffic only, none numerical beyond rounding:
+  * q+k+v and gate+up of a layer are ONE fused Linear each (weights and masks concatenated along the output dimension, one scale
+    group per projection so every tenant keeps its own coeff per projection): 4 Linear launches per layer instead of 7;
+  * the residual adds after o_proj / down_proj ride in the decode kernel's epilogue;
+  * per-tenant embedding / norm / lm_head are batched (serving.DataParallelModule's mechanisms), not a Python loop;
+  * the decode step is shape-static (KV cache of fixed length, a key-validity mask, the position held in a device tensor), so it
+    is captured once as a hipGraph and replayed: greedy feedback happens on the device, the host only polls the stop flags.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .binary_gemm_kernel import binary_linear, tenant_linear
+from .diff import binarize
+
+MODEL_CONFIGS = {
+    # name: (hidden, intermediate, layers, heads, kv_heads, vocab)
+    "llama-2-7b": (4096, 11008, 32, 32, 32, 32000),
+    "mistral-7b": (4096, 14336, 32, 32, 8, 32000),
+    "llama-2-70b": (8192, 28672, 80, 64, 8, 32000),
+    "tiny": (256, 512, 2, 4, 2, 512),
+}
+
+MAX_PROMPT = 1024      # demo/demo_backend.py:300-302
+MIN_PAD = 64           # demo/demo_backend.py:299
+
+
+def padded_length(longest):
+    """demo/demo_backend.py:297-299: next power of two, at least 64."""
+    return max(1 << max(longest - 1, 0).bit_length(), MIN_PAD)
+
+
+class FusedDeltaLinear(nn.Module):
+    """Several DiffCompress Linears that read the same input, launched as ONE:  W = cat(W_i), masks = cat(masks_i) along N,
+    alpha[t, g] = coeff of the projection that owns scale group g (group size = gcd of the output widths)."""
+
+    def __init__(self, weights, masks, coeffs):
+        super().__init__()
+        widths = [w.shape[0] for w in weights]
+        gsz = 0
+        for n in widths:
+            gsz = math.gcd(gsz, n)
+        self.widths = widths
+        self.register_buffer("weight", torch.cat(weights, 0).contiguous())                       # [N, K]
+        self.register_buffer("mask", torch.cat(masks, 2).contiguous())                           # [T, K/32, N]
+        alpha = torch.cat([c.float().reshape(-1, 1).expand(-1, n // gsz) for c, n in zip(coeffs, widths)], 1)
+        self.register_buffer("alpha", alpha.contiguous())                                        # [T, G]
+        self.groups = alpha.shape[1]
+
+    def forward(self, x, residual=None):
+        return binary_linear(x, self.weight, self.mask, self.alpha, groups=self.groups, residual=residual)
+
+    def linear_bytes(self):
+        """algorithmic HBM bytes of one decode launch: base once + every tenant's signs (activations / outputs are noise)"""
+        return self.weight.numel() * self.weight.element_size() + self.mask.numel() * 4
+
+
+def _rope_tables(length, dim, device, dtype, base=10000.0):
+    inv = 1.0 / (base ** (torch.arange(0, dim, 2, device=device, dtype=torch.float32) / dim))
+    ang = torch.outer(torch.arange(length, device=device, dtype=torch.float32), inv)
+    ang = torch.cat([ang, ang], dim=-1)
+    d = dim // 2
+    sin = ang.sin()
+    sin = torch.cat([-sin[:, :d], sin[:, d:]], dim=-1)                  # rotate-half sign folded in
+    return ang.cos().to(dtype), sin.to(dtype)
+
+
+def _rope(x, cos, sin):
+    # x [T, H, S, D]; cos / sin [S, D]
+    d = x.shape[-1] // 2
+    rot = torch.cat([x[..., d:], x[..., :d]], dim=-1)
+    return torch.addcmul(x * cos, rot, sin)
+
+
+class TenantDecoder(nn.Module):
+    """Llama / Mistral decoder for T tenants over one base: every `*proj*` Linear is base + T 1-bit deltas (fused HIP launches),
+    embedding / norms / lm_head are per tenant (stacked)."""
+
+    def __init__(self, cfg, tenants, device, dtype, max_len=MAX_PROMPT + 64, eps=1e-5):
+        super().__init__()
+        self.cfg, self.T, self.dtype, self.dev, self.eps = cfg, tenants, dtype, torch.device(device), eps
+        hid, inter, nl, heads, kvh, vocab = cfg
+        self.hd = hid // heads
+        self.max_len = max_len
+        self.layers = nn.ModuleList()
+        self.embed = None           # [T, vocab, hid]
+        self.final_norm = None      # [T, hid]
+        self.lm_head = None         # [T, vocab, hid]
+        cos, sin = _rope_tables(max_len, self.hd, self.dev, dtype)
+        self.register_buffer("cos", cos, persistent=False)
+        self.register_buffer("sin", sin, persistent=False)
+        self._graph = None
+
+    # ---------------------------------------------------------------- construction
+    @classmethod
+    def synthetic(cls, name, tenants, device, dtype=torch.float16, seed=0, layers=None, max_len=MAX_PROMPT + 64, shared_heads=False):
+        """Random weights with the statistics of SURVEY.md section 8(d): W ~ N(0, 0.02^2), fine-tune = W + N(0, (5e-4)^2) per
+        tenant (alpha = mean|delta| ~ 4e-4).  Embedding / norm / lm_head are per tenant as in the reference's diff.pt files
+        (`shared_heads=True` stores them once and expands -- same arithmetic, used only to keep test models small)."""
+        cfg = MODEL_CONFIGS[name] if isinstance(name, str) else tuple(name)
+        hid, inter, nl, heads, kvh, vocab = cfg
+        nl = layers or nl
+        self = cls(cfg, tenants, device, dtype, max_len=max_len)
+        gen = torch.Generator(device=device).manual_seed(seed)
+        hd = hid // heads
+
+        def delta_linear(n_out, n_in):
+            w = (torch.randn(n_out, n_in, device=device, generator=gen) * 0.02).to(dtype)
+            masks, coeffs = [], []
+            for _ in range(tenants):
+                fine = (w.float() + torch.randn(n_out, n_in, device=device, generator=gen) * 5e-4).to(dtype)
+                m, c = binarize(w, fine)
+                masks.append(m)
+                coeffs.append(c)
+            return w, torch.stack(masks, 0), torch.stack(coeffs, 0)
+
+        def fused(*shapes):
+            parts = [delta_linear(o, i) for o, i in shapes]
+            return FusedDeltaLinear([p[0] for p in parts], [p[1] for p in parts], [p[2] for p in parts])
+
+        def per_tenant(*shape, scale=None):
+            reps = 1 if shared_heads else tenants
+            if scale is None:
+                t = 1.0 + 0.1 * torch.randn(reps, *shape, device=device, generator=gen)
+            else:
+                t = torch.randn(reps, *shape, device=device, generator=gen) * scale
+            t = t.to(dtype)
+            return t.expand(tenants, *shape) if shared_heads else t
+
+        for _ in range(nl):
+            layer = nn.Module()
+            layer.qkv = fused((heads * hd, hid), (kvh * hd, hid), (kvh * hd, hid))
+            layer.o = fused((hid, heads * hd))
+            layer.gate_up = fused((inter, hid), (inter, hid))
+            layer.down = fused((hid, inter))
+            layer.norm1 = per_tenant(hid)
+            layer.norm2 = per_tenant(hid)
+            self.layers.append(layer)
+        self.embed = per_tenant(vocab, hid, scale=0.02)
+        self.final_norm = per_tenant(hid)
+        self.lm_head = per_tenant(vocab, hid, scale=0.02)
+        return self
+
+    # ---------------------------------------------------------------- accounting
+    def linear_bytes_per_step(self):
+        """algorithmic HBM bytes of the Linear launches of one decode step (the roofline numerator): delta Linears + lm_heads"""
+        b = sum(l.qkv.linear_bytes() + l.o.linear_bytes() + l.gate_up.linear_bytes() + l.down.linear_bytes() for l in self.layers)
+        return b, self.T * self.lm_head.shape[1] * self.lm_head.shape[2] * self.lm_head.element_size()
+
+    def linear_param_count(self):
+        return sum(l.qkv.weight.numel() + l.o.weight.numel() + l.gate_up.weight.numel() + l.down.weight.numel() for l in self.layers)
+
+    # ---------------------------------------------------------------- forward
+    def new_cache(self, length=None):
+        length = length or self.max_len
+        _, _, _, heads, kvh, _ = self.cfg
+        mk = lambda: torch.zeros(self.T, kvh, length, self.hd, device=self.dev, dtype=self.dtype)
+        return {"k": [mk() for _ in self.layers], "v": [mk() for _ in self.layers],
+                "valid": torch.zeros(self.T, length, dtype=torch.bool, device=self.dev)}
+
+    def _norm(self, x, w):
+        return F.rms_norm(x, (x.shape[-1],), None, self.eps) * w[:, None, :]
+
+    def _layer(self, layer, x, cos, sin, cache, li, pos_idx, attn_mask):
+        T, S, hid = x.shape
+        _, _, _, heads, kvh, _ = self.cfg
+        hd = self.hd
+        h = self._norm(x, layer.norm1)
+        qkv = layer.qkv(h)
+        q, k, v = qkv.split(layer.qkv.widths, dim=-1)
+        q = _rope(q.view(T, S, heads, hd).transpose(1, 2), cos, sin)
+        k = _rope(k.view(T, S, kvh, hd).transpose(1, 2), cos, sin)
+        v = v.view(T, S, kvh, hd).transpose(1, 2)
+        ck, cv = cache["k"][li], cache["v"][li]
+        ck.index_copy_(2, pos_idx, k)
+        cv.index_copy_(2, pos_idx, v)
+        a = F.scaled_dot_product_attention(q, ck, cv, attn_mask=attn_mask, enable_gqa=(kvh != heads))
+        a = a.transpose(1, 2).reshape(T, S, heads * hd)
+        x = layer.o(a, residual=x)
+        h = self._norm(x, layer.norm2)
+        gu = layer.gate_up(h)
+        g, u = gu.split(layer.gate_up.widths, dim=-1)
+        x = layer.down(F.silu(g) * u, residual=x)
+        return x
+
+    @torch.no_grad()
+    def forward(self, ids, pos_idx, cache, attn_mask):
+        """ids [T, S]; pos_idx [S] (device, positions of these tokens in the cache); attn_mask [T, 1, S, L] bool.
+        Returns the logits of the LAST position, [T, vocab]."""
+        T, S = ids.shape
+        cos, sin = self.cos[pos_idx], self.sin[pos_idx]
+        t_idx = torch.arange(T, device=ids.device).view(T, 1)
+        x = self.embed[t_idx, ids]                                            # per-tenant embedding: one gather
+        for li, layer in enumerate(self.layers):
+            x = self._layer(layer, x, cos, sin, cache, li, pos_idx, attn_mask)
+        last = self._norm(x[:, -1:, :], self.final_norm)
+        return tenant_linear(last, self.lm_head)[:, 0, :]                     # per-tenant lm_head: one launch
+
+    # ---------------------------------------------------------------- request handling (demo_backend.py:261-315 + :190-258)
+    def prepare(self, prompts):
+        """Left-pad T prompts with token 0 to a power of two >= 64; returns (ids [T, L], attention mask [T, L]) on the device."""
+        assert len(prompts) == self.T, "one prompt per tenant (batch row t is tenant t)"
+        longest = max(len(p) for p in prompts)
+        L = padded_length(longest)
+        if L > MAX_PROMPT:
+            raise ValueError("max_len too large, please reduce the input length")      # the reference's refusal, as an exception
+        ids = torch.zeros(self.T, L, dtype=torch.long)
+        am = torch.zeros(self.T, L, dtype=torch.bool)
+        for t, p in enumerate(prompts):
+            ids[t, L - len(p):] = torch.tensor(p, dtype=torch.long)
+            am[t, L - len(p):] = True
+        return ids.to(self.dev), am.to(self.dev)
+
+    @torch.no_grad()
+    def prefill(self, ids, attention_mask, cache):
+        T, L = ids.shape
+        pos_idx = torch.arange(L, device=self.dev)
+        cache["valid"].zero_()
+        cache["valid"][:, :L] = attention_mask
+        Lc = cache["k"][0].shape[2]
+        causal = torch.ones(L, Lc, dtype=torch.bool, device=self.dev).tril()                     # query i sees keys <= i
+        mask = causal[None, None] & cache["valid"][:, None, None, :]
+        # fully masked query rows (left pads) would be NaN in softmax: let a pad see itself; its output is never used
+        mask = mask | torch.eye(L, Lc, dtype=torch.bool, device=self.dev)[None, None]
+        return self.forward(ids, pos_idx, cache, mask)
+
+    def _decode_step(self, st):
+        """one greedy step on static buffers: st['tok'] [T,1] -> logits -> argmax -> st['tok']; position / masks advance on device"""
+        cache = st["cache"]
+        cache["valid"].index_fill_(1, st["pos"], True)
+        mask = cache["valid"][:, None, None, :]
+        logits = self.forward(st["tok"], st["pos"], cache, mask)
+        nxt = torch.argmax(logits, dim=-1)
+        st["tok"].copy_(nxt[:, None])
+        st["out"].index_copy_(1, st["step"], nxt[:, None])
+        st["stopped"] |= (nxt[:, None] == st["stop_ids"]).any(dim=1)
+        st["pos"] += 1
+        st["step"] += 1
+
+    @torch.no_grad()
+    def generate(self, prompts, max_new_tokens=16, stop_token_ids=None, use_graph=True, check_every=1):
+        """Greedy decoding of T prompts (one per tenant).  Returns (new_tokens [T, n] on the CPU, n_steps).
+        stop_token_ids: per-tenant lists of token ids; generation ends when every tenant has produced one (or at max_new_tokens),
+        exactly like the reference's loop; tokens after a tenant's stop token are still generated (the reference does the same and
+        hides them in its response formatting)."""
+        ids, am = self.prepare(prompts)
+        T, L = ids.shape
+        assert L + max_new_tokens <= self.max_len
+        cache = self.new_cache()
+        logits = self.prefill(ids, am, cache)
+        nstop = max((len(s) for s in stop_token_ids), default=0) if stop_token_ids else 0
+        stop = torch.full((T, max(nstop, 1)), -1, dtype=torch.long, device=self.dev)
+        if stop_token_ids:
+            for t, s in enumerate(stop_token_ids):
+                if len(s):
+                    stop[t, :len(s)] = torch.tensor(sorted(s), dtype=torch.long, device=self.dev)
+        first = torch.argmax(logits, dim=-1)
+        st = {"cache": cache, "tok": first[:, None].clone(), "pos": torch.tensor([L], device=self.dev),
+              "step": torch.tensor([1], device=self.dev), "stop_ids": stop,
+              "out": torch.zeros(T, max_new_tokens + 1, dtype=torch.long, device=self.dev),
+              "stopped": (first[:, None] == stop).any(dim=1)}
+        st["out"][:, 0] = first
+        n = 1
+        runner = self._graph_runner(st) if use_graph and max_new_tokens > 1 else (lambda: self._decode_step(st))
+        while n < max_new_tokens:
+            if (n - 1) % check_every == 0 and bool(st["stopped"].all()):
+                break
+            runner()
+            n += 1
+        return st["out"][:, :n].cpu(), n
+
+    def _graph_runner(self, st):
+        """Capture one decode step as a hipGraph on the request's static buffers and return a replay callable.  The launch-bound
+        step (4 Linear launches + ~20 small torch ops per layer) replays without per-op host overhead."""
+        side = torch.cuda.Stream(device=self.dev)
+        snap = {k: v.clone() for k, v in st.items() if torch.is_tensor(v)}
+        snap_valid = st["cache"]["valid"].clone()
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):                     # warm-up outside capture (allocations, workspace, lazy init)
+            self._decode_step(st)
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._decode_step(st)
+        torch.cuda.synchronize(self.dev)
+        for k, v in snap.items():                         # undo the two trial steps: replay starts from the request's real state
+            st[k].copy_(v)
+        st["cache"]["valid"].copy_(snap_valid)
+        return g.replay

@@ -434,6 +434,51 @@ static int run_decode_cold(const char* tag, int B, int M, int N, int K, int dt, 
     return (rc != 0 || bad != 0) ? 1 : 0;
 }
 
+// pure weight streaming: bd_tenant_linear (no sign operand) over `nset` cold copies of W; the ceiling of the decode kernel structure
+static int run_tenant_cold(const char* tag, int T, int N, int K, int iters) {
+    const size_t wbytes = (size_t)T * N * K * 2;
+    int nset = (int)(600e6 / (double)wbytes) + 1;
+    if (nset < 2) nset = 2;
+    if (nset > 24) nset = 24;
+    std::vector<uint16_t> hW((size_t)T * N * K), hX((size_t)T * K);
+    for (auto& v : hW) v = f2h(0.02f * nrand(), BD_F16);
+    for (auto& v : hX) v = f2h(nrand(), BD_F16);
+    void *dX, *dY;
+    std::vector<void*> Ws(nset);
+    HIPCHECK(hipMalloc(&dX, hX.size() * 2)); HIPCHECK(hipMemcpy(dX, hX.data(), hX.size() * 2, hipMemcpyHostToDevice));
+    HIPCHECK(hipMalloc(&dY, (size_t)T * N * 2));
+    for (int i = 0; i < nset; ++i) { HIPCHECK(hipMalloc(&Ws[i], wbytes)); HIPCHECK(hipMemcpy(Ws[i], hW.data(), wbytes, hipMemcpyHostToDevice)); }
+    auto call = [&](int i) { return bd_tenant_linear(dX, Ws[i], dY, T, 1, N, K, K, K, (int64_t)N * K, K, N, N, BD_F16, BD_F16, 0); };
+    int rc = call(0);
+    hipError_t herr = hipDeviceSynchronize();
+    int bad = 0;
+    if (rc == 0 && herr == hipSuccess) {
+        std::vector<uint16_t> hY((size_t)T * N);
+        HIPCHECK(hipMemcpy(hY.data(), dY, hY.size() * 2, hipMemcpyDeviceToHost));
+        for (int s = 0; s < 256; ++s) {
+            const int t = (int)(rng() % T), n = (int)(rng() % N);
+            double ref = 0;
+            for (int k = 0; k < K; ++k) ref += (double)h2f(hX[(size_t)t * K + k], BD_F16) * (double)h2f(hW[((size_t)t * N + n) * K + k], BD_F16);
+            const double got = h2f(hY[(size_t)t * N + n], BD_F16);
+            if (fabs(got - ref) > 2e-3 * fabs(ref) + 2e-3) ++bad;
+        }
+    }
+    double warm = 0, cold = 0;
+    if (rc == 0 && herr == hipSuccess && bad == 0) {
+        warm = time_ms([&] { call(0); }, 5, iters) * 1e3;
+        int idx = 0;
+        cold = time_ms([&] { call(idx); idx = (idx + 1) % nset; }, nset, iters) * 1e3;
+    }
+    printf("{\"tag\":\"%s\",\"T\":%d,\"N\":%d,\"K\":%d,\"rc\":%d,\"bad\":%d,\"MB\":%.1f,\"nset\":%d,\"warm_us\":%.2f,\"warm_gbps\":%.0f,"
+           "\"cold_us\":%.2f,\"cold_gbps\":%.0f}\n", tag, T, N, K, rc, bad, wbytes * 1e-6, nset, warm, warm > 0 ? wbytes / warm * 1e-3 : 0.0,
+           cold, cold > 0 ? wbytes / cold * 1e-3 : 0.0);
+    fflush(stdout);
+    hipFree(dX); hipFree(dY);
+    for (auto w : Ws) hipFree(w);
+    if (herr != hipSuccess) exit(3);
+    return (rc != 0 || bad != 0) ? 1 : 0;
+}
+
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "check";
     hipDeviceProp_t prop;
@@ -625,6 +670,22 @@ int main(int argc, char** argv) {
                 fails += run_decode_cold("dec_70b_gateup_shard", 1, 1, 7168, 8192, BD_BF16, 1, v, 100);
             }
         }
+    } else if (mode == "stream_ab") {
+        // A/B matrix of the streaming decode kernel (bd_set_stream_tuning: bit 0 natural-order W, bit 1 default cache policy, bit 2
+        // 4-wave blocks, bit 3 deeper prefetch), cold weights.  First the pure weight stream (no sign operand), then T = 1 / 6.
+        for (int tune = 0; tune < 16; ++tune) {
+            bd_set_stream_tuning(tune);
+            char tg[64];
+            snprintf(tg, sizeof tg, "ab%02d_stream_4096sq", tune);   fails += run_tenant_cold(tg, 1, 4096, 4096, 200);
+            snprintf(tg, sizeof tg, "ab%02d_stream_28672", tune);    fails += run_tenant_cold(tg, 1, 28672, 4096, 60);
+            snprintf(tg, sizeof tg, "ab%02d_T1_4096sq", tune);       fails += run_decode_cold(tg, 1, 1, 4096, 4096, BD_F16, 1, 600, 200);
+            snprintf(tg, sizeof tg, "ab%02d_T6_4096sq", tune);       fails += run_decode_cold(tg, 6, 1, 4096, 4096, BD_F16, 1, 600, 200);
+            snprintf(tg, sizeof tg, "ab%02d_T6_gateup", tune);       fails += run_decode_cold(tg, 6, 1, 28672, 4096, BD_F16, 1, 600, 60);
+            snprintf(tg, sizeof tg, "ab%02d_T6_down", tune);         fails += run_decode_cold(tg, 6, 1, 4096, 14336, BD_F16, 1, 600, 60);
+        }
+        bd_set_stream_tuning(0);
+        fails += run_decode_cold("ref300_T6_4096sq", 6, 1, 4096, 4096, BD_F16, 1, 300, 200);
+        fails += run_decode_cold("ref300_T6_gateup", 6, 1, 28672, 4096, BD_F16, 1, 300, 60);
     } else if (mode == "dec600_pmc") {
         // few launches of the headline decode shapes for rocprofv3 --kernel-trace / --pmc passes
         for (int v : {600, 500, 300})

@@ -85,3 +85,62 @@ def test_partition_helpers_single_process():
     m = torch.arange(8 * 6, dtype=torch.int32).reshape(8, 6)
     assert torch.equal(torch.cat([bdd.shard_mask_rows(m, r, 4) for r in range(4)], 0), m)
     assert torch.equal(torch.cat([bdd.shard_mask_columns(m, r, 2) for r in range(2)], 1), m)
+
+
+# ------------------------------------------------------------------------------------------------ tensor-parallel Linears through the HIP path
+def _tp_worker(rank, world, port, q):
+    """Two ranks share cuda:0 (the GPU box has one device); partial sums come from the HIP kernel (bd_binary_linear on the rank's
+    K-slice / N-slice) and are reduced over gloo on host copies -- the same code path bench.py --workload tp70b drives over RCCL."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from bitdelta_amd import dist as bdd
+    from bitdelta_amd import tp
+    import bitdelta_amd as bd
+    from oracle import bd_oracle as o
+    bdd.init_from_env(backend="gloo")
+    torch.manual_seed(0)                                   # same full problem on every rank
+    res = {}
+    for name, (N, K, M) in {"o_shard_like": (512, 256, 1), "down_like": (256, 1024, 3), "prefill": (384, 512, 200)}.items():
+        base = (torch.randn(N, K) * 0.02).bfloat16()
+        fine = (base.float() + torch.randn(N, K) * 5e-4).bfloat16()
+        x = torch.randn(2, M, K).bfloat16()
+        mask, coeff = o.binarize(base, fine)
+        full = o.binary_linear(x.reshape(1, -1, K), base, mask[None], coeff.reshape(1, 1), out_dtype=torch.float32).reshape(2, M, N)
+        dev = "cuda:0"
+        # row parallel: K-slices, fp32 partials from the HIP kernel, all-reduce (gloo on host copies)
+        rowp = tp.RowParallelBinaryDiff.from_full(base.to(dev), mask.to(dev), coeff.to(dev), rank, world)
+        k = K // world
+        part = rowp.partial(x[..., rank * k:(rank + 1) * k].contiguous().to(dev)).cpu()
+        dist.all_reduce(part)
+        ok_row = ((part - full).norm() / full.norm()).item() <= 1e-5
+        # column parallel: N-slices concatenate to the full result, no exchange
+        colp = tp.ColumnParallelBinaryDiff.from_full(base.to(dev), mask.to(dev), coeff.to(dev), rank, world)
+        ycol = colp(x.to(dev)).float().cpu()
+        gathered = [torch.empty_like(ycol) for _ in range(world)]
+        dist.all_gather(gathered, ycol)
+        ycat = torch.cat(gathered, dim=-1)
+        ok_col = ((ycat - full).norm() / full.norm()).item() <= 4e-3 and ycat.shape == full.shape
+        res[name] = (ok_row, ok_col)
+    q.put((rank, res))
+    dist.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_tensor_parallel_linears_world_size_2_through_hip():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, res in out:
+        for name, (ok_row, ok_col) in res.items():
+            assert ok_row and ok_col, (rank, name, ok_row, ok_col)
