@@ -16,7 +16,8 @@ import torch
 from . import _lib
 from ._lib import DTYPE_CODE, WORD_DTYPE, check, lib, ptr, require_gpu, stream_ptr, workspace
 
-__all__ = ["pack", "unpack", "binary_matmul", "binary_bmm", "delta_bmm", "binary_linear", "tenant_linear"]
+__all__ = ["pack", "unpack", "binary_matmul", "binary_bmm", "delta_bmm", "binary_linear", "tenant_linear", "tile_masks",
+           "binary_linear_decode", "decode_shape_ok"]
 
 
 def pack(x, n_bits=32):
@@ -152,6 +153,56 @@ def binary_linear(x, weight, mask, alpha, *, out_dtype=None, groups=1, residual=
     if residual is not None and not fused_residual:
         residual += y
         return residual
+    return y
+
+
+def tile_masks(mask):
+    """Repack packed sign words [T, K/32, N] (the reference / diff.pt layout) into the tile-major order of the streaming decode
+    kernel, [T, ceil(N/16), K/32, 16]: every 16-column tile's words become one contiguous run over k.  Done once per registered
+    tenant set on the serving side; columns past N are zero padding."""
+    assert mask.dim() == 3 and mask.dtype == torch.int32
+    T, KW, N = mask.shape
+    Np = (N + 15) // 16 * 16
+    if Np != N:
+        mask = torch.nn.functional.pad(mask, (0, Np - N))
+    return mask.view(T, KW, Np // 16, 16).permute(0, 2, 1, 3).contiguous()
+
+
+def decode_shape_ok(B, M, N, K, n_masks):
+    """True when bd_binary_linear_decode accepts the problem (the streaming decode kernel's envelope)."""
+    if M < 1 or M > 16 or N < 512 or K % 32:
+        return False
+    chunk = min(B, 16 // M)
+    return (1 if n_masks == 1 else chunk) <= 8
+
+
+def binary_linear_decode(x, weight, mask_tiled, alpha, *, out_dtype=None, groups=1, residual=None):
+    """binary_linear for decode shapes with tile-major masks (tile_masks): one launch of the streaming kernel.
+    x: (B, M, K), M <= 16; weight (N, K); mask_tiled (B or 1, ceil(N/16), K/32, 16); alpha fp32 (B or 1, groups)."""
+    require_gpu(x, weight, mask_tiled, alpha, residual)
+    B, M, K = x.shape
+    N = weight.shape[0]
+    assert mask_tiled.dim() == 4 and mask_tiled.dtype == torch.int32 and mask_tiled.is_contiguous()
+    assert mask_tiled.shape[1:] == ((N + 15) // 16, K // 32, 16) and mask_tiled.shape[0] in (1, B)
+    assert weight.shape[1] == K and weight.stride(1) == 1 and weight.dtype == x.dtype and x.stride(2) == 1
+    out_dtype = out_dtype or x.dtype
+    alpha = alpha.detach()
+    if alpha.dtype != torch.float32 or not alpha.is_contiguous():
+        alpha = alpha.float().contiguous()
+    alpha = alpha.reshape(-1, groups)
+    assert alpha.shape[0] in (1, B)
+    sPb = 0 if (mask_tiled.shape[0] == 1 and B > 1) else mask_tiled.stride(0)
+    sAlb = 0 if alpha.shape[0] == 1 else groups
+    if residual is not None:
+        assert residual.shape == (B, M, N) and residual.dtype == out_dtype and residual.stride(2) == 1
+        y = residual
+    else:
+        y = torch.empty((B, M, N), device=x.device, dtype=out_dtype)
+    with torch.cuda.device(x.device):
+        check(lib().bd_binary_linear_decode(ptr(x), ptr(weight), ptr(mask_tiled), ptr(alpha), ptr(y), B, M, N, K, x.stride(0),
+                                            x.stride(1), weight.stride(0), sPb, sAlb, groups, y.stride(0), y.stride(1),
+                                            DTYPE_CODE[x.dtype], DTYPE_CODE[out_dtype], 1 if residual is not None else 0,
+                                            stream_ptr()), "binary_linear_decode")
     return y
 
 

@@ -13,6 +13,7 @@
 #include "bd_gemm_fx.h"
 #include "bd_gemv.h"
 #include "bd_gemv_stream.h"
+#include "bd_serving.h"
 #include <atomic>
 
 using namespace bd;
@@ -117,6 +118,7 @@ struct Problem {
     int B, M, N, K;
     int64_t sAb, sAm, sPb, sCb, sCm, ldw, sAlb;
     int G, dtype, out_dtype, round_mode, accumulate;
+    int mask_tiled;           // 0: P is [B or 1, K/32, N] (reference layout); 1: tile-major [B or 1, ceil(N/16), K/32, 16] (decode kernel only)
     void* ws;
     int64_t ws_bytes;
     hipStream_t st;
@@ -302,7 +304,7 @@ inline bool stream_ok(const Problem& q, int rows, int nmask) {
     const int64_t lim = (1ll << 31) - 64;
     const int64_t xb = ((int64_t)(q.B - 1) * q.sAb + (int64_t)(q.M - 1) * q.sAm + q.K) * 2;
     const int64_t wb = q.W ? ((int64_t)(q.N - 1) * q.ldw + q.K) * 2 : 0;
-    const int64_t pb = ((int64_t)(nmask - 1) * q.sPb + (int64_t)(q.K / 32) * q.N) * 4;
+    const int64_t pb = ((int64_t)(nmask - 1) * q.sPb + (int64_t)(q.K / 32) * ((q.N + 15) / 16 * 16)) * 4;
     return xb > 0 && xb < lim && wb < lim && pb < lim && q.sAb >= 0 && q.sAm >= 0;
 }
 
@@ -361,10 +363,12 @@ int launch_gemv_stream_chunk(const Problem& q) {
     if (cpb < 4) cpb = 4;
     if (g_forced_variant > 600 && g_forced_variant <= 664) cpb = 4 * (g_forced_variant - 600);     // test hook: 600 + cpb/4
     sp.cpb = cpb;
+    sp.pts = q.mask_tiled ? 16u * (uint32_t)(q.K / 32) : 16u;
+    sp.prs = q.mask_tiled ? 16u : (uint32_t)q.N;
     const unsigned grid = (unsigned)((q.N + cpb - 1) / cpb);
     sp.x_bytes = (uint32_t)(((int64_t)(q.B - 1) * q.sAb + (int64_t)(q.M - 1) * q.sAm + q.K) * 2);
     sp.w_bytes = q.W ? (uint32_t)(((int64_t)(q.N - 1) * q.ldw + q.K) * 2) : 0u;
-    sp.p_bytes = (uint32_t)(((int64_t)(nmask - 1) * q.sPb + (int64_t)(q.K / 32) * q.N) * 4);
+    sp.p_bytes = (uint32_t)(((int64_t)(nmask - 1) * q.sPb + (int64_t)(q.K / 32) * (q.mask_tiled ? (q.N + 15) / 16 * 16 : q.N)) * 4);
     int rc;
     // NS = stages of loads in flight per wave; bounded by the 256-VGPR budget of a 2-waves-per-SIMD block (hipcc spills beyond)
 #define BD_STREAM(NM, NS8) rc = q.W ? launch_stream_tuned<DT, NM, true, NS8>(sp, dim3(grid), q.st) \
@@ -764,15 +768,23 @@ extern "C" int bd_delta_bmm(const void* A, const int32_t* P, void* C, int B, int
 
 static int binary_linear_impl(const void* X, const void* W, const int32_t* P, const float* alpha, void* Y, int B, int M,
                               int N, int K, int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb, int64_t sAlb, int G,
-                              int64_t sYb, int64_t sYm, int dtype, int out_dtype, int accumulate, void* ws, int64_t ws_bytes,
-                              void* stream) {
+                              int64_t sYb, int64_t sYm, int dtype, int out_dtype, int accumulate, int mask_tiled, void* ws,
+                              int64_t ws_bytes, void* stream) {
     if (B > 0 && M > 0 && N > 0 && !W) return BD_E_NULL;
     Problem q{};
     q.A = X; q.P = P; q.C = Y; q.W = W; q.alpha = alpha;
     q.B = B; q.M = M; q.N = N; q.K = K;
     q.sAb = sXb; q.sAm = sXm; q.sPb = sPb; q.sCb = sYb; q.sCm = sYm; q.ldw = ldw; q.sAlb = sAlb;
     q.G = G; q.dtype = dtype; q.out_dtype = out_dtype; q.round_mode = 0; q.accumulate = accumulate ? 1 : 0;
+    q.mask_tiled = mask_tiled ? 1 : 0;
     q.ws = ws; q.ws_bytes = ws_bytes; q.st = (hipStream_t)stream;
+    // tile-major masks exist for the streaming decode kernel only (serving-side repack; the reference layout works everywhere)
+    if (q.mask_tiled) {
+        const bool forced_other = g_forced_variant >= 0 && g_forced_variant != 200 && !(g_forced_variant >= 600 && g_forced_variant <= 664);
+        if (M < 1 || M > GEMV_MAX_M || forced_other || !gemv_ok(q)) return BD_E_BAD_SHAPE;
+        const int cb = GEMV_MAX_R / M, bc = B < cb ? B : cb;
+        if (!stream_ok(q, bc * M, sPb == 0 ? 1 : bc)) return BD_E_BAD_SHAPE;
+    }
     // Y += ... is an epilogue of the decode kernels only (a residual add costs a launch per Linear there; at prefill sizes it is
     // noise next to the GEMM and stays with the caller)
     if (q.accumulate && !(gemv_ok(q) && g_forced_variant < 0 || (g_forced_variant >= 200 && gemv_ok(q)))) return BD_E_BAD_SHAPE;
@@ -783,15 +795,22 @@ extern "C" int bd_binary_linear(const void* X, const void* W, const int32_t* P, 
                                 int N, int K, int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb, int64_t sAlb, int G,
                                 int64_t sYb, int64_t sYm, int dtype, int out_dtype, void* ws, int64_t ws_bytes,
                                 void* stream) {
-    return binary_linear_impl(X, W, P, alpha, Y, B, M, N, K, sXb, sXm, ldw, sPb, sAlb, G, sYb, sYm, dtype, out_dtype, 0, ws,
+    return binary_linear_impl(X, W, P, alpha, Y, B, M, N, K, sXb, sXm, ldw, sPb, sAlb, G, sYb, sYm, dtype, out_dtype, 0, 0, ws,
                               ws_bytes, stream);
+}
+
+extern "C" int bd_binary_linear_decode(const void* X, const void* W, const int32_t* P_tiled, const float* alpha, void* Y, int B,
+                                       int M, int N, int K, int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb, int64_t sAlb,
+                                       int G, int64_t sYb, int64_t sYm, int dtype, int out_dtype, int accumulate, void* stream) {
+    return binary_linear_impl(X, W, P_tiled, alpha, Y, B, M, N, K, sXb, sXm, ldw, sPb, sAlb, G, sYb, sYm, dtype, out_dtype,
+                              accumulate, 1, nullptr, 0, stream);
 }
 
 extern "C" int bd_binary_linear_residual(const void* X, const void* W, const int32_t* P, const float* alpha, void* Y, int B,
                                          int M, int N, int K, int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb,
                                          int64_t sAlb, int G, int64_t sYb, int64_t sYm, int dtype, int out_dtype, void* ws,
                                          int64_t ws_bytes, void* stream) {
-    return binary_linear_impl(X, W, P, alpha, Y, B, M, N, K, sXb, sXm, ldw, sPb, sAlb, G, sYb, sYm, dtype, out_dtype, 1, ws,
+    return binary_linear_impl(X, W, P, alpha, Y, B, M, N, K, sXb, sXm, ldw, sPb, sAlb, G, sYb, sYm, dtype, out_dtype, 1, 0, ws,
                               ws_bytes, stream);
 }
 
@@ -819,7 +838,7 @@ extern "C" int bd_tenant_linear(const void* X, const void* W, void* Y, int T, in
     gp.sXm = (int)sXm; gp.sCm = (int)sYm; gp.ldw = (int)ldw; gp.sAlb = 0; gp.gsz = N;
     gp.KS = 1; gp.kslice = K; gp.round_mode = 0; gp.accumulate = 0; gp.out_f32 = (out_dtype == BD_F32);
     sp.sXt = sXt; sp.sWt = sWt; sp.sCt = sYt;
-    sp.x_bytes = (uint32_t)xb; sp.w_bytes = (uint32_t)wb; sp.p_bytes = 0;
+    sp.x_bytes = (uint32_t)xb; sp.w_bytes = (uint32_t)wb; sp.p_bytes = 0; sp.pts = 16; sp.prs = (uint32_t)N;
     int bpt = num_cus() / T;                       // blocks per tenant: all tenants stream concurrently, ~one block per CU in total
     if (bpt < 1) bpt = 1;
     int cpb = (N + bpt - 1) / bpt;
@@ -831,6 +850,63 @@ extern "C" int bd_tenant_linear(const void* X, const void* W, void* Y, int T, in
     const int rc = dtype == BD_BF16 ? launch_stream_tuned<DT_BF16, 0, true, 4>(sp, grid, st)
                                     : launch_stream_tuned<DT_F16, 0, true, 4>(sp, grid, st);
     if (rc != BD_OK) return rc;
+    return launch_status();
+}
+
+// ------------------------------------------------------------------ serving-loop glue (decode step; callers of the path)
+extern "C" int bd_srv_rmsnorm(const void* X, const void* Wt, void* Y, int rows, int H, int64_t sx, int64_t sy, int64_t sw,
+                              int rows_per_tenant, float eps, int dtype, void* stream) {
+    if (rows < 0 || H < 0 || rows_per_tenant < 1) return BD_E_BAD_SHAPE;
+    if (dtype != BD_F16 && dtype != BD_BF16) return BD_E_BAD_DTYPE;
+    if (rows == 0 || H == 0) return BD_OK;
+    if (!X || !Wt || !Y) return BD_E_NULL;
+    if (H % 8 || sx % 8 || sy % 8 || sw % 8 || !aligned16(X) || !aligned16(Wt) || !aligned16(Y)) return BD_E_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == BD_BF16)
+        hipLaunchKernelGGL((rmsnorm_tenant_kernel<DT_BF16>), dim3(rows), dim3(256), 0, st, (const unsigned short*)X, (const unsigned short*)Wt,
+                           (unsigned short*)Y, H, (long long)sx, (long long)sy, (long long)sw, rows_per_tenant, eps);
+    else
+        hipLaunchKernelGGL((rmsnorm_tenant_kernel<DT_F16>), dim3(rows), dim3(256), 0, st, (const unsigned short*)X, (const unsigned short*)Wt,
+                           (unsigned short*)Y, H, (long long)sx, (long long)sy, (long long)sw, rows_per_tenant, eps);
+    return launch_status();
+}
+
+extern "C" int bd_srv_swiglu(const void* GU, void* Y, int rows, int I, int64_t sg, int64_t sy, int dtype, void* stream) {
+    if (rows < 0 || I < 0 || rows > 65535) return BD_E_BAD_SHAPE;
+    if (dtype != BD_F16 && dtype != BD_BF16) return BD_E_BAD_DTYPE;
+    if (rows == 0 || I == 0) return BD_OK;
+    if (!GU || !Y) return BD_E_NULL;
+    if (I % 8 || sg % 8 || sy % 8 || !aligned16(GU) || !aligned16(Y)) return BD_E_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((I / 8 + 255) / 256), (unsigned)rows);
+    if (dtype == BD_BF16)
+        hipLaunchKernelGGL((swiglu_kernel<DT_BF16>), grid, dim3(256), 0, st, (const unsigned short*)GU, (unsigned short*)Y, I, (long long)sg, (long long)sy);
+    else
+        hipLaunchKernelGGL((swiglu_kernel<DT_F16>), grid, dim3(256), 0, st, (const unsigned short*)GU, (unsigned short*)Y, I, (long long)sg, (long long)sy);
+    return launch_status();
+}
+
+extern "C" int bd_srv_decode_attention(const void* QKV, const void* cos_t, const void* sin_t, void* kcache, void* vcache,
+                                       void* valid, const int64_t* pos, void* out, int T, int H, int KVH, int head_dim, int Lc,
+                                       int64_t s_qkv, int64_t s_out, int dtype, void* stream) {
+    if (T < 0 || H < 1 || KVH < 1 || H % KVH || Lc < 1) return BD_E_BAD_SHAPE;
+    if (dtype != BD_F16 && dtype != BD_BF16) return BD_E_BAD_DTYPE;
+    if (T == 0) return BD_OK;
+    if (!QKV || !cos_t || !sin_t || !kcache || !vcache || !valid || !pos || !out) return BD_E_NULL;
+    const int G = H / KVH;
+    if (head_dim != 128 || (G != 1 && G != 4) || s_qkv % 8 || !aligned16(QKV) || !aligned16(kcache) || !aligned16(vcache))
+        return BD_E_BAD_SHAPE;                         // other head geometries: the caller keeps its torch attention
+    AttnParams p;
+    p.qkv = (const unsigned short*)QKV; p.cos = (const unsigned short*)cos_t; p.sin = (const unsigned short*)sin_t;
+    p.kc = (unsigned short*)kcache; p.vc = (unsigned short*)vcache; p.valid = (unsigned char*)valid; p.pos = (const long long*)pos;
+    p.out = (unsigned short*)out; p.T = T; p.H = H; p.KVH = KVH; p.Lc = Lc; p.s_qkv = s_qkv; p.s_out = s_out;
+    p.scale = 1.0f / sqrtf((float)head_dim);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)(T * KVH));
+#define BD_ATT(DT, GG) hipLaunchKernelGGL((decode_attn_kernel<DT, GG>), grid, dim3(256), 0, st, p)
+    if (dtype == BD_BF16) { if (G == 1) BD_ATT(DT_BF16, 1); else BD_ATT(DT_BF16, 4); }
+    else { if (G == 1) BD_ATT(DT_F16, 1); else BD_ATT(DT_F16, 4); }
+#undef BD_ATT
     return launch_status();
 }
 

@@ -61,6 +61,10 @@ struct StreamParams {
     uint32_t x_bytes, w_bytes, p_bytes;     // descriptor extents (bytes from the base pointers)
     // per-tenant dense weights (bd_tenant_linear: NM = 0, gridDim.y = tenants): element offsets of tenant blockIdx.y
     long long sXt, sWt, sCt;
+    // sign-word addressing, in words:  word(row i, column n) = P[(n >> 4) * pts + i * prs + (n & 15)]
+    //   reference layout [K/32, N]:            pts = 16,          prs = N
+    //   tile-major layout [N/16, K/32, 16]:    pts = 16 * K/32,   prs = 16   (a 16-column tile's words are one contiguous run over k)
+    uint32_t pts, prs;
 };
 
 // NW = waves per block (8: two per SIMD, 256 VGPRs each; 4: one per SIMD, the whole register file, deeper prefetch).
@@ -69,8 +73,10 @@ struct StreamParams {
 //   exactly one instruction); the sign operand keeps the word-row order (a lane's word is 32 consecutive k), which needs its own
 //   activation fragments: x is loaded in both orders (L2 hits).  WNAT = 0: one activation fragment set, W in the word-row order
 //   (each W instruction touches 64 sectors and uses 16 bytes of each; the 4 instructions of a stage complete them).
-// AUX = cache policy of the weight / sign streams (2 = nt, 0 = default).
-template <int DT, int NM, bool HASW, int NS, int NW = 8, int WNAT = 0, int AUX = 2>
+// AUX = cache policy of the weight / sign streams (0 = default, 2 = nt).  Measured (profiles/r02_decode_stream_ab.txt): with the
+//   word-row order nt costs 35 % of the pure weight stream (3.4 vs 5.2 TB/s at 235 MB): the 4 load instructions of a stage each
+//   use 16 bytes of the same 64-byte sectors, and a non-temporal line does not stay in L1 for the next one.
+template <int DT, int NM, bool HASW, int NS, int NW = 8, int WNAT = 0, int AUX = 0>
 __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams sp) {
     GemvParams p = sp.g;
     if constexpr (NM == 0) {       // blockIdx.y = tenant: its own activation rows, weight matrix and output rows
@@ -147,7 +153,8 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
 #pragma unroll
             for (int s = 0; s < 4; ++s) st.wf[s] = buf_load16<AUX>(rw, wo + 16u * s);
         }
-        [[maybe_unused]] const uint32_t po = (krow_ok && col_ok) ? ((uint32_t)irow * (uint32_t)p.N + (uint32_t)n) * 4u : STREAM_OOB;
+        [[maybe_unused]] const uint32_t po =
+            (krow_ok && col_ok) ? ((uint32_t)(n >> 4) * sp.pts + (uint32_t)irow * sp.prs + (uint32_t)(n & 15)) * 4u : STREAM_OOB;
 #pragma unroll
         for (int t = 0; t < NM; ++t) {
             const uint32_t tb = (uint32_t)(min(t, nmask - 1)) * (uint32_t)p.sPb * 4u;

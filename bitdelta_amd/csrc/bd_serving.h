@@ -1,0 +1,202 @@
+// Decode-step glue of the multi-tenant serving loop (demo/demo_backend.py:190-258 is the loop, the HF
+// Llama / Mistral decoder layer is what it calls between two of the reference's Linears).  These three kernels are NOT the hot
+// path -- they move a few hundred KB per layer -- but at decode every torch op is a launch, and a layer written with stock ops is
+// ~30 launches around 4 weight-streaming Linears.  HBM/latency-bound, elementwise or tiny reductions; fp32 math, results rounded
+// where the torch ops they replace round (noted per kernel), so they are compared against those ops in tests/test_gpu_serving.py.
+//
+//   rmsnorm_tenant_kernel   y[r] = w[tenant(r)] * round16(x[r] * rsqrt(mean(x[r]^2) + eps))        (HF RMSNorm, per-tenant weight)
+//   swiglu_kernel           y = round16(silu(g)) * u     from the fused gate|up output               (HF MLP act_fn(gate) * up)
+//   decode_attn_kernel      RoPE(q, k_new) -> KV-cache append -> softmax(q.K^T / sqrt(d)) . V        one new token per tenant, GQA
+#pragma once
+#include "bd_common.h"
+
+namespace bd {
+
+template <int DT> __device__ __forceinline__ float round16(float v) { return half_bits_to_f32<DT>(f32_to_half_bits<DT>(v)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// one block (256 threads) per row; H % 8 == 0
+template <int DT>
+__global__ void __launch_bounds__(256) rmsnorm_tenant_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
+                                                             unsigned short* __restrict__ y, int H, long long sx, long long sy,
+                                                             long long sw, int rows_per_tenant, float eps) {
+    __shared__ float part[4];
+    const int r = blockIdx.x, t = r / rows_per_tenant;
+    const unsigned short* xr = x + (long long)r * sx;
+    const unsigned short* wr = w + (long long)t * sw;
+    unsigned short* yr = y + (long long)r * sy;
+    float ss = 0.f;
+    for (int c = threadIdx.x * 8; c < H; c += 256 * 8) {
+        const u32x4_t v = *(const u32x4_t*)(xr + c);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const float a = half_bits_to_f32<DT>(v[d] & 0xffffu), b = half_bits_to_f32<DT>(v[d] >> 16);
+            ss += a * a + b * b;
+        }
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float rs = rsqrtf((part[0] + part[1] + part[2] + part[3]) / (float)H + eps);
+    for (int c = threadIdx.x * 8; c < H; c += 256 * 8) {
+        const u32x4_t v = *(const u32x4_t*)(xr + c), g = *(const u32x4_t*)(wr + c);
+        u32x4_t o;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const float a = round16<DT>(half_bits_to_f32<DT>(v[d] & 0xffffu) * rs), b = round16<DT>(half_bits_to_f32<DT>(v[d] >> 16) * rs);
+            const uint32_t lo = f32_to_half_bits<DT>(a * half_bits_to_f32<DT>(g[d] & 0xffffu));
+            const uint32_t hi = f32_to_half_bits<DT>(b * half_bits_to_f32<DT>(g[d] >> 16));
+            o[d] = lo | (hi << 16);
+        }
+        *(u32x4_t*)(yr + c) = o;
+    }
+}
+
+// gu [rows, 2*I] (gate columns then up columns, row stride sg) -> y [rows, I];  I % 8 == 0
+template <int DT>
+__global__ void __launch_bounds__(256) swiglu_kernel(const unsigned short* __restrict__ gu, unsigned short* __restrict__ y, int I,
+                                                     long long sg, long long sy) {
+    const int r = blockIdx.y;
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (c >= I) return;
+    const u32x4_t g = *(const u32x4_t*)(gu + (long long)r * sg + c), u = *(const u32x4_t*)(gu + (long long)r * sg + I + c);
+    u32x4_t o;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        float a = half_bits_to_f32<DT>(g[d] & 0xffffu), b = half_bits_to_f32<DT>(g[d] >> 16);
+        a = round16<DT>(a / (1.f + __expf(-a)));
+        b = round16<DT>(b / (1.f + __expf(-b)));
+        const uint32_t lo = f32_to_half_bits<DT>(a * half_bits_to_f32<DT>(u[d] & 0xffffu));
+        const uint32_t hi = f32_to_half_bits<DT>(b * half_bits_to_f32<DT>(u[d] >> 16));
+        o[d] = lo | (hi << 16);
+    }
+    *(u32x4_t*)(y + (long long)r * sy + c) = o;
+}
+
+struct AttnParams {
+    const unsigned short* qkv;     // [T, (H + 2*KVH) * 128]: q heads, then k heads, then v heads (the fused q+k+v Linear's output row)
+    const unsigned short* cos;     // [Lmax, 128] RoPE tables in the activation dtype, rotate-half sign folded into `sin`
+    const unsigned short* sin;
+    unsigned short* kc;            // KV cache [T, KVH, Lc, 128]
+    unsigned short* vc;
+    unsigned char* valid;          // [T, Lc] key-validity bytes (left padding = 0); the new position is set here
+    const long long* pos;          // device scalar: cache position of the new token
+    unsigned short* out;           // [T, H * 128]
+    int T, H, KVH, Lc;
+    long long s_qkv, s_out;        // row strides (elements)
+    float scale;                   // 1 / sqrt(head_dim)
+};
+
+// One block (4 waves) per (tenant, kv head): its G = H / KVH query heads share the K / V stream.  Lane (kq = l >> 4, d8 = l & 15)
+// reads 16 bytes (dims 8*d8 .. +7) of key / value row l0 + kq, so a wave instruction covers 4 whole 256-byte rows; the 4 waves
+// take rows 4*wave + kq + 16*j.  Online softmax per head in fp32; the partial (max, sum, acc) of the 16 row slots are merged through
+// LDS at the end.  head_dim = 128, G <= 8.
+template <int DT, int G>
+__global__ void __launch_bounds__(256) decode_attn_kernel(const AttnParams p) {
+    constexpr int HD = 128;
+    __shared__ float q_lds[G][HD];              // rotated, pre-scaled queries
+    __shared__ float kn_lds[HD], vn_lds[HD];    // the new token's rotated key / value (also written to the cache)
+    __shared__ float m_lds[16][G], s_lds[16][G];
+    __shared__ float a_lds[16][G][HD];
+    const int t = blockIdx.x / p.KVH, kvh = blockIdx.x % p.KVH;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long pos = *p.pos;
+    const unsigned short* row = p.qkv + (long long)t * p.s_qkv;
+    const unsigned short* cs = p.cos + pos * HD;
+    const unsigned short* sn = p.sin + pos * HD;
+    unsigned short* kbase = p.kc + ((long long)t * p.KVH + kvh) * p.Lc * HD;
+    unsigned short* vbase = p.vc + ((long long)t * p.KVH + kvh) * p.Lc * HD;
+    // ---- phase 0: RoPE of the G query heads and of the new key (torch: round16(round16(x*cos) + rot*sin)), cache append
+    auto rope = [&](const unsigned short* v, int d) {
+        const float x = half_bits_to_f32<DT>(v[d]), xr = half_bits_to_f32<DT>(v[d < HD / 2 ? d + HD / 2 : d - HD / 2]);
+        const float a = round16<DT>(x * half_bits_to_f32<DT>(cs[d]));
+        return round16<DT>(a + xr * half_bits_to_f32<DT>(sn[d]));
+    };
+    for (int i = threadIdx.x; i < G * HD; i += 256) {
+        const int g = i / HD, d = i % HD;
+        q_lds[g][d] = rope(row + (long long)(kvh * G + g) * HD, d) * p.scale;
+    }
+    if (threadIdx.x < HD) {
+        const int d = threadIdx.x;
+        const float kr = rope(row + (long long)(p.H + kvh) * HD, d);
+        const unsigned short vv = row[(long long)(p.H + p.KVH + kvh) * HD + d];
+        kn_lds[d] = kr;
+        vn_lds[d] = half_bits_to_f32<DT>(vv);
+        kbase[pos * HD + d] = (unsigned short)f32_to_half_bits<DT>(kr);
+        vbase[pos * HD + d] = vv;
+        if (d == 0 && kvh == 0) p.valid[(long long)t * p.Lc + pos] = 1;
+    }
+    __syncthreads();
+    const int kq = lane >> 4, d8 = lane & 15;
+    float q[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q[g][e] = q_lds[g][8 * d8 + e];
+    float m[G], s[G], acc[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        m[g] = -1e30f; s[g] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
+    }
+    const unsigned char* vld = p.valid + (long long)t * p.Lc;
+    const int slot = 4 * wave + kq;                      // this lane group's row slot (0..15)
+    for (long long l = slot; l <= pos; l += 16) {
+        const bool ok = (l == pos) || vld[l] != 0;
+        float kf[8], vf[8];
+        if (l == pos) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { kf[e] = kn_lds[8 * d8 + e]; vf[e] = vn_lds[8 * d8 + e]; }
+        } else {
+            const u32x4_t kk = *(const u32x4_t*)(kbase + l * HD + 8 * d8), vv = *(const u32x4_t*)(vbase + l * HD + 8 * d8);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                kf[2 * d] = half_bits_to_f32<DT>(kk[d] & 0xffffu); kf[2 * d + 1] = half_bits_to_f32<DT>(kk[d] >> 16);
+                vf[2 * d] = half_bits_to_f32<DT>(vv[d] & 0xffffu); vf[2 * d + 1] = half_bits_to_f32<DT>(vv[d] >> 16);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float sc = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sc += q[g][e] * kf[e];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sc += __shfl_xor(sc, o, 64);          // over the 16 lanes of this row
+            if (!ok) continue;                                                       // masked key (uniform within the 16 lanes)
+            const float mn = fmaxf(m[g], sc), f = __expf(m[g] - mn), pw = __expf(sc - mn);
+            s[g] = s[g] * f + pw;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[g][e] = acc[g][e] * f + pw * vf[e];
+            m[g] = mn;
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (d8 == 0) { m_lds[slot][g] = m[g]; s_lds[slot][g] = s[g]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a_lds[slot][g][8 * d8 + e] = acc[g][e];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < G * HD; i += 256) {
+        const int g = i / HD, d = i % HD;
+        float mm = -1e30f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) mm = fmaxf(mm, m_lds[j][g]);
+        float ssum = 0.f, a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float f = __expf(m_lds[j][g] - mm);
+            ssum += s_lds[j][g] * f;
+            a += a_lds[j][g][d] * f;
+        }
+        p.out[(long long)t * p.s_out + (long long)(kvh * G + g) * HD + d] = (unsigned short)f32_to_half_bits<DT>(a / ssum);
+    }
+}
+
+}  // namespace bd

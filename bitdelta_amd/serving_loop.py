@@ -23,8 +23,9 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .binary_gemm_kernel import binary_linear, tenant_linear
+from .binary_gemm_kernel import binary_linear, binary_linear_decode, decode_shape_ok, tenant_linear, tile_masks
 from .diff import binarize
+from . import serving_ops as ops
 
 MODEL_CONFIGS = {
     # name: (hidden, intermediate, layers, heads, kv_heads, vocab)
@@ -32,6 +33,7 @@ MODEL_CONFIGS = {
     "mistral-7b": (4096, 14336, 32, 32, 8, 32000),
     "llama-2-70b": (8192, 28672, 80, 64, 8, 32000),
     "tiny": (256, 512, 2, 4, 2, 512),
+    "tiny128": (512, 1024, 2, 4, 1, 512),        # head_dim 128, 4 query heads per kv head: exercises the decode glue kernels
 }
 
 MAX_PROMPT = 1024      # demo/demo_backend.py:300-302
@@ -59,8 +61,14 @@ class FusedDeltaLinear(nn.Module):
         alpha = torch.cat([c.float().reshape(-1, 1).expand(-1, n // gsz) for c, n in zip(coeffs, widths)], 1)
         self.register_buffer("alpha", alpha.contiguous())                                        # [T, G]
         self.groups = alpha.shape[1]
+        # decode copy of the sign words in the streaming kernel's tile-major order (prefill keeps the reference layout)
+        self.register_buffer("mask_tiled", tile_masks(self.mask))
 
     def forward(self, x, residual=None):
+        B, M, K = x.shape
+        if decode_shape_ok(B, M, self.weight.shape[0], K, self.mask.shape[0]) and x.data_ptr() % 16 == 0 and \
+                x.stride(0) % 8 == 0 and x.stride(1) % 8 == 0:
+            return binary_linear_decode(x, self.weight, self.mask_tiled, self.alpha, groups=self.groups, residual=residual)
         return binary_linear(x, self.weight, self.mask, self.alpha, groups=self.groups, residual=residual)
 
     def linear_bytes(self):
@@ -103,6 +111,7 @@ class TenantDecoder(nn.Module):
         self.register_buffer("cos", cos, persistent=False)
         self.register_buffer("sin", sin, persistent=False)
         self._graph = None
+        self.fast_glue = True       # decode steps use the HIP glue kernels (serving_ops); False = stock torch ops everywhere
 
     # ---------------------------------------------------------------- construction
     @classmethod
@@ -172,28 +181,38 @@ class TenantDecoder(nn.Module):
                 "valid": torch.zeros(self.T, length, dtype=torch.bool, device=self.dev)}
 
     def _norm(self, x, w):
+        if x.shape[1] <= 16 and self.fast_glue and x.shape[-1] % 8 == 0:
+            return ops.rmsnorm_tenant(x if x.is_contiguous() else x.contiguous(), w, self.eps)
         return F.rms_norm(x, (x.shape[-1],), None, self.eps) * w[:, None, :]
 
     def _layer(self, layer, x, cos, sin, cache, li, pos_idx, attn_mask):
         T, S, hid = x.shape
-        _, _, _, heads, kvh, _ = self.cfg
+        _, inter, _, heads, kvh, _ = self.cfg
         hd = self.hd
         h = self._norm(x, layer.norm1)
         qkv = layer.qkv(h)
-        q, k, v = qkv.split(layer.qkv.widths, dim=-1)
-        q = _rope(q.view(T, S, heads, hd).transpose(1, 2), cos, sin)
-        k = _rope(k.view(T, S, kvh, hd).transpose(1, 2), cos, sin)
-        v = v.view(T, S, kvh, hd).transpose(1, 2)
         ck, cv = cache["k"][li], cache["v"][li]
-        ck.index_copy_(2, pos_idx, k)
-        cv.index_copy_(2, pos_idx, v)
-        a = F.scaled_dot_product_attention(q, ck, cv, attn_mask=attn_mask, enable_gqa=(kvh != heads))
-        a = a.transpose(1, 2).reshape(T, S, heads * hd)
+        if S == 1 and self.fast_glue and ops.decode_attention_supported(heads, kvh, hd):
+            # decode: RoPE + cache append + attention over the valid keys in ONE launch (pos_idx is a one-element device tensor)
+            a = ops.decode_attention(qkv, self.cos, self.sin, ck, cv, cache["valid"], pos_idx, heads, kvh)
+        else:
+            q, k, v = qkv.split(layer.qkv.widths, dim=-1)
+            q = _rope(q.view(T, S, heads, hd).transpose(1, 2), cos, sin)
+            k = _rope(k.view(T, S, kvh, hd).transpose(1, 2), cos, sin)
+            v = v.view(T, S, kvh, hd).transpose(1, 2)
+            ck.index_copy_(2, pos_idx, k)
+            cv.index_copy_(2, pos_idx, v)
+            a = F.scaled_dot_product_attention(q, ck, cv, attn_mask=attn_mask, enable_gqa=(kvh != heads))
+            a = a.transpose(1, 2).reshape(T, S, heads * hd)
         x = layer.o(a, residual=x)
         h = self._norm(x, layer.norm2)
         gu = layer.gate_up(h)
-        g, u = gu.split(layer.gate_up.widths, dim=-1)
-        x = layer.down(F.silu(g) * u, residual=x)
+        if S <= 16 and self.fast_glue and inter % 8 == 0:
+            act = ops.swiglu(gu, inter)
+        else:
+            g, u = gu.split(layer.gate_up.widths, dim=-1)
+            act = F.silu(g) * u
+        x = layer.down(act, residual=x)
         return x
 
     @torch.no_grad()

@@ -1,0 +1,53 @@
+"""ctypes wrappers of the decode-step glue kernels (csrc/bd_serving.h): per-tenant RMSNorm, SwiGLU on the fused gate|up output,
+and single-token attention with RoPE + KV-cache append.  Callers of the hot path, used by serving_loop.TenantDecoder at decode;
+each has a stock-torch equivalent in that module (used at prefill and as the test reference)."""
+import torch
+
+from ._lib import DTYPE_CODE, check, lib, ptr, require_gpu, stream_ptr
+
+
+def rmsnorm_tenant(x, w, eps):
+    """x [T, M, H], w [T, H] -> w[t] * round(x * rsqrt(mean(x^2) + eps))   (HF RMSNorm, tenant t's weight for row block t)"""
+    require_gpu(x, w)
+    T, M, H = x.shape
+    assert w.shape == (T, H) and w.dtype == x.dtype and x.stride(2) == 1 and w.stride(1) == 1
+    assert x.stride(0) == M * x.stride(1), "rows must be evenly strided"
+    y = torch.empty((T, M, H), device=x.device, dtype=x.dtype)
+    with torch.cuda.device(x.device):
+        check(lib().bd_srv_rmsnorm(ptr(x), ptr(w), ptr(y), T * M, H, x.stride(1), H, w.stride(0), M, float(eps),
+                                   DTYPE_CODE[x.dtype], stream_ptr()), "srv_rmsnorm")
+    return y
+
+
+def swiglu(gu, inter):
+    """gu [T, M, 2*inter] (gate columns, then up columns) -> round(silu(gate)) * up, [T, M, inter]"""
+    require_gpu(gu)
+    T, M, W = gu.shape
+    assert W == 2 * inter and gu.stride(2) == 1 and gu.stride(0) == M * gu.stride(1)
+    y = torch.empty((T, M, inter), device=gu.device, dtype=gu.dtype)
+    with torch.cuda.device(gu.device):
+        check(lib().bd_srv_swiglu(ptr(gu), ptr(y), T * M, inter, gu.stride(1), inter, DTYPE_CODE[gu.dtype], stream_ptr()),
+              "srv_swiglu")
+    return y
+
+
+def decode_attention(qkv, cos, sin, kcache, vcache, valid, pos, heads, kv_heads):
+    """One new token per tenant.  qkv [T, 1, (heads + 2 kv_heads) * 128]; cos / sin [Lmax, 128]; caches [T, kv_heads, Lc, 128];
+    valid [T, Lc] bool; pos: int64 device tensor with one element.  Returns [T, 1, heads * 128]; the caches and valid[:, pos] are
+    updated in place."""
+    require_gpu(qkv, cos, sin, kcache, vcache, valid, pos)
+    T = qkv.shape[0]
+    hd = kcache.shape[3]
+    assert qkv.shape[1] == 1 and qkv.shape[2] == (heads + 2 * kv_heads) * hd and qkv.stride(2) == 1
+    assert kcache.is_contiguous() and vcache.is_contiguous() and valid.is_contiguous() and valid.dtype == torch.bool
+    assert cos.is_contiguous() and sin.is_contiguous() and cos.dtype == qkv.dtype and pos.dtype == torch.int64
+    out = torch.empty((T, 1, heads * hd), device=qkv.device, dtype=qkv.dtype)
+    with torch.cuda.device(qkv.device):
+        check(lib().bd_srv_decode_attention(ptr(qkv), ptr(cos), ptr(sin), ptr(kcache), ptr(vcache), ptr(valid), ptr(pos), ptr(out),
+                                            T, heads, kv_heads, hd, kcache.shape[2], qkv.stride(0), out.stride(0),
+                                            DTYPE_CODE[qkv.dtype], stream_ptr()), "srv_decode_attention")
+    return out
+
+
+def decode_attention_supported(heads, kv_heads, head_dim):
+    return head_dim == 128 and heads % kv_heads == 0 and heads // kv_heads in (1, 4)

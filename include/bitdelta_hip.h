@@ -80,6 +80,17 @@ int bd_binary_linear(const void* X, const void* W, const int32_t* P, const float
                      int64_t sYb, int64_t sYm, int dtype, int out_dtype,
                      void* ws, int64_t ws_bytes, void* stream);
 
+/* decode form of the fused Linear with the sign words in TILE-MAJOR order: P_tiled int32 [B or 1, ceil(N/16), K/32, 16]
+ * (word (i, n) of the reference layout sits at [n / 16][i][n % 16]; columns past N are zero padding; sPb = tenant stride in words,
+ * 0 broadcasts).  A 16-column MFMA tile then reads its sign words as one contiguous run over k instead of 64-byte pieces of
+ * N*4-byte rows -- the serving side repacks a tenant's masks once when it registers them (diff.pt keeps the reference layout).
+ * Streaming decode kernel only: B*M rows in chunks of <= 16, M <= 16, N >= 512, <= 8 masks per chunk, else BD_E_BAD_SHAPE.
+ * accumulate = 1 adds onto Y (residual epilogue).  Needs no workspace. */
+int bd_binary_linear_decode(const void* X, const void* W, const int32_t* P_tiled, const float* alpha, void* Y,
+                            int B, int M, int N, int K,
+                            int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb, int64_t sAlb, int G,
+                            int64_t sYb, int64_t sYm, int dtype, int out_dtype, int accumulate, void* stream);
+
 /* the same Linear with the residual connection folded into its epilogue:  Y[b] = Y_in[b] + X[b] . W^T + alpha * (X[b] . S[b])
  * (fp32 sum, one rounding) -- the `hidden = residual + o_proj(...)` / `+ down_proj(...)` of the decoder layers that call the
  * reference's modules.  Decode shapes only (B*M <= 64 rows, M <= 16: where the add would otherwise be a launch of its own);
@@ -98,6 +109,22 @@ int bd_binary_linear_residual(const void* X, const void* W, const int32_t* P, co
 int bd_tenant_linear(const void* X, const void* W, void* Y, int T, int M, int N, int K,
                      int64_t sXt, int64_t sXm, int64_t sWt, int64_t ldw, int64_t sYt, int64_t sYm,
                      int dtype, int out_dtype, void* stream);
+
+/* ---- decode-step glue of the multi-tenant serving loop (callers of the path, demo/demo_backend.py:190-258 + the HF decoder layer
+ * between two of the reference's Linears).  Not the hot path: they exist because at decode every stock op is a launch.
+ * bd_srv_rmsnorm: Y[r] = Wt[r / rows_per_tenant] * round(X[r] * rsqrt(mean(X[r]^2) + eps))   (HF RMSNorm with per-tenant weights,
+ *   the DataParallelModule-wrapped norms of demo_backend.py:62-79); X, Y [rows, H] (strides sx, sy), Wt [tenants, H] (stride sw).
+ * bd_srv_swiglu:  Y = round(silu(G)) * U from the fused gate|up output GU [rows, 2*I] (row stride sg) -> Y [rows, I].
+ * bd_srv_decode_attention: one new token per tenant: RoPE of q and the new k (tables cos/sin [Lmax, 128], rotate-half sign folded
+ *   into sin), append k/v at *pos to the caches [T, KVH, Lc, 128], mark valid[t, *pos], then softmax(q.K^T/sqrt(128)).V over the
+ *   valid keys 0..*pos (left padding = 0 in valid [T, Lc] bytes), grouped-query (H/KVH in {1, 4}); QKV [T, (H+2*KVH)*128] is the
+ *   fused q+k+v Linear's output; out [T, H*128].  `pos` is a DEVICE scalar so the step replays inside a hipGraph. */
+int bd_srv_rmsnorm(const void* X, const void* Wt, void* Y, int rows, int H, int64_t sx, int64_t sy, int64_t sw,
+                   int rows_per_tenant, float eps, int dtype, void* stream);
+int bd_srv_swiglu(const void* GU, void* Y, int rows, int I, int64_t sg, int64_t sy, int dtype, void* stream);
+int bd_srv_decode_attention(const void* QKV, const void* cos_t, const void* sin_t, void* kcache, void* vcache, void* valid,
+                            const int64_t* pos, void* out, int T, int H, int KVH, int head_dim, int Lc,
+                            int64_t s_qkv, int64_t s_out, int dtype, void* stream);
 
 /* bytes of scratch bd_delta_bmm / bd_binary_linear may need for this problem (split-k partials of the decode path) */
 int64_t bd_gemm_workspace_bytes(int B, int M, int N, int K);

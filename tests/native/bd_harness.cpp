@@ -391,11 +391,29 @@ static void bits_bench() {
 // Decode timing with COLD weights: the same problem over `nset` device copies of W and P (nset * bytes > 2 x the 256 MB Infinity
 // Cache), launched round-robin, so every launch streams its weights from HBM as a decode step of a real model does.  (run_case's
 // loop re-reads one 46 MB problem from the Infinity Cache and flatters HBM-bound kernels.)  Prints warm and cold us per launch.
+static int g_tiled = 0;      // 1: decode calls go through bd_binary_linear_decode with tile-major sign words
+static int call_decode(const Problem& q) {
+    if (!g_tiled || !q.fused) return call_api(q, 0);
+    const int64_t sPb = q.tenants == 1 ? 0 : (int64_t)(q.K / 32) * ((q.N + 15) / 16 * 16);
+    return bd_binary_linear_decode(q.dA, q.dW, (const int32_t*)q.dP, (const float*)q.dAl, q.dC, q.B, q.M, q.N, q.K,
+                                   (int64_t)q.M * q.K, q.K, q.K, sPb, 1, 1, (int64_t)q.M * q.N, q.N, q.dt, q.out_dt, 0, 0);
+}
 static int run_decode_cold(const char* tag, int B, int M, int N, int K, int dt, int fused, int variant, int iters) {
     Problem q{B, M, N, K, dt, dt, fused, B};
     make_problem(q);
+    void* dP_ref = q.dP;
+    if (g_tiled && fused) {      // repack [T][K/32][N] -> [T][N/16][K/32][16] on the host (the host copy q.P keeps the reference order)
+        const int KW = K / 32, NT = (N + 15) / 16, T = (q.tenants == 1 ? 1 : B);
+        std::vector<uint32_t> tp((size_t)T * NT * KW * 16, 0u);
+        for (int t = 0; t < T; ++t)
+            for (int i = 0; i < KW; ++i)
+                for (int n = 0; n < N; ++n)
+                    tp[(((size_t)t * NT + (n >> 4)) * KW + i) * 16 + (n & 15)] = q.P[((size_t)t * KW + i) * N + n];
+        HIPCHECK(hipMalloc(&q.dP, tp.size() * 4));
+        HIPCHECK(hipMemcpy(q.dP, tp.data(), tp.size() * 4, hipMemcpyHostToDevice));
+    }
     bd_set_gemm_variant(variant);
-    int rc = call_api(q, 0);
+    int rc = call_decode(q);
     hipError_t herr = hipDeviceSynchronize();
     const int used = bd_last_gemm_variant();
     int bad = -1;
@@ -405,8 +423,8 @@ static int run_decode_cold(const char* tag, int B, int M, int N, int K, int dt, 
         HIPCHECK(hipMemcpy(hC.data(), q.dC, hC.size(), hipMemcpyDeviceToHost));
         bad = check_output(q, hC.data(), 2048, &max_err, &max_ulp);
     }
-    const double wbytes = fused ? 2.0 * N * K : 0.0, pbytes = (double)B * K * N / 8;
-    const double bytes = 2.0 * B * M * K + pbytes + 2.0 * B * M * N + wbytes;
+    const double wbytes = fused ? 2.0 * N * K : 0.0, pbytes = (double)B * K * ((g_tiled && fused) ? (N + 15) / 16 * 16 : N) / 8;
+    const double bytes = 2.0 * B * M * K + (double)B * K * N / 8 + 2.0 * B * M * N + wbytes;
     int nset = (int)(600e6 / (wbytes + pbytes)) + 1;
     if (nset < 2) nset = 2;
     if (nset > 24) nset = 24;
@@ -417,10 +435,10 @@ static int run_decode_cold(const char* tag, int B, int M, int N, int K, int dt, 
     }
     double warm = 0, cold = 0;
     if (rc == 0 && herr == hipSuccess && bad == 0) {
-        warm = time_ms([&] { call_api(q, 0); }, 5, iters) * 1e3;
+        warm = time_ms([&] { call_decode(q); }, 5, iters) * 1e3;
         int idx = 0;
         Problem c = q;
-        cold = time_ms([&] { c.dW = Ws[idx]; c.dP = Ps[idx]; idx = (idx + 1) % nset; call_api(c, 0); }, nset, iters) * 1e3;
+        cold = time_ms([&] { c.dW = Ws[idx]; c.dP = Ps[idx]; idx = (idx + 1) % nset; call_decode(c); }, nset, iters) * 1e3;
     }
     printf("{\"tag\":\"%s\",\"B\":%d,\"M\":%d,\"N\":%d,\"K\":%d,\"dt\":\"%s\",\"fused\":%d,\"variant\":%d,\"used\":%d,\"rc\":%d,"
            "\"bad\":%d,\"max_ulp\":%.3g,\"MB\":%.1f,\"nset\":%d,\"warm_us\":%.2f,\"warm_gbps\":%.0f,\"cold_us\":%.2f,\"cold_gbps\":%.0f}\n",
@@ -429,6 +447,7 @@ static int run_decode_cold(const char* tag, int B, int M, int N, int K, int dt, 
     fflush(stdout);
     bd_set_gemm_variant(-1);
     for (int i = 0; i < nset; ++i) { if (Ws[i]) hipFree(Ws[i]); hipFree(Ps[i]); }
+    if (q.dP != dP_ref) { hipFree(q.dP); q.dP = dP_ref; }
     free_problem(q);
     if (herr != hipSuccess) exit(3);
     return (rc != 0 || bad != 0) ? 1 : 0;
@@ -672,16 +691,27 @@ int main(int argc, char** argv) {
         }
     } else if (mode == "stream_ab") {
         // A/B matrix of the streaming decode kernel (bd_set_stream_tuning: bit 0 natural-order W, bit 1 default cache policy, bit 2
-        // 4-wave blocks, bit 3 deeper prefetch), cold weights.  First the pure weight stream (no sign operand), then T = 1 / 6.
-        for (int tune = 0; tune < 16; ++tune) {
+        // 4-wave blocks, bit 3 deeper prefetch) x sign-word layout (reference [K/32, N] vs tile-major), cold weights.
+        // argv[2] = list of tune codes (default: all 16)
+        std::vector<int> tunes;
+        if (argc > 2) { for (char* t = strtok(argv[2], ","); t; t = strtok(nullptr, ",")) tunes.push_back(atoi(t)); }
+        else for (int t = 0; t < 16; ++t) tunes.push_back(t);
+        for (int tune : tunes) {
             bd_set_stream_tuning(tune);
             char tg[64];
             snprintf(tg, sizeof tg, "ab%02d_stream_4096sq", tune);   fails += run_tenant_cold(tg, 1, 4096, 4096, 200);
             snprintf(tg, sizeof tg, "ab%02d_stream_28672", tune);    fails += run_tenant_cold(tg, 1, 28672, 4096, 60);
-            snprintf(tg, sizeof tg, "ab%02d_T1_4096sq", tune);       fails += run_decode_cold(tg, 1, 1, 4096, 4096, BD_F16, 1, 600, 200);
-            snprintf(tg, sizeof tg, "ab%02d_T6_4096sq", tune);       fails += run_decode_cold(tg, 6, 1, 4096, 4096, BD_F16, 1, 600, 200);
-            snprintf(tg, sizeof tg, "ab%02d_T6_gateup", tune);       fails += run_decode_cold(tg, 6, 1, 28672, 4096, BD_F16, 1, 600, 60);
-            snprintf(tg, sizeof tg, "ab%02d_T6_down", tune);         fails += run_decode_cold(tg, 6, 1, 4096, 14336, BD_F16, 1, 600, 60);
+            for (int tiled : {0, 1}) {
+                g_tiled = tiled;
+                const char* ly = tiled ? "tile" : "ref";
+                snprintf(tg, sizeof tg, "ab%02d_%s_T1_4096sq", tune, ly);    fails += run_decode_cold(tg, 1, 1, 4096, 4096, BD_F16, 1, 600, 200);
+                snprintf(tg, sizeof tg, "ab%02d_%s_T6_4096sq", tune, ly);    fails += run_decode_cold(tg, 6, 1, 4096, 4096, BD_F16, 1, 600, 200);
+                snprintf(tg, sizeof tg, "ab%02d_%s_T6_qkv", tune, ly);       fails += run_decode_cold(tg, 6, 1, 6144, 4096, BD_F16, 1, 600, 200);
+                snprintf(tg, sizeof tg, "ab%02d_%s_T6_gateup", tune, ly);    fails += run_decode_cold(tg, 6, 1, 28672, 4096, BD_F16, 1, 600, 60);
+                snprintf(tg, sizeof tg, "ab%02d_%s_T6_down", tune, ly);      fails += run_decode_cold(tg, 6, 1, 4096, 14336, BD_F16, 1, 600, 60);
+                snprintf(tg, sizeof tg, "ab%02d_%s_T4_4096sq", tune, ly);    fails += run_decode_cold(tg, 4, 1, 4096, 4096, BD_F16, 1, 600, 200);
+            }
+            g_tiled = 0;
         }
         bd_set_stream_tuning(0);
         fails += run_decode_cold("ref300_T6_4096sq", 6, 1, 4096, 4096, BD_F16, 1, 300, 200);
