@@ -29,7 +29,7 @@ static thread_local int g_gemv_wave_spec = 1;        // 1 = fused launches of th
 static thread_local int g_gemv_two_launch = 1;       // 1 (default) = split-k partials are summed by gemv_reduce_kernel; 0 = in-launch tickets
                                         // (measured slower: the last-arriver tail is serial inside every tile; bd_gemv.h)
 static thread_local int g_gemv_target_blocks = 512;
-static thread_local int g_stream_tune = 0;            // A/B hook (harness build): bit 0 = natural-order W, bit 1 = default cache policy, bit 2 = 4-wave blocks
+static thread_local int g_stream_tune = 0;            // A/B hook (harness build): bit 0 = natural-order W, bit 1 = nt cache policy, bit 2 = 8-wave blocks, bit 3 = deeper prefetch
 static thread_local int t_last_variant = -1;
 
 extern "C" int bd_version(void) { return 1; }
@@ -317,10 +317,11 @@ int launch_stream_inst(const StreamParams& sp, dim3 grid, hipStream_t st) {
     return BD_OK;
 }
 
-// NS8 = stages of loads in flight per wave (8-wave blocks); bounded by the 256-VGPR budget of two waves per SIMD.
-// Harness builds (-DBD_AB_VARIANTS) add the A/B matrix selected by bd_set_stream_tuning: bit 0 natural-order W, bit 1 default cache
-// policy, bit 2 4-wave blocks (one wave per SIMD, NS4 stages), bit 3 the deeper of two prefetch depths.
-template <int DT, int NM, bool HASW, int NS8>
+// Shipped configuration (profiles/r02_decode_stream_ab.txt): 4-wave blocks (one wave per SIMD, the whole register file: NS4 stages
+// of loads in flight per wave), word-row order for W, default cache policy.  Harness builds (-DBD_AB_VARIANTS) add the A/B matrix
+// selected by bd_set_stream_tuning: bit 0 natural-order W, bit 1 nt cache policy, bit 2 8-wave blocks (two waves per SIMD), bit 3 the
+// deeper of two prefetch depths.
+template <int DT, int NM, bool HASW, int NS4>
 int launch_stream_tuned(const StreamParams& sp, dim3 grid, hipStream_t st) {
 #ifdef BD_AB_VARIANTS
     if constexpr (DT == DT_F16 && HASW && (NM == 0 || NM == 1 || NM == 6)) {
@@ -328,15 +329,15 @@ int launch_stream_tuned(const StreamParams& sp, dim3 grid, hipStream_t st) {
         constexpr int A4 = NM == 6 ? 4 : 8, B4 = NM == 6 ? 6 : 12;         // 4-wave blocks
         switch (g_stream_tune & 15) {
 #define BD_T(code, NS, NW, WN, AX) case code: return launch_stream_inst<DT, NM, HASW, NS, NW, WN, AX>(sp, grid, st)
-            BD_T(0, A8, 8, 0, 2); BD_T(1, A8, 8, 1, 2); BD_T(2, A8, 8, 0, 0); BD_T(3, A8, 8, 1, 0);
-            BD_T(4, A4, 4, 0, 2); BD_T(5, A4, 4, 1, 2); BD_T(6, A4, 4, 0, 0); BD_T(7, A4, 4, 1, 0);
-            BD_T(8, B8, 8, 0, 2); BD_T(9, B8, 8, 1, 2); BD_T(10, B8, 8, 0, 0); BD_T(11, B8, 8, 1, 0);
-            BD_T(12, B4, 4, 0, 2); BD_T(13, B4, 4, 1, 2); BD_T(14, B4, 4, 0, 0); BD_T(15, B4, 4, 1, 0);
+            BD_T(0, A4, 4, 0, 0); BD_T(1, A4, 4, 1, 0); BD_T(2, A4, 4, 0, 2); BD_T(3, A4, 4, 1, 2);
+            BD_T(4, A8, 8, 0, 0); BD_T(5, A8, 8, 1, 0); BD_T(6, A8, 8, 0, 2); BD_T(7, A8, 8, 1, 2);
+            BD_T(8, B4, 4, 0, 0); BD_T(9, B4, 4, 1, 0); BD_T(10, B4, 4, 0, 2); BD_T(11, B4, 4, 1, 2);
+            BD_T(12, B8, 8, 0, 0); BD_T(13, B8, 8, 1, 0); BD_T(14, B8, 8, 0, 2); BD_T(15, B8, 8, 1, 2);
 #undef BD_T
         }
     }
 #endif
-    return launch_stream_inst<DT, NM, HASW, NS8>(sp, grid, st);
+    return launch_stream_inst<DT, NM, HASW, NS4, 4, 0, 0>(sp, grid, st);
 }
 
 template <int DT>
@@ -371,14 +372,14 @@ int launch_gemv_stream_chunk(const Problem& q) {
     sp.p_bytes = (uint32_t)(((int64_t)(nmask - 1) * q.sPb + (int64_t)(q.K / 32) * (q.mask_tiled ? (q.N + 15) / 16 * 16 : q.N)) * 4);
     int rc;
     // NS = stages of loads in flight per wave; bounded by the 256-VGPR budget of a 2-waves-per-SIMD block (hipcc spills beyond)
-#define BD_STREAM(NM, NS8) rc = q.W ? launch_stream_tuned<DT, NM, true, NS8>(sp, dim3(grid), q.st) \
-                                     : launch_stream_tuned<DT, NM, false, NS8>(sp, dim3(grid), q.st)
-    if (nmask <= 1) BD_STREAM(1, 4);
-    else if (nmask <= 2) BD_STREAM(2, 4);
-    else if (nmask <= 3) BD_STREAM(3, 2);
-    else if (nmask <= 4) BD_STREAM(4, 2);
-    else if (nmask <= 6) BD_STREAM(6, 2);
-    else BD_STREAM(8, 2);
+#define BD_STREAM(NM, NS4) rc = q.W ? launch_stream_tuned<DT, NM, true, NS4>(sp, dim3(grid), q.st) \
+                                     : launch_stream_tuned<DT, NM, false, NS4>(sp, dim3(grid), q.st)
+    if (nmask <= 1) BD_STREAM(1, 8);
+    else if (nmask <= 2) BD_STREAM(2, 6);
+    else if (nmask <= 3) BD_STREAM(3, 4);
+    else if (nmask <= 4) BD_STREAM(4, 4);
+    else if (nmask <= 6) BD_STREAM(6, 4);
+    else BD_STREAM(8, 4);
 #undef BD_STREAM
     if (rc != BD_OK) return rc;
     return launch_status();
@@ -847,8 +848,8 @@ extern "C" int bd_tenant_linear(const void* X, const void* W, void* Y, int T, in
     sp.cpb = cpb;
     dim3 grid((unsigned)((N + cpb - 1) / cpb), (unsigned)T);
     hipStream_t st = (hipStream_t)stream;
-    const int rc = dtype == BD_BF16 ? launch_stream_tuned<DT_BF16, 0, true, 4>(sp, grid, st)
-                                    : launch_stream_tuned<DT_F16, 0, true, 4>(sp, grid, st);
+    const int rc = dtype == BD_BF16 ? launch_stream_tuned<DT_BF16, 0, true, 8>(sp, grid, st)
+                                    : launch_stream_tuned<DT_F16, 0, true, 8>(sp, grid, st);
     if (rc != BD_OK) return rc;
     return launch_status();
 }
@@ -903,7 +904,7 @@ extern "C" int bd_srv_decode_attention(const void* QKV, const void* cos_t, const
     p.scale = 1.0f / sqrtf((float)head_dim);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)(T * KVH));
-#define BD_ATT(DT, GG) hipLaunchKernelGGL((decode_attn_kernel<DT, GG>), grid, dim3(256), 0, st, p)
+#define BD_ATT(DT, GG) hipLaunchKernelGGL((decode_attn_kernel<DT, GG>), grid, dim3(1024), 0, st, p)
     if (dtype == BD_BF16) { if (G == 1) BD_ATT(DT_BF16, 1); else BD_ATT(DT_BF16, 4); }
     else { if (G == 1) BD_ATT(DT_F16, 1); else BD_ATT(DT_F16, 4); }
 #undef BD_ATT

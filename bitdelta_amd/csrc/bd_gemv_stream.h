@@ -76,7 +76,7 @@ struct StreamParams {
 // AUX = cache policy of the weight / sign streams (0 = default, 2 = nt).  Measured (profiles/r02_decode_stream_ab.txt): with the
 //   word-row order nt costs 35 % of the pure weight stream (3.4 vs 5.2 TB/s at 235 MB): the 4 load instructions of a stage each
 //   use 16 bytes of the same 64-byte sectors, and a non-temporal line does not stay in L1 for the next one.
-template <int DT, int NM, bool HASW, int NS, int NW = 8, int WNAT = 0, int AUX = 0>
+template <int DT, int NM, bool HASW, int NS, int NW = 4, int WNAT = 0, int AUX = 0>
 __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams sp) {
     GemvParams p = sp.g;
     if constexpr (NM == 0) {       // blockIdx.y = tenant: its own activation rows, weight matrix and output rows

@@ -92,17 +92,18 @@ struct AttnParams {
     float scale;                   // 1 / sqrt(head_dim)
 };
 
-// One block (4 waves) per (tenant, kv head): its G = H / KVH query heads share the K / V stream.  Lane (kq = l >> 4, d8 = l & 15)
-// reads 16 bytes (dims 8*d8 .. +7) of key / value row l0 + kq, so a wave instruction covers 4 whole 256-byte rows; the 4 waves
-// take rows 4*wave + kq + 16*j.  Online softmax per head in fp32; the partial (max, sum, acc) of the 16 row slots are merged through
-// LDS at the end.  head_dim = 128, G <= 8.
+// One block of 16 waves per (tenant, kv head): its G = H / KVH query heads share the K / V stream.  Lane (kq = l >> 4, d8 = l & 15)
+// reads 16 bytes (dims 8*d8 .. +7) of key / value row l0 + kq, so a wave instruction covers 4 whole 256-byte rows and the block 64
+// rows per iteration (a 512-token cache is 8 iterations); the next iteration's rows are in flight while the current ones are
+// scored.  Online softmax per head in fp32; the 4 row slots of a wave are merged with lane shuffles, the 16 waves through LDS.
+// head_dim = 128, G in {1, 4}.  (The first version ran 4 waves with no prefetch: 32 dependent HBM round trips per layer.)
 template <int DT, int G>
-__global__ void __launch_bounds__(256) decode_attn_kernel(const AttnParams p) {
-    constexpr int HD = 128;
+__global__ void __launch_bounds__(1024) decode_attn_kernel(const AttnParams p) {
+    constexpr int HD = 128, NWV = 16;
     __shared__ float q_lds[G][HD];              // rotated, pre-scaled queries
     __shared__ float kn_lds[HD], vn_lds[HD];    // the new token's rotated key / value (also written to the cache)
-    __shared__ float m_lds[16][G], s_lds[16][G];
-    __shared__ float a_lds[16][G][HD];
+    __shared__ float m_lds[NWV][G], s_lds[NWV][G];
+    __shared__ float a_lds[NWV][G][HD];
     const int t = blockIdx.x / p.KVH, kvh = blockIdx.x % p.KVH;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long pos = *p.pos;
@@ -111,28 +112,43 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const AttnParams p) {
     const unsigned short* sn = p.sin + pos * HD;
     unsigned short* kbase = p.kc + ((long long)t * p.KVH + kvh) * p.Lc * HD;
     unsigned short* vbase = p.vc + ((long long)t * p.KVH + kvh) * p.Lc * HD;
+    const unsigned char* vld = p.valid + (long long)t * p.Lc;
+    const int kq = lane >> 4, d8 = lane & 15;
+    const int slot = 4 * wave + kq;                      // this lane group's row slot (0..63)
+
+    // first rows in flight before anything else (they do not depend on the new token)
+    auto load_row = [&](long long l, u32x4_t& kk, u32x4_t& vv, bool& ok) {
+        const bool in = l < pos;                          // row `pos` itself comes from LDS (it is being written by this block)
+        const long long lc = in ? l : 0;
+        kk = *(const u32x4_t*)(kbase + lc * HD + 8 * d8);
+        vv = *(const u32x4_t*)(vbase + lc * HD + 8 * d8);
+        ok = in && vld[lc] != 0;
+    };
+    u32x4_t kk, vv;
+    bool ok;
+    load_row(slot, kk, vv, ok);
+
     // ---- phase 0: RoPE of the G query heads and of the new key (torch: round16(round16(x*cos) + rot*sin)), cache append
     auto rope = [&](const unsigned short* v, int d) {
         const float x = half_bits_to_f32<DT>(v[d]), xr = half_bits_to_f32<DT>(v[d < HD / 2 ? d + HD / 2 : d - HD / 2]);
         const float a = round16<DT>(x * half_bits_to_f32<DT>(cs[d]));
         return round16<DT>(a + xr * half_bits_to_f32<DT>(sn[d]));
     };
-    for (int i = threadIdx.x; i < G * HD; i += 256) {
+    for (int i = threadIdx.x; i < G * HD; i += 1024) {
         const int g = i / HD, d = i % HD;
         q_lds[g][d] = rope(row + (long long)(kvh * G + g) * HD, d) * p.scale;
     }
-    if (threadIdx.x < HD) {
-        const int d = threadIdx.x;
+    if (threadIdx.x >= 1024 - HD) {                      // the last two waves (the first ones may be busy with the q heads)
+        const int d = threadIdx.x - (1024 - HD);
         const float kr = rope(row + (long long)(p.H + kvh) * HD, d);
-        const unsigned short vv = row[(long long)(p.H + p.KVH + kvh) * HD + d];
+        const unsigned short vn = row[(long long)(p.H + p.KVH + kvh) * HD + d];
         kn_lds[d] = kr;
-        vn_lds[d] = half_bits_to_f32<DT>(vv);
+        vn_lds[d] = half_bits_to_f32<DT>(vn);
         kbase[pos * HD + d] = (unsigned short)f32_to_half_bits<DT>(kr);
-        vbase[pos * HD + d] = vv;
+        vbase[pos * HD + d] = vn;
         if (d == 0 && kvh == 0) p.valid[(long long)t * p.Lc + pos] = 1;
     }
     __syncthreads();
-    const int kq = lane >> 4, d8 = lane & 15;
     float q[G][8];
 #pragma unroll
     for (int g = 0; g < G; ++g)
@@ -145,22 +161,7 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
     }
-    const unsigned char* vld = p.valid + (long long)t * p.Lc;
-    const int slot = 4 * wave + kq;                      // this lane group's row slot (0..15)
-    for (long long l = slot; l <= pos; l += 16) {
-        const bool ok = (l == pos) || vld[l] != 0;
-        float kf[8], vf[8];
-        if (l == pos) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { kf[e] = kn_lds[8 * d8 + e]; vf[e] = vn_lds[8 * d8 + e]; }
-        } else {
-            const u32x4_t kk = *(const u32x4_t*)(kbase + l * HD + 8 * d8), vv = *(const u32x4_t*)(vbase + l * HD + 8 * d8);
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                kf[2 * d] = half_bits_to_f32<DT>(kk[d] & 0xffffu); kf[2 * d + 1] = half_bits_to_f32<DT>(kk[d] >> 16);
-                vf[2 * d] = half_bits_to_f32<DT>(vv[d] & 0xffffu); vf[2 * d + 1] = half_bits_to_f32<DT>(vv[d] >> 16);
-            }
-        }
+    auto score_row = [&](const float (&kf)[8], const float (&vf)[8], bool valid_row) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             float sc = 0.f;
@@ -168,29 +169,69 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const AttnParams p) {
             for (int e = 0; e < 8; ++e) sc += q[g][e] * kf[e];
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) sc += __shfl_xor(sc, o, 64);          // over the 16 lanes of this row
-            if (!ok) continue;                                                       // masked key (uniform within the 16 lanes)
-            const float mn = fmaxf(m[g], sc), f = __expf(m[g] - mn), pw = __expf(sc - mn);
-            s[g] = s[g] * f + pw;
+            if (valid_row) {                                                         // uniform within the 16 lanes
+                const float mn = fmaxf(m[g], sc), f = __expf(m[g] - mn), pw = __expf(sc - mn);
+                s[g] = s[g] * f + pw;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[g][e] = acc[g][e] * f + pw * vf[e];
+                for (int e = 0; e < 8; ++e) acc[g][e] = acc[g][e] * f + pw * vf[e];
+                m[g] = mn;
+            }
+        }
+    };
+    const long long nrows = pos + 1;                     // rows 0 .. pos
+    const long long niter = (nrows + 63) / 64;           // uniform over the block (shuffles need whole 16-lane groups only, but
+                                                         // keeping the trip count uniform lets every lane run the prefetch)
+    for (long long it = 0; it < niter; ++it) {
+        const long long l = it * 64 + slot;
+        u32x4_t kn2, vn2;
+        bool ok2;
+        load_row(l + 64, kn2, vn2, ok2);                  // next iteration's rows
+        float kf[8], vf[8];
+        bool use = ok;
+        if (l == pos) {
+            use = true;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { kf[e] = kn_lds[8 * d8 + e]; vf[e] = vn_lds[8 * d8 + e]; }
+        } else {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                kf[2 * d] = half_bits_to_f32<DT>(kk[d] & 0xffffu); kf[2 * d + 1] = half_bits_to_f32<DT>(kk[d] >> 16);
+                vf[2 * d] = half_bits_to_f32<DT>(vv[d] & 0xffffu); vf[2 * d + 1] = half_bits_to_f32<DT>(vv[d] >> 16);
+            }
+        }
+        score_row(kf, vf, use);
+        kk = kn2; vv = vn2; ok = ok2;
+    }
+    // merge the 4 row slots of the wave (lanes l, l^16, l^32 hold the same dims of different rows)
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float mo = __shfl_xor(m[g], o, 64), so = __shfl_xor(s[g], o, 64);
+            const float mn = fmaxf(m[g], mo), f1 = __expf(m[g] - mn), f2 = __expf(mo - mn);
+            s[g] = s[g] * f1 + so * f2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[g][e] = acc[g][e] * f1 + __shfl_xor(acc[g][e], o, 64) * f2;
             m[g] = mn;
         }
     }
+    if (kq == 0) {
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        if (d8 == 0) { m_lds[slot][g] = m[g]; s_lds[slot][g] = s[g]; }
+        for (int g = 0; g < G; ++g) {
+            if (d8 == 0) { m_lds[wave][g] = m[g]; s_lds[wave][g] = s[g]; }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a_lds[slot][g][8 * d8 + e] = acc[g][e];
+            for (int e = 0; e < 8; ++e) a_lds[wave][g][8 * d8 + e] = acc[g][e];
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < G * HD; i += 256) {
+    for (int i = threadIdx.x; i < G * HD; i += 1024) {
         const int g = i / HD, d = i % HD;
         float mm = -1e30f;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) mm = fmaxf(mm, m_lds[j][g]);
+        for (int j = 0; j < NWV; ++j) mm = fmaxf(mm, m_lds[j][g]);
         float ssum = 0.f, a = 0.f;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < NWV; ++j) {
             const float f = __expf(m_lds[j][g] - mm);
             ssum += s_lds[j][g] * f;
             a += a_lds[j][g][d] * f;

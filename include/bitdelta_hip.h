@@ -166,7 +166,7 @@ int bd_set_decode_two_launch(int on);
 /* A/B hook: 1 (default) = fused launches of the VALU decode kernel run wave-specialised (4 weight-streaming + 4 sign waves per block) */
 int bd_set_decode_wave_spec(int on);
 /* A/B hook of the streaming decode kernel (effective only in -DBD_AB_VARIANTS builds; the shipped library ignores it):
- * bit 0 = natural-order base-weight loads, bit 1 = default cache policy instead of nt, bit 2 = 4-wave blocks */
+ * bit 0 = natural-order base-weight loads, bit 1 = nt cache policy, bit 2 = 8-wave blocks, bit 3 = deeper prefetch */
 int bd_set_stream_tuning(int flags);
 /* A/B hook, sign LUT of the no-split-k decode kernel: -1 (default) automatic, 1 = single 4-KiB table, 0 = 16-copy conflict-free
  * 64-KiB table whenever it fits in LDS */
