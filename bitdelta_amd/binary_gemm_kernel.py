@@ -233,6 +233,34 @@ def tenant_linear(x, weights, *, out_dtype=None):
     return y
 
 
+def _words32(b, n_bits):
+    """Packed sign words of any reference width as int32 words [.., K/32, N] with the SAME bit <-> k mapping: the reference kernels
+    read bit (k % n_bits) of word row k // n_bits (bitdelta/binary_gemm_kernel.py:109-111, :128 / :251-253, :270); regrouping the
+    rows into 32-bit words keeps k = 32 i + j <-> bit j of word i.  A re-layout of the operand (torch integer ops on the device,
+    exact), not a compute path: the GEMM itself always runs on the int32 kernel."""
+    if n_bits == 32:
+        assert b.dtype == torch.int32, "n_bits = 32 expects int32 words"
+        return b
+    assert n_bits in (8, 16, 64), "n_bits must be 8, 16, 32 or 64"
+    assert b.dtype == WORD_DTYPE[n_bits], f"n_bits = {n_bits} expects {WORD_DTYPE[n_bits]} words"
+    KW, N = b.shape[-2], b.shape[-1]
+    K = KW * n_bits
+    assert K % 32 == 0, "K must be a multiple of 32"
+    lead = b.shape[:-2]
+    if n_bits == 64:
+        lo = (b & 0xffffffff).to(torch.int64)
+        hi = (b >> 32) & 0xffffffff
+        w = torch.stack([lo, hi], dim=-2).reshape(*lead, KW * 2, N)                     # word i of width 64 -> rows 2i, 2i+1
+    else:
+        per = 32 // n_bits
+        mask = (1 << n_bits) - 1
+        u = (b.to(torch.int64) & mask).reshape(*lead, KW // per, per, N)
+        sh = torch.arange(per, device=b.device, dtype=torch.int64).view(*([1] * len(lead)), 1, per, 1) * n_bits
+        w = (u << sh).sum(dim=-2)
+    w = torch.where(w >= 2 ** 31, w - 2 ** 32, w)                                         # wrap to int32 (bit 31 -> negative)
+    return w.to(torch.int32).contiguous()
+
+
 def binary_matmul(a, b, n_bits=32, activation="", *, round_mode=1, out_dtype=None):
     """
         a: float tensor (M, K)
@@ -243,9 +271,8 @@ def binary_matmul(a, b, n_bits=32, activation="", *, round_mode=1, out_dtype=Non
     assert a.shape[1] == b.shape[0] * n_bits, "Incompatible dimensions"
     assert a.is_contiguous(), "Matrix A must be contiguous"
     assert b.is_contiguous(), "Matrix B must be contiguous"
-    assert n_bits == 32, "the packed operand must be int32 words (the reference's only exercised width)"
     # `activation` is accepted and ignored, exactly like the reference (:73, :141-142)
-    return delta_bmm(a.unsqueeze(0), b.unsqueeze(0), round_mode=round_mode, out_dtype=out_dtype)[0]
+    return delta_bmm(a.unsqueeze(0), _words32(b, n_bits).unsqueeze(0), round_mode=round_mode, out_dtype=out_dtype)[0]
 
 
 def binary_bmm(a, b, n_bits=32, activation="", *, round_mode=1, out_dtype=None):
@@ -261,6 +288,5 @@ def binary_bmm(a, b, n_bits=32, activation="", *, round_mode=1, out_dtype=None):
     assert a.is_contiguous(), "Matrix A must be contiguous"
     assert b.is_contiguous(), "Matrix B must be contiguous"
     assert a.device == b.device, "A and B must be on the same device"
-    assert n_bits == 32, "the packed operand must be int32 words (the reference's only exercised width)"
     # output: non-differentiable tensor of a.dtype, fp32 accumulate -> fp16 -> a.dtype (reference :287, :314)
-    return delta_bmm(a, b, round_mode=round_mode, out_dtype=out_dtype)
+    return delta_bmm(a, _words32(b, n_bits), round_mode=round_mode, out_dtype=out_dtype)

@@ -672,7 +672,9 @@ int main(int argc, char** argv) {
         // streaming decode kernel (600, the automatic choice) vs the round-1 kernels (300 wave-specialised VALU, 500 one-launch col16),
         // warm (Infinity-Cache resident) and cold (HBM) weights.  argv[2] = "quick" -> headline shapes only
         const bool quick = argc > 2 && std::string(argv[2]) == "quick";
+        g_tiled = argc > 3 && std::string(argv[3]) == "tile";          // tile-major sign words for the streaming kernel (variant 600)
         for (int v : {600, 300, 500}) {
+            if (g_tiled && v != 600) continue;
             for (int T : {1, 4, 6, 8}) {
                 if (quick && T != 6 && T != 1) continue;
                 fails += run_decode_cold("dec_4096sq", T, 1, 4096, 4096, BD_F16, 1, v, 200);
@@ -716,12 +718,21 @@ int main(int argc, char** argv) {
         bd_set_stream_tuning(0);
         fails += run_decode_cold("ref300_T6_4096sq", 6, 1, 4096, 4096, BD_F16, 1, 300, 200);
         fails += run_decode_cold("ref300_T6_gateup", 6, 1, 28672, 4096, BD_F16, 1, 300, 60);
+    } else if (mode == "dec1") {
+        // one decode case for rocprofv3 passes: dec1 <T> <N> <K> <variant> <tiled 0|1> [iters]
+        if (argc < 7) { fprintf(stderr, "usage: dec1 T N K variant tiled [iters]\n"); return 2; }
+        g_tiled = atoi(argv[6]);
+        fails += run_decode_cold("dec1", atoi(argv[2]), 1, atoi(argv[3]), atoi(argv[4]), BD_F16, 1, atoi(argv[5]), argc > 7 ? atoi(argv[7]) : 20);
     } else if (mode == "dec600_pmc") {
-        // few launches of the headline decode shapes for rocprofv3 --kernel-trace / --pmc passes
-        for (int v : {600, 500, 300})
-            for (int T : {1, 6}) fails += run_decode_cold("pmc_4096sq", T, 1, 4096, 4096, BD_F16, 1, v, 20);
+        // few launches of the headline decode shapes for rocprofv3 --kernel-trace / --pmc passes (streaming kernel, tile-major signs;
+        // then the round-1 kernels on the reference layout for comparison)
+        g_tiled = 1;
+        for (int T : {1, 6}) fails += run_decode_cold("pmc_4096sq", T, 1, 4096, 4096, BD_F16, 1, 600, 20);
+        fails += run_decode_cold("pmc_qkv6144", 6, 1, 6144, 4096, BD_F16, 1, 600, 20);
         fails += run_decode_cold("pmc_gateup28672", 6, 1, 28672, 4096, BD_F16, 1, 600, 20);
         fails += run_decode_cold("pmc_down14336", 6, 1, 4096, 14336, BD_F16, 1, 600, 20);
+        g_tiled = 0;
+        for (int v : {500, 300}) fails += run_decode_cold("pmc_4096sq", 6, 1, 4096, 4096, BD_F16, 1, v, 20);
     } else if (mode == "notebook") {
         // the shapes the reference's notebook publishes (fp16, FLOP = 2*B*M*N*K, delta-only kernels)
         for (int NK : {4096, 8192}) {

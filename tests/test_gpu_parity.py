@@ -474,3 +474,21 @@ def test_full_size_fused_spot_rows(bd):
     # 1 bf16 ulp, with the absolute floor of fp32 accumulation noise for outputs that cancel to ~0 (|y| ~ 1e-5 among O(1) values)
     ok, same = within_one_ulp(y[0, rows].cpu(), ref.bfloat16().cpu(), K)
     assert ok and same >= 0.98, (ok, same)
+
+
+def test_binary_gemm_accepts_every_reference_word_width(bd, oracle):
+    """The reference kernels take n_bits (binary_gemm_kernel.py:109-111, :128, :153): 8 / 16 / 64-bit packed operands give the same
+    result as the int32 pack of the same bits."""
+    torch.manual_seed(17)
+    bits = torch.rand(2, 256, 72, device="cuda") > 0.5
+    a = torch.randn(2, 5, 256, device="cuda").half()
+    want = bd.binary_bmm(a, bd.pack(bits, 32))
+    ref = oracle.delta_bmm(a.cpu(), oracle.pack(bits.cpu(), 32), round_mode=1)
+    assert ulp_diff(want.cpu(), ref).max().item() <= 1
+    for nb in (8, 16, 64):
+        got = bd.binary_bmm(a, bd.pack(bits, nb), n_bits=nb)
+        assert torch.equal(got, want), nb
+        got2 = bd.binary_matmul(a[0], bd.pack(bits[0], nb), n_bits=nb)
+        assert torch.equal(got2, want[0]), nb
+    with pytest.raises(AssertionError):
+        bd.binary_bmm(a, bd.pack(bits, 8), n_bits=16)                  # word dtype must match n_bits
