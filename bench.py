@@ -67,16 +67,17 @@ class LaunchTimer:
         k.binary_linear = d.binary_linear = s.binary_linear = sl.binary_linear = timed
         orig_dec = k.binary_linear_decode
 
-        def timed_dec(x, weight, mask_tiled, alpha, **kw):
+        def timed_dec(x, weight, mask, alpha, **kw):
             if not timer.enabled:
-                return orig_dec(x, weight, mask_tiled, alpha, **kw)
+                return orig_dec(x, weight, mask, alpha, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            y = orig_dec(x, weight, mask_tiled, alpha, **kw)
+            y = orig_dec(x, weight, mask, alpha, **kw)
             e1.record()
             B, M, K = x.shape
             N = weight.shape[0]
-            nbytes = 2.0 * B * M * K + 2.0 * N * K + mask_tiled.shape[0] * K * N / 8.0 + 4.0 * mask_tiled.shape[0] + 2.0 * B * M * N
+            nmask = B if kw.get("layout", "tile") == "packed" else mask.shape[0]      # algorithmic: one mask per tenant, no padding
+            nbytes = 2.0 * B * M * K + 2.0 * N * K + nmask * K * N / 8.0 + 4.0 * nmask + 2.0 * B * M * N
             timer.records.append((e0, e1, 4.0 * B * M * K * N, nbytes))
             return y
         k.binary_linear_decode = sl.binary_linear_decode = timed_dec

@@ -6,7 +6,7 @@ Drop-in module map (reference -> here):
     demo.demo_backend (modules)  ->  bitdelta_amd.serving              (DiffCompressModule, DataParallelModule, register_diff_compress, ...)
 """
 from .binary_gemm_kernel import (binary_bmm, binary_linear, binary_linear_decode, binary_matmul, delta_bmm, pack,  # noqa: F401
-                                 tenant_linear, tile_masks, unpack)
+                                 pack_decode_masks, tenant_linear, tile_masks, unpack)
 from .diff import BinaryDiff, BinaryLinear, compress_diff, load_diff, save_diff, save_full_model  # noqa: F401
 from .serving import DiffCompressModule  # noqa: F401
 

@@ -27,7 +27,7 @@ SIGNATURES = {
                            _vp, _i64, _ci, _ci, _vp, _i64, _vp]),
     "bd_binary_linear": (_ci, [_vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _ci,
                                _i64, _i64, _ci, _ci, _vp, _i64, _vp]),
-    "bd_binary_linear_decode": (_ci, [_vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _ci,
+    "bd_binary_linear_decode": (_ci, [_vp, _vp, _vp, _ci, _ci, _vp, _vp, _ci, _ci, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _ci,
                                       _i64, _i64, _ci, _ci, _ci, _vp]),
     "bd_binary_linear_residual": (_ci, [_vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _ci,
                                         _i64, _i64, _ci, _ci, _vp, _i64, _vp]),

@@ -17,7 +17,7 @@ from . import _lib
 from ._lib import DTYPE_CODE, WORD_DTYPE, check, lib, ptr, require_gpu, stream_ptr, workspace
 
 __all__ = ["pack", "unpack", "binary_matmul", "binary_bmm", "delta_bmm", "binary_linear", "tenant_linear", "tile_masks",
-           "binary_linear_decode", "decode_shape_ok"]
+           "pack_decode_masks", "binary_linear_decode", "decode_shape_ok"]
 
 
 def pack(x, n_bits=32):
@@ -168,6 +168,27 @@ def tile_masks(mask):
     return mask.view(T, KW, Np // 16, 16).permute(0, 2, 1, 3).contiguous()
 
 
+def pack_decode_masks(mask):
+    """Repack packed sign words [T, K/32, N] (reference / diff.pt layout) into the PACKED layout of the streaming decode kernel:
+    int32 [ceil(N/16), ceil(K/128), 4, 16, t_pad] with element [tile][it][g][c][t] = tenant t's dword whose byte s holds the 8 signs
+    of k = 128 it + 32 s + 8 g .. + 7 of column 16 tile + c; tenants interleaved, zero-padded to t_pad in {1, 2, 4, 6, 8}.
+    Exact byte shuffling (torch ops on the device), done once per registered tenant set."""
+    assert mask.dim() == 3 and mask.dtype == torch.int32
+    T, KW, N = mask.shape
+    assert T <= 8, "the packed decode layout holds at most 8 tenants per call"
+    tp = next(v for v in (1, 2, 4, 6, 8) if v >= T)
+    KW4, N16 = (KW + 3) // 4 * 4, (N + 15) // 16 * 16
+    if KW4 != KW or N16 != N:
+        mask = torch.nn.functional.pad(mask, (0, N16 - N, 0, KW4 - KW))
+    # bytes: [t][it][s][tile][c][g]   (byte g of word row 4 it + s covers k = 128 it + 32 s + 8 g .. + 7; little-endian)
+    b = mask.contiguous().view(torch.uint8).view(T, KW4 // 4, 4, N16 // 16, 16, 4)
+    b = b.permute(3, 1, 5, 4, 0, 2).contiguous()                       # [tile][it][g][c][t][s]
+    out = b.view(torch.int32).view(N16 // 16, KW4 // 4, 4, 16, T)      # the 4 bytes over s form one dword
+    if tp != T:
+        out = torch.nn.functional.pad(out, (0, tp - T))
+    return out.contiguous()
+
+
 def decode_shape_ok(B, M, N, K, n_masks):
     """True when bd_binary_linear_decode accepts the problem (the streaming decode kernel's envelope)."""
     if M < 1 or M > 16 or N < 512 or K % 32:
@@ -176,14 +197,24 @@ def decode_shape_ok(B, M, N, K, n_masks):
     return (1 if n_masks == 1 else chunk) <= 8
 
 
-def binary_linear_decode(x, weight, mask_tiled, alpha, *, out_dtype=None, groups=1, residual=None):
-    """binary_linear for decode shapes with tile-major masks (tile_masks): one launch of the streaming kernel.
-    x: (B, M, K), M <= 16; weight (N, K); mask_tiled (B or 1, ceil(N/16), K/32, 16); alpha fp32 (B or 1, groups)."""
-    require_gpu(x, weight, mask_tiled, alpha, residual)
+def binary_linear_decode(x, weight, mask, alpha, *, layout="tile", out_dtype=None, groups=1, residual=None):
+    """binary_linear for decode shapes with repacked masks: one launch of the streaming kernel.
+    x: (B, M, K), M <= 16; weight (N, K); alpha fp32 (B or 1, groups);
+    layout "tile":   mask = tile_masks(...)        (B or 1, ceil(N/16), K/32, 16)
+    layout "packed": mask = pack_decode_masks(...) (ceil(N/16), ceil(K/128), 4, 16, t_pad), B <= t_pad tenants, B*M <= 16."""
+    require_gpu(x, weight, mask, alpha, residual)
     B, M, K = x.shape
     N = weight.shape[0]
-    assert mask_tiled.dim() == 4 and mask_tiled.dtype == torch.int32 and mask_tiled.is_contiguous()
-    assert mask_tiled.shape[1:] == ((N + 15) // 16, K // 32, 16) and mask_tiled.shape[0] in (1, B)
+    assert mask.dtype == torch.int32 and mask.is_contiguous()
+    if layout == "tile":
+        assert mask.dim() == 4 and mask.shape[1:] == ((N + 15) // 16, K // 32, 16) and mask.shape[0] in (1, B)
+        code, t_pad = 1, 0
+        sPb = 0 if (mask.shape[0] == 1 and B > 1) else mask.stride(0)
+    else:
+        assert layout == "packed" and mask.dim() == 5
+        assert mask.shape[:4] == ((N + 15) // 16, (K + 127) // 128, 4, 16) and B <= mask.shape[4] and B * M <= 16
+        code, t_pad = 2, mask.shape[4]
+        sPb = 1
     assert weight.shape[1] == K and weight.stride(1) == 1 and weight.dtype == x.dtype and x.stride(2) == 1
     out_dtype = out_dtype or x.dtype
     alpha = alpha.detach()
@@ -191,7 +222,6 @@ def binary_linear_decode(x, weight, mask_tiled, alpha, *, out_dtype=None, groups
         alpha = alpha.float().contiguous()
     alpha = alpha.reshape(-1, groups)
     assert alpha.shape[0] in (1, B)
-    sPb = 0 if (mask_tiled.shape[0] == 1 and B > 1) else mask_tiled.stride(0)
     sAlb = 0 if alpha.shape[0] == 1 else groups
     if residual is not None:
         assert residual.shape == (B, M, N) and residual.dtype == out_dtype and residual.stride(2) == 1
@@ -199,10 +229,10 @@ def binary_linear_decode(x, weight, mask_tiled, alpha, *, out_dtype=None, groups
     else:
         y = torch.empty((B, M, N), device=x.device, dtype=out_dtype)
     with torch.cuda.device(x.device):
-        check(lib().bd_binary_linear_decode(ptr(x), ptr(weight), ptr(mask_tiled), ptr(alpha), ptr(y), B, M, N, K, x.stride(0),
-                                            x.stride(1), weight.stride(0), sPb, sAlb, groups, y.stride(0), y.stride(1),
-                                            DTYPE_CODE[x.dtype], DTYPE_CODE[out_dtype], 1 if residual is not None else 0,
-                                            stream_ptr()), "binary_linear_decode")
+        check(lib().bd_binary_linear_decode(ptr(x), ptr(weight), ptr(mask), code, t_pad, ptr(alpha), ptr(y), B, M, N, K,
+                                            x.stride(0), x.stride(1), weight.stride(0), sPb, sAlb, groups, y.stride(0),
+                                            y.stride(1), DTYPE_CODE[x.dtype], DTYPE_CODE[out_dtype],
+                                            1 if residual is not None else 0, stream_ptr()), "binary_linear_decode")
     return y
 
 

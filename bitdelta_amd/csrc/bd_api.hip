@@ -118,7 +118,9 @@ struct Problem {
     int B, M, N, K;
     int64_t sAb, sAm, sPb, sCb, sCm, ldw, sAlb;
     int G, dtype, out_dtype, round_mode, accumulate;
-    int mask_tiled;           // 0: P is [B or 1, K/32, N] (reference layout); 1: tile-major [B or 1, ceil(N/16), K/32, 16] (decode kernel only)
+    int mask_tiled;           // 0: P is [B or 1, K/32, N] (reference layout); 1: tile-major [B or 1, ceil(N/16), K/32, 16];
+                              // 2: packed decode layout [ceil(N/16), ceil(K/128), 4, 16, t_pad] (decode kernel only, see bd_gemv_stream.h)
+    int t_pad;                // layout 2: dwords per (tile, iteration, lane group, column) = tenants padded to 1 / 2 / 4 / 6 / 8
     void* ws;
     int64_t ws_bytes;
     hipStream_t st;
@@ -304,13 +306,14 @@ inline bool stream_ok(const Problem& q, int rows, int nmask) {
     const int64_t lim = (1ll << 31) - 64;
     const int64_t xb = ((int64_t)(q.B - 1) * q.sAb + (int64_t)(q.M - 1) * q.sAm + q.K) * 2;
     const int64_t wb = q.W ? ((int64_t)(q.N - 1) * q.ldw + q.K) * 2 : 0;
-    const int64_t pb = ((int64_t)(nmask - 1) * q.sPb + (int64_t)(q.K / 32) * ((q.N + 15) / 16 * 16)) * 4;
+    const int64_t pb = q.mask_tiled == 2 ? (int64_t)((q.N + 15) / 16) * ((q.K + 127) / 128) * 4 * 16 * q.t_pad * 4
+                                         : ((int64_t)(nmask - 1) * q.sPb + (int64_t)(q.K / 32) * ((q.N + 15) / 16 * 16)) * 4;
     return xb > 0 && xb < lim && wb < lim && pb < lim && q.sAb >= 0 && q.sAm >= 0;
 }
 
-template <int DT, int NM, bool HASW, int NS, int NW = 8, int WNAT = 0, int AUX = 2>
+template <int DT, int NM, bool HASW, int NS, int NW = 8, int WNAT = 0, int AUX = 2, int PK = 0>
 int launch_stream_inst(const StreamParams& sp, dim3 grid, hipStream_t st) {
-    auto kern = gemv_stream_kernel<DT, NM, HASW, NS, NW, WNAT, AUX>;
+    auto kern = gemv_stream_kernel<DT, NM, HASW, NS, NW, WNAT, AUX, PK>;
     static std::atomic<uint64_t> lds_done{0};
     if (!ensure_dyn_lds((const void*)kern, STREAM_LDS_BYTES, lds_done)) return BD_E_LAUNCH;
     hipLaunchKernelGGL(kern, grid, dim3(64 * NW), STREAM_LDS_BYTES, st, sp);
@@ -364,13 +367,30 @@ int launch_gemv_stream_chunk(const Problem& q) {
     if (cpb < 4) cpb = 4;
     if (g_forced_variant > 600 && g_forced_variant <= 664) cpb = 4 * (g_forced_variant - 600);     // test hook: 600 + cpb/4
     sp.cpb = cpb;
-    sp.pts = q.mask_tiled ? 16u * (uint32_t)(q.K / 32) : 16u;
-    sp.prs = q.mask_tiled ? 16u : (uint32_t)q.N;
+    sp.pts = q.mask_tiled == 1 ? 16u * (uint32_t)(q.K / 32) : 16u;
+    sp.prs = q.mask_tiled == 1 ? 16u : (uint32_t)q.N;
+    sp.tp = (uint32_t)q.t_pad;
     const unsigned grid = (unsigned)((q.N + cpb - 1) / cpb);
     sp.x_bytes = (uint32_t)(((int64_t)(q.B - 1) * q.sAb + (int64_t)(q.M - 1) * q.sAm + q.K) * 2);
     sp.w_bytes = q.W ? (uint32_t)(((int64_t)(q.N - 1) * q.ldw + q.K) * 2) : 0u;
     sp.p_bytes = (uint32_t)(((int64_t)(nmask - 1) * q.sPb + (int64_t)(q.K / 32) * (q.mask_tiled ? (q.N + 15) / 16 * 16 : q.N)) * 4);
     int rc;
+    if (q.mask_tiled == 2) {      // packed layout: all tenants of the call in one chunk, interleaved; extent from the pack's own geometry
+        sp.p_bytes = (uint32_t)((int64_t)((q.N + 15) / 16) * ((q.K + 127) / 128) * 4 * 16 * q.t_pad * 4);
+#define BD_PK(NM, NS4) rc = q.W ? launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1>(sp, dim3(grid), q.st) \
+                                : launch_stream_inst<DT, NM, false, NS4, 4, 1, 0, 1>(sp, dim3(grid), q.st)
+        switch (q.t_pad) {
+            case 1: BD_PK(1, 8); break;
+            case 2: BD_PK(2, 6); break;
+            case 4: BD_PK(4, 4); break;
+            case 6: BD_PK(6, 4); break;
+            case 8: BD_PK(8, 4); break;
+            default: return BD_E_BAD_SHAPE;
+        }
+#undef BD_PK
+        if (rc != BD_OK) return rc;
+        return launch_status();
+    }
     // NS = stages of loads in flight per wave; bounded by the 256-VGPR budget of a 2-waves-per-SIMD block (hipcc spills beyond)
 #define BD_STREAM(NM, NS4) rc = q.W ? launch_stream_tuned<DT, NM, true, NS4>(sp, dim3(grid), q.st) \
                                      : launch_stream_tuned<DT, NM, false, NS4>(sp, dim3(grid), q.st)
@@ -769,15 +789,15 @@ extern "C" int bd_delta_bmm(const void* A, const int32_t* P, void* C, int B, int
 
 static int binary_linear_impl(const void* X, const void* W, const int32_t* P, const float* alpha, void* Y, int B, int M,
                               int N, int K, int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb, int64_t sAlb, int G,
-                              int64_t sYb, int64_t sYm, int dtype, int out_dtype, int accumulate, int mask_tiled, void* ws,
-                              int64_t ws_bytes, void* stream) {
+                              int64_t sYb, int64_t sYm, int dtype, int out_dtype, int accumulate, int mask_tiled, int t_pad,
+                              void* ws, int64_t ws_bytes, void* stream) {
     if (B > 0 && M > 0 && N > 0 && !W) return BD_E_NULL;
     Problem q{};
     q.A = X; q.P = P; q.C = Y; q.W = W; q.alpha = alpha;
     q.B = B; q.M = M; q.N = N; q.K = K;
     q.sAb = sXb; q.sAm = sXm; q.sPb = sPb; q.sCb = sYb; q.sCm = sYm; q.ldw = ldw; q.sAlb = sAlb;
     q.G = G; q.dtype = dtype; q.out_dtype = out_dtype; q.round_mode = 0; q.accumulate = accumulate ? 1 : 0;
-    q.mask_tiled = mask_tiled ? 1 : 0;
+    q.mask_tiled = mask_tiled; q.t_pad = t_pad;
     q.ws = ws; q.ws_bytes = ws_bytes; q.st = (hipStream_t)stream;
     // tile-major masks exist for the streaming decode kernel only (serving-side repack; the reference layout works everywhere)
     if (q.mask_tiled) {
@@ -785,6 +805,12 @@ static int binary_linear_impl(const void* X, const void* W, const int32_t* P, co
         if (M < 1 || M > GEMV_MAX_M || forced_other || !gemv_ok(q)) return BD_E_BAD_SHAPE;
         const int cb = GEMV_MAX_R / M, bc = B < cb ? B : cb;
         if (!stream_ok(q, bc * M, sPb == 0 ? 1 : bc)) return BD_E_BAD_SHAPE;
+        if (q.mask_tiled == 2) {      // interleaved tenants: the whole batch is one chunk, one dword slot per tenant
+            const bool tp_ok = t_pad == 1 || t_pad == 2 || t_pad == 4 || t_pad == 6 || t_pad == 8;
+            if (!tp_ok || B > t_pad || B > cb || (sPb == 0 && B > 1 && t_pad != 1)) return BD_E_BAD_SHAPE;
+            q.sPb = t_pad == 1 ? 0 : 1;             // only "broadcast or not" matters to the kernel in this layout
+            if (t_pad == 1 && B > 1) q.sPb = 0;
+        } else if (q.mask_tiled != 1) return BD_E_BAD_SHAPE;
     }
     // Y += ... is an epilogue of the decode kernels only (a residual add costs a launch per Linear there; at prefill sizes it is
     // noise next to the GEMM and stays with the caller)
@@ -796,22 +822,24 @@ extern "C" int bd_binary_linear(const void* X, const void* W, const int32_t* P, 
                                 int N, int K, int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb, int64_t sAlb, int G,
                                 int64_t sYb, int64_t sYm, int dtype, int out_dtype, void* ws, int64_t ws_bytes,
                                 void* stream) {
-    return binary_linear_impl(X, W, P, alpha, Y, B, M, N, K, sXb, sXm, ldw, sPb, sAlb, G, sYb, sYm, dtype, out_dtype, 0, 0, ws,
+    return binary_linear_impl(X, W, P, alpha, Y, B, M, N, K, sXb, sXm, ldw, sPb, sAlb, G, sYb, sYm, dtype, out_dtype, 0, 0, 0, ws,
                               ws_bytes, stream);
 }
 
-extern "C" int bd_binary_linear_decode(const void* X, const void* W, const int32_t* P_tiled, const float* alpha, void* Y, int B,
-                                       int M, int N, int K, int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb, int64_t sAlb,
-                                       int G, int64_t sYb, int64_t sYm, int dtype, int out_dtype, int accumulate, void* stream) {
-    return binary_linear_impl(X, W, P_tiled, alpha, Y, B, M, N, K, sXb, sXm, ldw, sPb, sAlb, G, sYb, sYm, dtype, out_dtype,
-                              accumulate, 1, nullptr, 0, stream);
+extern "C" int bd_binary_linear_decode(const void* X, const void* W, const int32_t* P, int mask_layout, int t_pad, const float* alpha,
+                                       void* Y, int B, int M, int N, int K, int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb,
+                                       int64_t sAlb, int G, int64_t sYb, int64_t sYm, int dtype, int out_dtype, int accumulate,
+                                       void* stream) {
+    if (mask_layout != 1 && mask_layout != 2) return BD_E_BAD_SHAPE;
+    return binary_linear_impl(X, W, P, alpha, Y, B, M, N, K, sXb, sXm, ldw, sPb, sAlb, G, sYb, sYm, dtype, out_dtype,
+                              accumulate, mask_layout, t_pad, nullptr, 0, stream);
 }
 
 extern "C" int bd_binary_linear_residual(const void* X, const void* W, const int32_t* P, const float* alpha, void* Y, int B,
                                          int M, int N, int K, int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb,
                                          int64_t sAlb, int G, int64_t sYb, int64_t sYm, int dtype, int out_dtype, void* ws,
                                          int64_t ws_bytes, void* stream) {
-    return binary_linear_impl(X, W, P, alpha, Y, B, M, N, K, sXb, sXm, ldw, sPb, sAlb, G, sYb, sYm, dtype, out_dtype, 1, 0, ws,
+    return binary_linear_impl(X, W, P, alpha, Y, B, M, N, K, sXb, sXm, ldw, sPb, sAlb, G, sYb, sYm, dtype, out_dtype, 1, 0, 0, ws,
                               ws_bytes, stream);
 }
 

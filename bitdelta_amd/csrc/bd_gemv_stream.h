@@ -65,6 +65,8 @@ struct StreamParams {
     //   reference layout [K/32, N]:            pts = 16,          prs = N
     //   tile-major layout [N/16, K/32, 16]:    pts = 16 * K/32,   prs = 16   (a 16-column tile's words are one contiguous run over k)
     uint32_t pts, prs;
+    // packed decode layout (PK kernels): tenants interleaved, `tp` dwords per (tile, iteration, lane group, column) -- see PK below
+    uint32_t tp;
 };
 
 // NW = waves per block (8: two per SIMD, 256 VGPRs each; 4: one per SIMD, the whole register file, deeper prefetch).
@@ -76,8 +78,17 @@ struct StreamParams {
 // AUX = cache policy of the weight / sign streams (0 = default, 2 = nt).  Measured (profiles/r02_decode_stream_ab.txt): with the
 //   word-row order nt costs 35 % of the pure weight stream (3.4 vs 5.2 TB/s at 235 MB): the 4 load instructions of a stage each
 //   use 16 bytes of the same 64-byte sectors, and a non-temporal line does not stay in L1 for the next one.
-template <int DT, int NM, bool HASW, int NS, int NW = 4, int WNAT = 0, int AUX = 0>
+// PK = 1: PACKED sign layout, everything in the natural k order with ONE activation fragment set.  The serving side repacks a tenant
+//   set's masks once (binary_gemm_kernel.pack_decode_masks) into  P[tile n/16][iteration k/128][lane group g][column n%16][tenant t]
+//   dwords whose byte s holds the 8 signs of k = 128 it + 32 s + 8 g .. + 7 (a 4 x 4 byte transpose of the 4 word rows of an
+//   iteration), so that (a) byte s of a lane's dword is exactly the sign fragment of natural MFMA step s, (b) W and x are read with
+//   the sector-friendly natural pattern (16 rows x 64 contiguous bytes per instruction), (c) the NM tenants' dwords of a lane are
+//   adjacent: one or two wide loads instead of NM dword loads.  Why: the PMC passes of the word-row kernel
+//   (profiles/r02_decode_pmc.txt) show its waves 37 % issue-stalled and 35 % busy -- one wave per SIMD, and 14 load instructions per
+//   5.5 KB stage that each touch 32-64 cache lines -- not 70 % waiting on memory as an HBM-bound kernel should be.
+template <int DT, int NM, bool HASW, int NS, int NW = 4, int WNAT = 0, int AUX = 0, int PK = 0>
 __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams sp) {
+    static_assert(!PK || (WNAT == 1 && NM > 0), "packed layout = natural order, with a sign operand");
     GemvParams p = sp.g;
     if constexpr (NM == 0) {       // blockIdx.y = tenant: its own activation rows, weight matrix and output rows
         p.X += (long long)blockIdx.y * sp.sXt;
@@ -85,8 +96,8 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
         p.C = (char*)p.C + (long long)blockIdx.y * sp.sCt * (p.out_f32 ? 4 : 2);
     }
     constexpr int NMA = NM > 0 ? NM : 1;      // array extent (no zero-length arrays)
-    constexpr bool XP = NM > 0 || !(HASW && WNAT);      // activation fragments in word-row order (sign operand; W too unless WNAT)
-    constexpr bool XN = HASW && WNAT;                    // activation fragments in natural order (W operand)
+    constexpr bool XP = !PK && (NM > 0 || !(HASW && WNAT));   // activation fragments in word-row order (sign operand; W too unless WNAT)
+    constexpr bool XN = PK || (HASW && WNAT);                  // activation fragments in natural order (W operand; signs too when PK)
     extern __shared__ __attribute__((aligned(256))) char dyn_lds[];     // [64 KiB sign LUT][32 KiB reduction buffers]
     float* const red = (float*)(dyn_lds + STREAM_LUT_BYTES);
     float* const a_lds = (float*)(dyn_lds + STREAM_LUT_BYTES + STREAM_RED_BYTES);
@@ -146,19 +157,45 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
             for (int s = 0; s < 4; ++s) {
                 const bool ok = it_ok && (k0 + 32 * s < p.K);
                 st.xn[s] = buf_load16<0>(rx, ok ? x_off + (uint32_t)(k0 + 32 * s) * 2u : STREAM_OOB);
-                st.wf[s] = buf_load16<AUX>(rw, (ok && col_ok) ? (uint32_t)n * (uint32_t)p.ldw * 2u + (uint32_t)(k0 + 32 * s) * 2u : STREAM_OOB);
+                if constexpr (HASW)
+                    st.wf[s] = buf_load16<AUX>(rw, (ok && col_ok) ? (uint32_t)n * (uint32_t)p.ldw * 2u + (uint32_t)(k0 + 32 * s) * 2u : STREAM_OOB);
             }
         } else if constexpr (HASW) {
             const uint32_t wo = (krow_ok && col_ok) ? (uint32_t)n * (uint32_t)p.ldw * 2u + (uint32_t)irow * 64u : STREAM_OOB;
 #pragma unroll
             for (int s = 0; s < 4; ++s) st.wf[s] = buf_load16<AUX>(rw, wo + 16u * s);
         }
-        [[maybe_unused]] const uint32_t po =
-            (krow_ok && col_ok) ? ((uint32_t)(n >> 4) * sp.pts + (uint32_t)irow * sp.prs + (uint32_t)(n & 15)) * 4u : STREAM_OOB;
+        if constexpr (PK) {
+            // dword index ((tile_g * nit + it) * 4 + g) * 16 + (n & 15), tp dwords each; iterations past K are zero padding in the pack
+            const bool ok = tile < ntile && it < nit && col_ok;
+            const uint32_t po = ok ? ((((uint32_t)(n >> 4) * (uint32_t)nit + (uint32_t)it) * 4u + (uint32_t)g) * 16u + (uint32_t)(n & 15)) * sp.tp * 4u
+                                   : STREAM_OOB;
+            if constexpr (NM == 1) {
+                st.wd[0] = buf_load4<AUX>(rp, po);
+            } else if constexpr (NM == 2) {
+                const u32x2_t v = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rp, (int)po, 0, AUX));
+                st.wd[0] = v[0]; st.wd[1] = v[1];
+            } else {
+                const u32x4_t v = buf_load16<AUX>(rp, po);
 #pragma unroll
-        for (int t = 0; t < NM; ++t) {
-            const uint32_t tb = (uint32_t)(min(t, nmask - 1)) * (uint32_t)p.sPb * 4u;
-            st.wd[t] = buf_load4<AUX>(rp, po == STREAM_OOB ? STREAM_OOB : po + tb);
+                for (int t = 0; t < 4 && t < NM; ++t) st.wd[t] = v[t];
+                if constexpr (NM == 6) {
+                    const u32x2_t v2 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rp, (int)(po == STREAM_OOB ? STREAM_OOB : po + 16u), 0, AUX));
+                    st.wd[4] = v2[0]; st.wd[5] = v2[1];
+                } else if constexpr (NM == 8) {
+                    const u32x4_t v2 = buf_load16<AUX>(rp, po == STREAM_OOB ? STREAM_OOB : po + 16u);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) st.wd[4 + t] = v2[t];
+                }
+            }
+        } else {
+            [[maybe_unused]] const uint32_t po =
+                (krow_ok && col_ok) ? ((uint32_t)(n >> 4) * sp.pts + (uint32_t)irow * sp.prs + (uint32_t)(n & 15)) * 4u : STREAM_OOB;
+#pragma unroll
+            for (int t = 0; t < NM; ++t) {
+                const uint32_t tb = (uint32_t)(min(t, nmask - 1)) * (uint32_t)p.sPb * 4u;
+                st.wd[t] = buf_load4<AUX>(rp, po == STREAM_OOB ? STREAM_OOB : po + tb);
+            }
         }
         // the stages must enter the load queue in stream order: without this fence hipcc clusters the loads of ALL prologue stages
         // by descriptor (every x, then every W, then every sign word), and stage 0 cannot be consumed before nearly all of them land
@@ -226,7 +263,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
             }
             if constexpr (HASW) accB = mfma16<DT>(cur.wf[s], XN ? cur.xn[s] : cur.xf[s], accB);
 #pragma unroll
-            for (int t = 0; t < NM; ++t) accD[t] = mfma16<DT>(sf[SFDB ? (s & 1) : 0][t], cur.xf[s], accD[t]);
+            for (int t = 0; t < NM; ++t) accD[t] = mfma16<DT>(sf[SFDB ? (s & 1) : 0][t], PK ? cur.xn[s] : cur.xf[s], accD[t]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };

@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .binary_gemm_kernel import binary_linear, binary_linear_decode, decode_shape_ok, tenant_linear, tile_masks
+from .binary_gemm_kernel import binary_linear, binary_linear_decode, decode_shape_ok, pack_decode_masks, tenant_linear
 from .diff import binarize
 from . import serving_ops as ops
 
@@ -61,14 +61,17 @@ class FusedDeltaLinear(nn.Module):
         alpha = torch.cat([c.float().reshape(-1, 1).expand(-1, n // gsz) for c, n in zip(coeffs, widths)], 1)
         self.register_buffer("alpha", alpha.contiguous())                                        # [T, G]
         self.groups = alpha.shape[1]
-        # decode copy of the sign words in the streaming kernel's tile-major order (prefill keeps the reference layout)
-        self.register_buffer("mask_tiled", tile_masks(self.mask))
+        # decode copy of the sign words in the streaming kernel's packed order (tenants interleaved, natural k order); prefill keeps
+        # the reference layout
+        self.register_buffer("mask_packed", pack_decode_masks(self.mask) if self.mask.shape[0] <= 8 else None)
 
     def forward(self, x, residual=None):
         B, M, K = x.shape
-        if decode_shape_ok(B, M, self.weight.shape[0], K, self.mask.shape[0]) and x.data_ptr() % 16 == 0 and \
+        if self.mask_packed is not None and B == self.mask.shape[0] and B * M <= 16 and \
+                decode_shape_ok(B, M, self.weight.shape[0], K, B) and x.data_ptr() % 16 == 0 and \
                 x.stride(0) % 8 == 0 and x.stride(1) % 8 == 0:
-            return binary_linear_decode(x, self.weight, self.mask_tiled, self.alpha, groups=self.groups, residual=residual)
+            return binary_linear_decode(x, self.weight, self.mask_packed, self.alpha, layout="packed", groups=self.groups,
+                                        residual=residual)
         return binary_linear(x, self.weight, self.mask, self.alpha, groups=self.groups, residual=residual)
 
     def linear_bytes(self):

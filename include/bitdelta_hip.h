@@ -80,13 +80,17 @@ int bd_binary_linear(const void* X, const void* W, const int32_t* P, const float
                      int64_t sYb, int64_t sYm, int dtype, int out_dtype,
                      void* ws, int64_t ws_bytes, void* stream);
 
-/* decode form of the fused Linear with the sign words in TILE-MAJOR order: P_tiled int32 [B or 1, ceil(N/16), K/32, 16]
- * (word (i, n) of the reference layout sits at [n / 16][i][n % 16]; columns past N are zero padding; sPb = tenant stride in words,
- * 0 broadcasts).  A 16-column MFMA tile then reads its sign words as one contiguous run over k instead of 64-byte pieces of
- * N*4-byte rows -- the serving side repacks a tenant's masks once when it registers them (diff.pt keeps the reference layout).
- * Streaming decode kernel only: B*M rows in chunks of <= 16, M <= 16, N >= 512, <= 8 masks per chunk, else BD_E_BAD_SHAPE.
+/* decode form of the fused Linear with the sign words repacked for the streaming decode kernel.  The serving side repacks a
+ * tenant set's masks once when it registers them (diff.pt and the nn.Module buffers keep the reference layout):
+ *   mask_layout 1, TILE-MAJOR:  P int32 [B or 1, ceil(N/16), K/32, 16]: word (i, n) of the reference layout at [n / 16][i][n % 16]
+ *     (a 16-column MFMA tile reads its words as one contiguous run over k); sPb = tenant stride in words (0 broadcasts); t_pad unused.
+ *   mask_layout 2, PACKED:  P int32 [ceil(N/16), ceil(K/128), 4, 16, t_pad]: element [tile][it][g][c][t] is tenant t's dword whose
+ *     byte s holds the 8 signs of k = 128 it + 32 s + 8 g .. + 7 of column 16 tile + c (a 4 x 4 byte transpose of the iteration's 4
+ *     word rows), tenants interleaved and zero-padded to t_pad in {1, 2, 4, 6, 8}; B <= t_pad tenants, all in one call (B*M <= 16).
+ *     Natural k order for every operand: one activation fragment set, sector-contiguous weight loads, 1-2 wide sign loads per stage.
+ * Columns past N / k past K are zero padding.  Streaming decode kernel only: M <= 16, N >= 512, <= 8 masks, else BD_E_BAD_SHAPE.
  * accumulate = 1 adds onto Y (residual epilogue).  Needs no workspace. */
-int bd_binary_linear_decode(const void* X, const void* W, const int32_t* P_tiled, const float* alpha, void* Y,
+int bd_binary_linear_decode(const void* X, const void* W, const int32_t* P, int mask_layout, int t_pad, const float* alpha, void* Y,
                             int B, int M, int N, int K,
                             int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb, int64_t sAlb, int G,
                             int64_t sYb, int64_t sYm, int dtype, int out_dtype, int accumulate, void* stream);

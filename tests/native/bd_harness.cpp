@@ -391,26 +391,45 @@ static void bits_bench() {
 // Decode timing with COLD weights: the same problem over `nset` device copies of W and P (nset * bytes > 2 x the 256 MB Infinity
 // Cache), launched round-robin, so every launch streams its weights from HBM as a decode step of a real model does.  (run_case's
 // loop re-reads one 46 MB problem from the Infinity Cache and flatters HBM-bound kernels.)  Prints warm and cold us per launch.
-static int g_tiled = 0;      // 1: decode calls go through bd_binary_linear_decode with tile-major sign words
+static int g_tiled = 0;      // decode calls go through bd_binary_linear_decode: 1 = tile-major sign words, 2 = packed (interleaved tenants)
+static int tpad_of(int T) { return T <= 1 ? 1 : T <= 2 ? 2 : T <= 4 ? 4 : T <= 6 ? 6 : 8; }
 static int call_decode(const Problem& q) {
     if (!g_tiled || !q.fused) return call_api(q, 0);
+    const int T = q.tenants == 1 ? 1 : q.B;
     const int64_t sPb = q.tenants == 1 ? 0 : (int64_t)(q.K / 32) * ((q.N + 15) / 16 * 16);
-    return bd_binary_linear_decode(q.dA, q.dW, (const int32_t*)q.dP, (const float*)q.dAl, q.dC, q.B, q.M, q.N, q.K,
-                                   (int64_t)q.M * q.K, q.K, q.K, sPb, 1, 1, (int64_t)q.M * q.N, q.N, q.dt, q.out_dt, 0, 0);
+    return bd_binary_linear_decode(q.dA, q.dW, (const int32_t*)q.dP, g_tiled, g_tiled == 2 ? tpad_of(T) : 0, (const float*)q.dAl, q.dC,
+                                   q.B, q.M, q.N, q.K, (int64_t)q.M * q.K, q.K, q.K, sPb, 1, 1, (int64_t)q.M * q.N, q.N, q.dt,
+                                   q.out_dt, 0, 0);
 }
 static int run_decode_cold(const char* tag, int B, int M, int N, int K, int dt, int fused, int variant, int iters) {
     Problem q{B, M, N, K, dt, dt, fused, B};
     make_problem(q);
     void* dP_ref = q.dP;
-    if (g_tiled && fused) {      // repack [T][K/32][N] -> [T][N/16][K/32][16] on the host (the host copy q.P keeps the reference order)
+    size_t pbytes_dev = (size_t)(q.tenants == 1 ? 1 : B) * (K / 32) * N * 4;
+    if (g_tiled && fused) {      // repack on the host (the host copy q.P keeps the reference order for the checker)
         const int KW = K / 32, NT = (N + 15) / 16, T = (q.tenants == 1 ? 1 : B);
-        std::vector<uint32_t> tp((size_t)T * NT * KW * 16, 0u);
-        for (int t = 0; t < T; ++t)
-            for (int i = 0; i < KW; ++i)
-                for (int n = 0; n < N; ++n)
-                    tp[(((size_t)t * NT + (n >> 4)) * KW + i) * 16 + (n & 15)] = q.P[((size_t)t * KW + i) * N + n];
-        HIPCHECK(hipMalloc(&q.dP, tp.size() * 4));
-        HIPCHECK(hipMemcpy(q.dP, tp.data(), tp.size() * 4, hipMemcpyHostToDevice));
+        std::vector<uint32_t> tp;
+        if (g_tiled == 1) {      // [T][K/32][N] -> [T][N/16][K/32][16]
+            tp.assign((size_t)T * NT * KW * 16, 0u);
+            for (int t = 0; t < T; ++t)
+                for (int i = 0; i < KW; ++i)
+                    for (int n = 0; n < N; ++n)
+                        tp[(((size_t)t * NT + (n >> 4)) * KW + i) * 16 + (n & 15)] = q.P[((size_t)t * KW + i) * N + n];
+        } else {                 // -> [N/16][K/128][4 g][16][t_pad], byte s of a dword = byte g of word row 4 it + s
+            const int NIT = (K + 127) / 128, TP = tpad_of(T);
+            tp.assign((size_t)NT * NIT * 4 * 16 * TP, 0u);
+            for (int t = 0; t < T; ++t)
+                for (int i = 0; i < KW; ++i)
+                    for (int n = 0; n < N; ++n) {
+                        const uint32_t w = q.P[((size_t)t * KW + i) * N + n];
+                        const int it = i >> 2, sidx = i & 3;
+                        for (int g = 0; g < 4; ++g)
+                            tp[((((size_t)(n >> 4) * NIT + it) * 4 + g) * 16 + (n & 15)) * TP + t] |= ((w >> (8 * g)) & 0xffu) << (8 * sidx);
+                    }
+        }
+        pbytes_dev = tp.size() * 4;
+        HIPCHECK(hipMalloc(&q.dP, pbytes_dev));
+        HIPCHECK(hipMemcpy(q.dP, tp.data(), pbytes_dev, hipMemcpyHostToDevice));
     }
     bd_set_gemm_variant(variant);
     int rc = call_decode(q);
@@ -423,7 +442,7 @@ static int run_decode_cold(const char* tag, int B, int M, int N, int K, int dt, 
         HIPCHECK(hipMemcpy(hC.data(), q.dC, hC.size(), hipMemcpyDeviceToHost));
         bad = check_output(q, hC.data(), 2048, &max_err, &max_ulp);
     }
-    const double wbytes = fused ? 2.0 * N * K : 0.0, pbytes = (double)B * K * ((g_tiled && fused) ? (N + 15) / 16 * 16 : N) / 8;
+    const double wbytes = fused ? 2.0 * N * K : 0.0, pbytes = (double)pbytes_dev;
     const double bytes = 2.0 * B * M * K + (double)B * K * N / 8 + 2.0 * B * M * N + wbytes;
     int nset = (int)(600e6 / (wbytes + pbytes)) + 1;
     if (nset < 2) nset = 2;
@@ -672,7 +691,7 @@ int main(int argc, char** argv) {
         // streaming decode kernel (600, the automatic choice) vs the round-1 kernels (300 wave-specialised VALU, 500 one-launch col16),
         // warm (Infinity-Cache resident) and cold (HBM) weights.  argv[2] = "quick" -> headline shapes only
         const bool quick = argc > 2 && std::string(argv[2]) == "quick";
-        g_tiled = argc > 3 && std::string(argv[3]) == "tile";          // tile-major sign words for the streaming kernel (variant 600)
+        g_tiled = argc > 3 ? (std::string(argv[3]) == "tile" ? 1 : std::string(argv[3]) == "pack" ? 2 : 0) : 0;   // sign-word layout of variant 600
         for (int v : {600, 300, 500}) {
             if (g_tiled && v != 600) continue;
             for (int T : {1, 4, 6, 8}) {
@@ -703,9 +722,9 @@ int main(int argc, char** argv) {
             char tg[64];
             snprintf(tg, sizeof tg, "ab%02d_stream_4096sq", tune);   fails += run_tenant_cold(tg, 1, 4096, 4096, 200);
             snprintf(tg, sizeof tg, "ab%02d_stream_28672", tune);    fails += run_tenant_cold(tg, 1, 28672, 4096, 60);
-            for (int tiled : {0, 1}) {
+            for (int tiled : {0, 1, 2}) {
                 g_tiled = tiled;
-                const char* ly = tiled ? "tile" : "ref";
+                const char* ly = tiled == 2 ? "pack" : tiled ? "tile" : "ref";
                 snprintf(tg, sizeof tg, "ab%02d_%s_T1_4096sq", tune, ly);    fails += run_decode_cold(tg, 1, 1, 4096, 4096, BD_F16, 1, 600, 200);
                 snprintf(tg, sizeof tg, "ab%02d_%s_T6_4096sq", tune, ly);    fails += run_decode_cold(tg, 6, 1, 4096, 4096, BD_F16, 1, 600, 200);
                 snprintf(tg, sizeof tg, "ab%02d_%s_T6_qkv", tune, ly);       fails += run_decode_cold(tg, 6, 1, 6144, 4096, BD_F16, 1, 600, 200);

@@ -492,3 +492,46 @@ def test_binary_gemm_accepts_every_reference_word_width(bd, oracle):
         assert torch.equal(got2, want[0]), nb
     with pytest.raises(AssertionError):
         bd.binary_bmm(a, bd.pack(bits, 8), n_bits=16)                  # word dtype must match n_bits
+
+
+DECODE_LAYOUT_SHAPES = [
+    # B (tenants), M, K, N, per-tenant masks?
+    (6, 1, 1024, 1000, True), (1, 1, 4096, 4096, True), (3, 2, 512, 520, True), (5, 1, 1184, 777, True), (8, 2, 288, 640, True),
+    (2, 4, 160, 520, True), (1, 16, 512, 600, True), (4, 1, 2048, 1040, True), (6, 1, 4096, 6144, True), (7, 1, 384, 512, True),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", DECODE_LAYOUT_SHAPES)
+def test_binary_linear_decode_layouts_vs_oracle(bd, oracle, dtype, shape):
+    """bd_binary_linear_decode with tile-major and with packed (interleaved tenants, natural k order) sign words: same values as the
+    reference-layout call and the oracle; the repacks themselves are exact byte shuffles (checked against their definition)."""
+    B, M, K, N, _ = shape
+    a, p, w, alpha = rand_problem(B, M, K, N, dtype, B, seed=(B * 77 + M * 13 + K + N) & 0xffff)
+    ref32 = oracle.binary_linear(a, w, p, alpha, out_dtype=torch.float32, round_mode=0)
+    pd = dev(p)
+    tiled = bd.tile_masks(pd)
+    packed = bd.pack_decode_masks(pd)
+    # definition of the tile-major repack
+    n = torch.arange(N)
+    assert torch.equal(tiled[:, n // 16, :, n % 16].permute(1, 2, 0).cpu(), p)
+    # definition of the packed repack: byte s of [tile][it][g][c][t] = byte g of word row 4 it + s
+    pk = packed.cpu().view(torch.uint8).view(*packed.shape, 4)
+    pb = torch.nn.functional.pad(p, (0, 0, 0, (-p.shape[1]) % 4)).contiguous().view(torch.uint8).view(B, -1, N, 4)
+    for (t, i, nn_) in ((0, 0, 0), (B - 1, p.shape[1] - 1, N - 1), (B // 2, p.shape[1] // 2, N // 3)):
+        for g in range(4):
+            assert pk[nn_ // 16, i // 4, g, nn_ % 16, t, i % 4] == pb[t, i, nn_, g]
+    base = bd.binary_linear(dev(a), dev(w), pd, dev(alpha), out_dtype=torch.float32)
+    for layout, m in (("tile", tiled), ("packed", packed)):
+        y32 = bd.binary_linear_decode(dev(a), dev(w), m, dev(alpha), layout=layout, out_dtype=torch.float32)
+        fro, mrel = relerr(y32.cpu(), ref32)
+        assert fro <= 1e-5 and mrel <= 2e-5, (layout, fro, mrel)
+        assert relerr(y32.cpu(), base.cpu())[0] <= 2e-6
+        y16 = bd.binary_linear_decode(dev(a), dev(w), m, dev(alpha), layout=layout)
+        ok, same = within_one_ulp(y16.cpu(), ref32.to(dtype), K)
+        assert ok and same >= 0.99, (layout, ok, same)
+        r = torch.randn(B, M, N).to(dtype)
+        out = bd.binary_linear_decode(dev(a), dev(w), m, dev(alpha), layout=layout, residual=dev(r).clone())
+        want = (r.float() + ref32).to(dtype)
+        d = (out.cpu().float() - want.float()).abs()
+        assert (d <= (r.float().abs() + ref32.abs()) * (2 ** -7 if dtype == torch.bfloat16 else 2 ** -10) + 1e-4).all()
