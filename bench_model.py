@@ -15,6 +15,7 @@ import torch.nn.functional as F
 from bitdelta_amd.diff import BinaryDiff
 from bitdelta_amd.serving import DiffCompressModule
 from bitdelta_amd.diff import binarize
+from bitdelta_amd import serving_ops as ops
 
 CONFIGS = {
     # name: (hidden, intermediate, layers, heads, kv_heads, vocab)
@@ -113,13 +114,19 @@ class DecoderLayer(nn.Module):
         self.input_layernorm = RMSNorm(hid, dtype, device)
         self.post_attention_layernorm = RMSNorm(hid, dtype, device)
 
-    def forward(self, x, cos, sin, kv=None):
+    def forward(self, x, cos, sin, kv=None, rope=None):
         B, S, _ = x.shape
         h = self.input_layernorm(x)
-        q = self.q_proj(h).view(B, S, self.heads, self.hd).transpose(1, 2)
-        k = self.k_proj(h).view(B, S, self.kvh, self.hd).transpose(1, 2)
-        v = self.v_proj(h).view(B, S, self.kvh, self.hd).transpose(1, 2)
-        q, k = apply_rope(q, cos, sin), apply_rope(k, cos, sin)
+        if self.hd == 128 and rope is not None:
+            # fused in-place RoPE on the projection outputs (one pass instead of cat + mul + addcmul and their temporaries)
+            q = ops.rope_(self.q_proj(h), rope[0], rope[1], self.heads, S, rope[2]).view(B, S, self.heads, self.hd).transpose(1, 2)
+            k = ops.rope_(self.k_proj(h), rope[0], rope[1], self.kvh, S, rope[2]).view(B, S, self.kvh, self.hd).transpose(1, 2)
+            v = self.v_proj(h).view(B, S, self.kvh, self.hd).transpose(1, 2)
+        else:
+            q = self.q_proj(h).view(B, S, self.heads, self.hd).transpose(1, 2)
+            k = self.k_proj(h).view(B, S, self.kvh, self.hd).transpose(1, 2)
+            v = self.v_proj(h).view(B, S, self.kvh, self.hd).transpose(1, 2)
+            q, k = apply_rope(q, cos, sin), apply_rope(k, cos, sin)
         if kv is not None:                      # decode: write into the preallocated cache [B, kvh, Lmax, hd]
             pos = kv[2]
             kv[0][:, :, pos:pos + S] = k
@@ -134,7 +141,9 @@ class DecoderLayer(nn.Module):
         a = a.transpose(1, 2).reshape(B, S, self.heads * self.hd)
         x = x + self.o_proj(a)
         h = self.post_attention_layernorm(x)
-        x = x + self.down_proj(F.silu(self.gate_proj(h)) * self.up_proj(h))
+        g, u = self.gate_proj(h), self.up_proj(h)
+        act = ops.swiglu2(g, u) if g.shape[-1] % 8 == 0 else F.silu(g) * u       # one pass: round(silu(g)) * u
+        x = x + self.down_proj(act)
         return x
 
 
@@ -177,7 +186,8 @@ class Decoder(nn.Module):
             self._rope = (cos.to(self.dtype), sin.to(self.dtype))
             self._rope_key = key
         cos, sin = self._rope[0][pos0:], self._rope[1][pos0:]
+        rope = (self._rope[0], self._rope[1], pos0)          # whole tables + first position, for the fused in-place kernel
         x = self.embed(ids)
         for i, layer in enumerate(self.layers):
-            x = layer(x, cos, sin, None if cache is None else cache[i])
+            x = layer(x, cos, sin, None if cache is None else cache[i], rope)
         return self.lm_head(self.norm(x[:, -1:, :]))

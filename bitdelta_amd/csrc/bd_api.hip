@@ -900,18 +900,38 @@ extern "C" int bd_srv_rmsnorm(const void* X, const void* Wt, void* Y, int rows, 
     return launch_status();
 }
 
-extern "C" int bd_srv_swiglu(const void* GU, void* Y, int rows, int I, int64_t sg, int64_t sy, int dtype, void* stream) {
+extern "C" int bd_srv_swiglu(const void* G, const void* U, void* Y, int rows, int I, int64_t sg, int64_t su, int64_t sy, int dtype,
+                             void* stream) {
     if (rows < 0 || I < 0 || rows > 65535) return BD_E_BAD_SHAPE;
     if (dtype != BD_F16 && dtype != BD_BF16) return BD_E_BAD_DTYPE;
     if (rows == 0 || I == 0) return BD_OK;
-    if (!GU || !Y) return BD_E_NULL;
-    if (I % 8 || sg % 8 || sy % 8 || !aligned16(GU) || !aligned16(Y)) return BD_E_BAD_SHAPE;
+    if (!G || !U || !Y) return BD_E_NULL;
+    if (I % 8 || sg % 8 || su % 8 || sy % 8 || !aligned16(G) || !aligned16(U) || !aligned16(Y)) return BD_E_BAD_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)((I / 8 + 255) / 256), (unsigned)rows);
     if (dtype == BD_BF16)
-        hipLaunchKernelGGL((swiglu_kernel<DT_BF16>), grid, dim3(256), 0, st, (const unsigned short*)GU, (unsigned short*)Y, I, (long long)sg, (long long)sy);
+        hipLaunchKernelGGL((swiglu_kernel<DT_BF16>), grid, dim3(256), 0, st, (const unsigned short*)G, (const unsigned short*)U,
+                           (unsigned short*)Y, I, (long long)sg, (long long)su, (long long)sy);
     else
-        hipLaunchKernelGGL((swiglu_kernel<DT_F16>), grid, dim3(256), 0, st, (const unsigned short*)GU, (unsigned short*)Y, I, (long long)sg, (long long)sy);
+        hipLaunchKernelGGL((swiglu_kernel<DT_F16>), grid, dim3(256), 0, st, (const unsigned short*)G, (const unsigned short*)U,
+                           (unsigned short*)Y, I, (long long)sg, (long long)su, (long long)sy);
+    return launch_status();
+}
+
+extern "C" int bd_srv_rope(void* X, const void* cos_t, const void* sin_t, int rows, int heads, int head_dim, int64_t sx, int seq,
+                           int pos0, int dtype, void* stream) {
+    if (rows < 0 || heads < 1 || seq < 1 || pos0 < 0) return BD_E_BAD_SHAPE;
+    if (dtype != BD_F16 && dtype != BD_BF16) return BD_E_BAD_DTYPE;
+    if (rows == 0) return BD_OK;
+    if (!X || !cos_t || !sin_t) return BD_E_NULL;
+    if (head_dim != 128 || sx % 8 || !aligned16(X) || !aligned16(cos_t) || !aligned16(sin_t)) return BD_E_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == BD_BF16)
+        hipLaunchKernelGGL((rope_kernel<DT_BF16>), dim3(rows), dim3(256), 0, st, (unsigned short*)X, (const unsigned short*)cos_t,
+                           (const unsigned short*)sin_t, heads, (long long)sx, seq, pos0);
+    else
+        hipLaunchKernelGGL((rope_kernel<DT_F16>), dim3(rows), dim3(256), 0, st, (unsigned short*)X, (const unsigned short*)cos_t,
+                           (const unsigned short*)sin_t, heads, (long long)sx, seq, pos0);
     return launch_status();
 }
 
@@ -932,7 +952,7 @@ extern "C" int bd_srv_decode_attention(const void* QKV, const void* cos_t, const
     p.scale = 1.0f / sqrtf((float)head_dim);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)(T * KVH));
-#define BD_ATT(DT, GG) hipLaunchKernelGGL((decode_attn_kernel<DT, GG>), grid, dim3(1024), 0, st, p)
+#define BD_ATT(DT, GG) hipLaunchKernelGGL((decode_attn_kernel<DT, GG>), grid, dim3(512), 0, st, p)
     if (dtype == BD_BF16) { if (G == 1) BD_ATT(DT_BF16, 1); else BD_ATT(DT_BF16, 4); }
     else { if (G == 1) BD_ATT(DT_F16, 1); else BD_ATT(DT_F16, 4); }
 #undef BD_ATT

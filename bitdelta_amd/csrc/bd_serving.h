@@ -6,6 +6,7 @@
 //
 //   rmsnorm_tenant_kernel   y[r] = w[tenant(r)] * round16(x[r] * rsqrt(mean(x[r]^2) + eps))        (HF RMSNorm, per-tenant weight)
 //   swiglu_kernel           y = round16(silu(g)) * u     from the fused gate|up output               (HF MLP act_fn(gate) * up)
+//   rope_kernel             in-place rotary embedding of a q / k projection output (prefill)
 //   decode_attn_kernel      RoPE(q, k_new) -> KV-cache append -> softmax(q.K^T / sqrt(d)) . V        one new token per tenant, GQA
 #pragma once
 #include "bd_common.h"
@@ -57,14 +58,14 @@ __global__ void __launch_bounds__(256) rmsnorm_tenant_kernel(const unsigned shor
     }
 }
 
-// gu [rows, 2*I] (gate columns then up columns, row stride sg) -> y [rows, I];  I % 8 == 0
+// g, u [rows, I] (row strides sg, su; the fused gate|up output passes u = g + I) -> y [rows, I];  I % 8 == 0
 template <int DT>
-__global__ void __launch_bounds__(256) swiglu_kernel(const unsigned short* __restrict__ gu, unsigned short* __restrict__ y, int I,
-                                                     long long sg, long long sy) {
+__global__ void __launch_bounds__(256) swiglu_kernel(const unsigned short* __restrict__ gp, const unsigned short* __restrict__ up,
+                                                     unsigned short* __restrict__ y, int I, long long sg, long long su, long long sy) {
     const int r = blockIdx.y;
     const int c = (blockIdx.x * 256 + threadIdx.x) * 8;
     if (c >= I) return;
-    const u32x4_t g = *(const u32x4_t*)(gu + (long long)r * sg + c), u = *(const u32x4_t*)(gu + (long long)r * sg + I + c);
+    const u32x4_t g = *(const u32x4_t*)(gp + (long long)r * sg + c), u = *(const u32x4_t*)(up + (long long)r * su + c);
     u32x4_t o;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
@@ -76,6 +77,43 @@ __global__ void __launch_bounds__(256) swiglu_kernel(const unsigned short* __res
         o[d] = lo | (hi << 16);
     }
     *(u32x4_t*)(y + (long long)r * sy + c) = o;
+}
+
+// In-place rotary embedding of [rows, heads * 128] (a q or k projection output before the head transpose), HF rotate-half form with
+// the sign folded into `sin`: out[d] = round16(round16(x[d] * cos[d]) + x[d +- 64] * sin[d])  -- the rounding points of the stock
+// composition `torch.addcmul(x * cos, rot, sin)`, which costs five passes (cat, mul, addcmul + two temporaries) instead of one.
+// Position of row r = pos0 + r % seq.  One block per row, one thread per (head, 8 dims of the lower half + their partners).
+template <int DT>
+__global__ void __launch_bounds__(256) rope_kernel(unsigned short* __restrict__ x, const unsigned short* __restrict__ cos_t,
+                                                   const unsigned short* __restrict__ sin_t, int heads, long long sx, int seq, int pos0) {
+    const int r = blockIdx.x;
+    const long long pos = pos0 + r % seq;
+    const unsigned short* cs = cos_t + pos * 128;
+    const unsigned short* sn = sin_t + pos * 128;
+    for (int i = threadIdx.x; i < heads * 8; i += 256) {
+        const int h = i >> 3, d0 = (i & 7) * 8;
+        unsigned short* px = x + (long long)r * sx + h * 128;
+        const u32x4_t lo = *(const u32x4_t*)(px + d0), hi = *(const u32x4_t*)(px + 64 + d0);
+        const u32x4_t cl = *(const u32x4_t*)(cs + d0), ch = *(const u32x4_t*)(cs + 64 + d0);
+        const u32x4_t sl = *(const u32x4_t*)(sn + d0), sh = *(const u32x4_t*)(sn + 64 + d0);
+        u32x4_t ol, oh;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            uint32_t rl = 0, rh = 0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int shf = 16 * e;
+                const float a = half_bits_to_f32<DT>((lo[d] >> shf) & 0xffffu), b = half_bits_to_f32<DT>((hi[d] >> shf) & 0xffffu);
+                const float c0 = half_bits_to_f32<DT>((cl[d] >> shf) & 0xffffu), c1 = half_bits_to_f32<DT>((ch[d] >> shf) & 0xffffu);
+                const float s0 = half_bits_to_f32<DT>((sl[d] >> shf) & 0xffffu), s1 = half_bits_to_f32<DT>((sh[d] >> shf) & 0xffffu);
+                rl |= f32_to_half_bits<DT>(round16<DT>(a * c0) + b * s0) << shf;
+                rh |= f32_to_half_bits<DT>(round16<DT>(b * c1) + a * s1) << shf;
+            }
+            ol[d] = rl; oh[d] = rh;
+        }
+        *(u32x4_t*)(px + d0) = ol;
+        *(u32x4_t*)(px + 64 + d0) = oh;
+    }
 }
 
 struct AttnParams {
@@ -92,14 +130,15 @@ struct AttnParams {
     float scale;                   // 1 / sqrt(head_dim)
 };
 
-// One block of 16 waves per (tenant, kv head): its G = H / KVH query heads share the K / V stream.  Lane (kq = l >> 4, d8 = l & 15)
-// reads 16 bytes (dims 8*d8 .. +7) of key / value row l0 + kq, so a wave instruction covers 4 whole 256-byte rows and the block 64
-// rows per iteration (a 512-token cache is 8 iterations); the next iteration's rows are in flight while the current ones are
-// scored.  Online softmax per head in fp32; the 4 row slots of a wave are merged with lane shuffles, the 16 waves through LDS.
-// head_dim = 128, G in {1, 4}.  (The first version ran 4 waves with no prefetch: 32 dependent HBM round trips per layer.)
+// One block of 8 waves per (tenant, kv head): its G = H / KVH query heads share the K / V stream.  Lane (kq = l >> 4, d8 = l & 15)
+// reads 16 bytes (dims 8*d8 .. +7) of key / value row l0 + kq, so a wave instruction covers 4 whole 256-byte rows and the block 32
+// rows per iteration; a 4-deep register ring keeps the rows of the next 4 iterations in flight (8 KB per wave), so the loop runs at
+// its issue rate instead of one HBM round trip per iteration.  Online softmax per head in fp32; the 4 row slots of a wave are merged
+// with lane shuffles, the 8 waves through LDS.  head_dim = 128, G in {1, 4}.
+// (History, profiles/r02_decode_step.txt: 4 waves, no prefetch -> 16 waves, one iteration ahead: 21 us per layer -> this form.)
 template <int DT, int G>
-__global__ void __launch_bounds__(1024) decode_attn_kernel(const AttnParams p) {
-    constexpr int HD = 128, NWV = 16;
+__global__ void __launch_bounds__(512) decode_attn_kernel(const AttnParams p) {
+    constexpr int HD = 128, NWV = 8, RPI = 4 * NWV, DEPTH = 4;
     __shared__ float q_lds[G][HD];              // rotated, pre-scaled queries
     __shared__ float kn_lds[HD], vn_lds[HD];    // the new token's rotated key / value (also written to the cache)
     __shared__ float m_lds[NWV][G], s_lds[NWV][G];
@@ -114,19 +153,20 @@ __global__ void __launch_bounds__(1024) decode_attn_kernel(const AttnParams p) {
     unsigned short* vbase = p.vc + ((long long)t * p.KVH + kvh) * p.Lc * HD;
     const unsigned char* vld = p.valid + (long long)t * p.Lc;
     const int kq = lane >> 4, d8 = lane & 15;
-    const int slot = 4 * wave + kq;                      // this lane group's row slot (0..63)
+    const int slot = 4 * wave + kq;                      // this lane group's row slot (0 .. RPI-1)
 
-    // first rows in flight before anything else (they do not depend on the new token)
-    auto load_row = [&](long long l, u32x4_t& kk, u32x4_t& vv, bool& ok) {
+    struct Rows { u32x4_t kk, vv; bool ok; };
+    auto load_row = [&](long long l, Rows& r) {
         const bool in = l < pos;                          // row `pos` itself comes from LDS (it is being written by this block)
         const long long lc = in ? l : 0;
-        kk = *(const u32x4_t*)(kbase + lc * HD + 8 * d8);
-        vv = *(const u32x4_t*)(vbase + lc * HD + 8 * d8);
-        ok = in && vld[lc] != 0;
+        r.kk = *(const u32x4_t*)(kbase + lc * HD + 8 * d8);
+        r.vv = *(const u32x4_t*)(vbase + lc * HD + 8 * d8);
+        r.ok = in && vld[lc] != 0;
     };
-    u32x4_t kk, vv;
-    bool ok;
-    load_row(slot, kk, vv, ok);
+    // the first DEPTH iterations' rows go in flight before anything else (they do not depend on the new token)
+    Rows ring[DEPTH];
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) load_row((long long)u * RPI + slot, ring[u]);
 
     // ---- phase 0: RoPE of the G query heads and of the new key (torch: round16(round16(x*cos) + rot*sin)), cache append
     auto rope = [&](const unsigned short* v, int d) {
@@ -134,12 +174,12 @@ __global__ void __launch_bounds__(1024) decode_attn_kernel(const AttnParams p) {
         const float a = round16<DT>(x * half_bits_to_f32<DT>(cs[d]));
         return round16<DT>(a + xr * half_bits_to_f32<DT>(sn[d]));
     };
-    for (int i = threadIdx.x; i < G * HD; i += 1024) {
+    for (int i = threadIdx.x; i < G * HD; i += 64 * NWV) {
         const int g = i / HD, d = i % HD;
         q_lds[g][d] = rope(row + (long long)(kvh * G + g) * HD, d) * p.scale;
     }
-    if (threadIdx.x >= 1024 - HD) {                      // the last two waves (the first ones may be busy with the q heads)
-        const int d = threadIdx.x - (1024 - HD);
+    if (threadIdx.x >= 64 * NWV - HD) {                  // the last two waves (the first ones may be busy with the q heads)
+        const int d = threadIdx.x - (64 * NWV - HD);
         const float kr = rope(row + (long long)(p.H + kvh) * HD, d);
         const unsigned short vn = row[(long long)(p.H + p.KVH + kvh) * HD + d];
         kn_lds[d] = kr;
@@ -178,29 +218,28 @@ __global__ void __launch_bounds__(1024) decode_attn_kernel(const AttnParams p) {
             }
         }
     };
-    const long long nrows = pos + 1;                     // rows 0 .. pos
-    const long long niter = (nrows + 63) / 64;           // uniform over the block (shuffles need whole 16-lane groups only, but
-                                                         // keeping the trip count uniform lets every lane run the prefetch)
-    for (long long it = 0; it < niter; ++it) {
-        const long long l = it * 64 + slot;
-        u32x4_t kn2, vn2;
-        bool ok2;
-        load_row(l + 64, kn2, vn2, ok2);                  // next iteration's rows
-        float kf[8], vf[8];
-        bool use = ok;
-        if (l == pos) {
-            use = true;
+    const long long nrows = pos + 1;                                       // rows 0 .. pos
+    const long long niter = (nrows + RPI - 1) / RPI;                       // uniform over the block
+    for (long long it0 = 0; it0 < niter; it0 += DEPTH) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { kf[e] = kn_lds[8 * d8 + e]; vf[e] = vn_lds[8 * d8 + e]; }
-        } else {
+        for (int u = 0; u < DEPTH; ++u) {
+            const long long l = (it0 + u) * RPI + slot;
+            float kf[8], vf[8];
+            bool use = ring[u].ok;
+            if (l == pos) {
+                use = true;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                kf[2 * d] = half_bits_to_f32<DT>(kk[d] & 0xffffu); kf[2 * d + 1] = half_bits_to_f32<DT>(kk[d] >> 16);
-                vf[2 * d] = half_bits_to_f32<DT>(vv[d] & 0xffffu); vf[2 * d + 1] = half_bits_to_f32<DT>(vv[d] >> 16);
+                for (int e = 0; e < 8; ++e) { kf[e] = kn_lds[8 * d8 + e]; vf[e] = vn_lds[8 * d8 + e]; }
+            } else {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    kf[2 * d] = half_bits_to_f32<DT>(ring[u].kk[d] & 0xffffu); kf[2 * d + 1] = half_bits_to_f32<DT>(ring[u].kk[d] >> 16);
+                    vf[2 * d] = half_bits_to_f32<DT>(ring[u].vv[d] & 0xffffu); vf[2 * d + 1] = half_bits_to_f32<DT>(ring[u].vv[d] >> 16);
+                }
             }
+            score_row(kf, vf, use);                                         // rows past `pos` carry ok = false
+            load_row(l + (long long)DEPTH * RPI, ring[u]);                   // refill this slot DEPTH iterations ahead
         }
-        score_row(kf, vf, use);
-        kk = kn2; vv = vn2; ok = ok2;
     }
     // merge the 4 row slots of the wave (lanes l, l^16, l^32 hold the same dims of different rows)
 #pragma unroll
@@ -224,7 +263,7 @@ __global__ void __launch_bounds__(1024) decode_attn_kernel(const AttnParams p) {
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < G * HD; i += 1024) {
+    for (int i = threadIdx.x; i < G * HD; i += 64 * NWV) {
         const int g = i / HD, d = i % HD;
         float mm = -1e30f;
 #pragma unroll

@@ -21,12 +21,19 @@ def rmsnorm_tenant(x, w, eps):
 
 def swiglu(gu, inter):
     """gu [T, M, 2*inter] (gate columns, then up columns) -> round(silu(gate)) * up, [T, M, inter]"""
-    require_gpu(gu)
-    T, M, W = gu.shape
-    assert W == 2 * inter and gu.stride(2) == 1 and gu.stride(0) == M * gu.stride(1)
-    y = torch.empty((T, M, inter), device=gu.device, dtype=gu.dtype)
-    with torch.cuda.device(gu.device):
-        check(lib().bd_srv_swiglu(ptr(gu), ptr(y), T * M, inter, gu.stride(1), inter, DTYPE_CODE[gu.dtype], stream_ptr()),
+    assert gu.shape[2] == 2 * inter
+    return swiglu2(gu[..., :inter], gu[..., inter:])
+
+
+def swiglu2(g, u):
+    """g, u [B, S, I] (views allowed: last dim contiguous, rows evenly strided) -> round(silu(g)) * u as a new [B, S, I] tensor"""
+    require_gpu(g, u)
+    B, S, I = g.shape
+    assert u.shape == g.shape and u.dtype == g.dtype and g.stride(2) == 1 and u.stride(2) == 1
+    assert g.stride(0) == S * g.stride(1) and u.stride(0) == S * u.stride(1)
+    y = torch.empty((B, S, I), device=g.device, dtype=g.dtype)
+    with torch.cuda.device(g.device):
+        check(lib().bd_srv_swiglu(ptr(g), ptr(u), ptr(y), B * S, I, g.stride(1), u.stride(1), I, DTYPE_CODE[g.dtype], stream_ptr()),
               "srv_swiglu")
     return y
 
@@ -51,3 +58,15 @@ def decode_attention(qkv, cos, sin, kcache, vcache, valid, pos, heads, kv_heads)
 
 def decode_attention_supported(heads, kv_heads, head_dim):
     return head_dim == 128 and heads % kv_heads == 0 and heads // kv_heads in (1, 4)
+
+
+def rope_(x, cos, sin, heads, seq, pos0=0):
+    """In-place rotary embedding of x [B, S, heads * 128] (a q / k projection output, before the head transpose); row r sits at position
+    pos0 + r % seq.  cos / sin [Lmax, 128] in x.dtype with the rotate-half sign folded into sin.  Returns x."""
+    require_gpu(x, cos, sin)
+    assert x.dim() == 3 and x.shape[2] == heads * 128 and x.stride(2) == 1 and x.stride(0) == x.shape[1] * x.stride(1)
+    assert cos.is_contiguous() and sin.is_contiguous() and cos.dtype == x.dtype and cos.shape[0] >= pos0 + seq
+    with torch.cuda.device(x.device):
+        check(lib().bd_srv_rope(ptr(x), ptr(cos), ptr(sin), x.shape[0] * x.shape[1], heads, 128, x.stride(1), seq, pos0,
+                                DTYPE_CODE[x.dtype], stream_ptr()), "srv_rope")
+    return x

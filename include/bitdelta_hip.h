@@ -118,14 +118,18 @@ int bd_tenant_linear(const void* X, const void* W, void* Y, int T, int M, int N,
  * between two of the reference's Linears).  Not the hot path: they exist because at decode every stock op is a launch.
  * bd_srv_rmsnorm: Y[r] = Wt[r / rows_per_tenant] * round(X[r] * rsqrt(mean(X[r]^2) + eps))   (HF RMSNorm with per-tenant weights,
  *   the DataParallelModule-wrapped norms of demo_backend.py:62-79); X, Y [rows, H] (strides sx, sy), Wt [tenants, H] (stride sw).
- * bd_srv_swiglu:  Y = round(silu(G)) * U from the fused gate|up output GU [rows, 2*I] (row stride sg) -> Y [rows, I].
+ * bd_srv_swiglu:  Y = round(silu(G)) * U, G / U [rows, I] (row strides sg / su; the fused gate|up output passes U = G + I) -> Y [rows, I].
  * bd_srv_decode_attention: one new token per tenant: RoPE of q and the new k (tables cos/sin [Lmax, 128], rotate-half sign folded
  *   into sin), append k/v at *pos to the caches [T, KVH, Lc, 128], mark valid[t, *pos], then softmax(q.K^T/sqrt(128)).V over the
  *   valid keys 0..*pos (left padding = 0 in valid [T, Lc] bytes), grouped-query (H/KVH in {1, 4}); QKV [T, (H+2*KVH)*128] is the
  *   fused q+k+v Linear's output; out [T, H*128].  `pos` is a DEVICE scalar so the step replays inside a hipGraph. */
 int bd_srv_rmsnorm(const void* X, const void* Wt, void* Y, int rows, int H, int64_t sx, int64_t sy, int64_t sw,
                    int rows_per_tenant, float eps, int dtype, void* stream);
-int bd_srv_swiglu(const void* GU, void* Y, int rows, int I, int64_t sg, int64_t sy, int dtype, void* stream);
+int bd_srv_swiglu(const void* G, const void* U, void* Y, int rows, int I, int64_t sg, int64_t su, int64_t sy, int dtype, void* stream);
+/* bd_srv_rope: in-place rotary embedding of X [rows, heads*128] (row stride sx), position of row r = pos0 + r % seq, tables as for
+ * bd_srv_decode_attention; rounds where `torch.addcmul(x * cos, rotate_half(x), sin)` rounds. */
+int bd_srv_rope(void* X, const void* cos_t, const void* sin_t, int rows, int heads, int head_dim, int64_t sx, int seq, int pos0,
+                int dtype, void* stream);
 int bd_srv_decode_attention(const void* QKV, const void* cos_t, const void* sin_t, void* kcache, void* vcache, void* valid,
                             const int64_t* pos, void* out, int T, int H, int KVH, int head_dim, int Lc,
                             int64_t s_qkv, int64_t s_out, int dtype, void* stream);

@@ -283,6 +283,15 @@ def test_decode_glue_kernels_vs_torch_ops(bd):
         want = F.silu(gu[..., :I]) * gu[..., I:]
         got = ops.swiglu(gu, I)
         assert torch.allclose(got.float(), want.float(), rtol=2 ** -7 if dtype == torch.bfloat16 else 2 ** -9, atol=1e-3)
+        # fused in-place RoPE (prefill): bit-identical to the stock composition torch.addcmul(x * cos, rotate_half(x), sin)
+        Bq, Sq, Hq = 2, 37, 5
+        cos_t, sin_t = _rope_tables(64, 128, dev, dtype)
+        xq = torch.randn(Bq, Sq, Hq * 128, device=dev).to(dtype)
+        want = _rope(xq.view(Bq, Sq, Hq, 128).transpose(1, 2), cos_t[3:3 + Sq], sin_t[3:3 + Sq]).transpose(1, 2).reshape(Bq, Sq, Hq * 128)
+        got = ops.rope_(xq.clone(), cos_t, sin_t, Hq, Sq, 3)
+        assert torch.equal(got, want)
+        g2, u2 = torch.randn(2, 9, 264, device=dev).to(dtype), torch.randn(2, 9, 264, device=dev).to(dtype)
+        assert torch.allclose(ops.swiglu2(g2, u2).float(), (F.silu(g2) * u2).float(), rtol=2 ** -7 if dtype == torch.bfloat16 else 2 ** -9, atol=1e-3)
         for heads, kvh in ((8, 2), (4, 4)):                              # G = 4 (Mistral-style GQA) and G = 1 (Llama-2-7B-style MHA)
             hd, Lc, pos = 128, 96, 70
             cos, sin = _rope_tables(Lc, hd, dev, dtype)
