@@ -15,6 +15,17 @@ namespace bd {
 
 template <int DT> __device__ __forceinline__ float round16(float v) { return half_bits_to_f32<DT>(f32_to_half_bits<DT>(v)); }
 
+// sum over the 16 lanes of a DPP row, result in every lane: quad xor 1, quad xor 2, half-row mirror, row mirror -- four VALU ops.
+// (__shfl_xor lowers to ds_bpermute_b32: an LDS-crossbar round trip per step; four dependent ones per head per key row made the
+// decode attention kernel latency-chain-bound at ~3000 cycles per 32 rows.)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
+    return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -202,13 +213,17 @@ __global__ void __launch_bounds__(512) decode_attn_kernel(const AttnParams p) {
         for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
     }
     auto score_row = [&](const float (&kf)[8], const float (&vf)[8], bool valid_row) {
+        float scv[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             float sc = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) sc += q[g][e] * kf[e];
+            scv[g] = row16_sum(sc);                                                  // over the 16 lanes of this row (DPP)
+        }
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) sc += __shfl_xor(sc, o, 64);          // over the 16 lanes of this row
+        for (int g = 0; g < G; ++g) {
+            const float sc = scv[g];
             if (valid_row) {                                                         // uniform within the 16 lanes
                 const float mn = fmaxf(m[g], sc), f = __expf(m[g] - mn), pw = __expf(sc - mn);
                 s[g] = s[g] * f + pw;

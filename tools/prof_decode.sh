@@ -16,12 +16,14 @@ run() {   # tag T N K variant tiled
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/$tag/pmc3" -o p -- $H dec1 "$@" 10 > "$OUT/$tag.pmc3.log" 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/$tag/pmc4" -o p -- $H dec1 "$@" 10 > "$OUT/$tag.pmc4.log" 2>&1
 }
-run o_4096_T6_tile      6 4096 4096 600 1
+# last argument: sign-word layout of the streaming kernel (0 reference [K/32,N], 1 tile-major, 2 packed)
+run o_4096_T6_pack      6 4096 4096 600 2
 run o_4096_T6_ref       6 4096 4096 600 0
-run gateup_T6_tile      6 28672 4096 600 1
-run down_T6_tile        6 4096 14336 600 1
-run qkv_T6_tile         6 6144 4096 600 1
-run o_4096_T1_tile      1 4096 4096 600 1
+run gateup_T6_pack      6 28672 4096 600 2
+run gateup_T6_ref       6 28672 4096 600 0
+run down_T6_pack        6 4096 14336 600 2
+run qkv_T6_pack         6 6144 4096 600 2
+run o_4096_T1_pack      1 4096 4096 600 2
 run o_4096_T6_r01valu   6 4096 4096 300 0
 run gateup_T6_r01valu   6 28672 4096 300 0
 # keep only the small CSVs
