@@ -172,7 +172,7 @@ def delta_gemm_microbench(dev, M=4096, N=4096, K=4096, iters=30):
             "bytes_per_launch": 2.0 * M * K + K * N / 8 + 2.0 * M * N}
 
 
-def run_mt_decode(dev, timer, model_name, tenants, kv_len, steps, warmup, layers=None, seed=4321):
+def run_mt_decode(dev, timer, model_name, tenants, kv_len, steps, warmup, layers=None, seed=4321, ab_glue=False):
     """configs[2] / [4]: one base + `tenants` 1-bit deltas, greedy decode steps at cache length ~kv_len through the serving loop.
     Returns a dict of eager / hipGraph step times and the HBM roofline of the Linear launches."""
     from bitdelta_amd import dist as bdd
@@ -218,6 +218,21 @@ def run_mt_decode(dev, timer, model_name, tenants, kv_len, steps, warmup, layers
         graph_ms = graph_s / steps * 1e3
     except Exception as e:          # report, never hide
         graph_err = f"{type(e).__name__}: {e}"
+    ab = None
+    if ab_glue and graph_ms is not None:
+        # same process, same box, alternating: the step with RMSNorm / SwiGLU folded into the Linear launches vs separate glue launches
+        ab = {"fused_glue_ms": [], "separate_glue_ms": []}
+        runners = {}
+        for name, flag in (("fused_glue_ms", True), ("separate_glue_ms", False)):
+            dec.fuse_glue = flag
+            restore()
+            runners[name] = dec._graph_runner(st)
+        for _ in range(3):
+            for name, run in runners.items():
+                restore()
+                run()
+                ab[name].append(bdd.timed_region(run, steps, device_sync=torch.cuda.synchronize) / steps * 1e3)
+        dec.fuse_glue = True
     lin_bytes, head_bytes = dec.linear_bytes_per_step()
     best_ms = graph_ms if graph_ms is not None else eager_s / steps * 1e3
     out = {
@@ -237,6 +252,8 @@ def run_mt_decode(dev, timer, model_name, tenants, kv_len, steps, warmup, layers
         "step_frac_of_hbm_peak": (lin_bytes + head_bytes) / (best_ms * 1e-3) * 1e-9 / PEAK_HBM_GBS,
         "peak_gbs": PEAK_HBM_GBS,
     }
+    if ab is not None:
+        out["glue_ab"] = ab
     del dec, cache, st
     torch.cuda.empty_cache()
     return out
@@ -257,6 +274,7 @@ def main():
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result is then marked invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ab-glue", action="store_true", help="mt-decode: also time the step with separate RMSNorm / SwiGLU launches")
     ap.add_argument("--no-mt-decode", action="store_true", help="skip the configs[2] leg of the default run")
     args = ap.parse_args()
 
@@ -283,7 +301,8 @@ def main():
     if args.workload == "mt-decode":
         tenants = args.tenants or 6
         model = args.model or "mistral-7b"
-        d = run_mt_decode(dev, timer, model, tenants, args.kv_len, args.steps, args.warmup, layers=args.layers, seed=4321 + rank)
+        d = run_mt_decode(dev, timer, model, tenants, args.kv_len, args.steps, args.warmup, layers=args.layers, seed=4321 + rank,
+                          ab_glue=args.ab_glue)
         ms = d["hipgraph_ms_per_step"] or d["eager_ms_per_step"]      # already the MAX over ranks (dist.timed_region)
         if rank != 0:
             return

@@ -197,12 +197,21 @@ def decode_shape_ok(B, M, N, K, n_masks):
     return (1 if n_masks == 1 else chunk) <= 8
 
 
-def binary_linear_decode(x, weight, mask, alpha, *, layout="tile", out_dtype=None, groups=1, residual=None):
+def fused_norm_ok(B, M, K):
+    """envelope of the fused RMSNorm prologue of bd_binary_linear_decode_fused (include/bitdelta_hip.h)"""
+    return M == 1 and K >= 2048 and K & (K - 1) == 0 and B * K <= 16 * 2048 and 83968 + B * (2 * K + 16) <= 160 * 1024
+
+
+def binary_linear_decode(x, weight, mask, alpha, *, layout="tile", out_dtype=None, groups=1, residual=None,
+                         norm_weight=None, eps=1e-5, swiglu=False):
     """binary_linear for decode shapes with repacked masks: one launch of the streaming kernel.
     x: (B, M, K), M <= 16; weight (N, K); alpha fp32 (B or 1, groups);
     layout "tile":   mask = tile_masks(...)        (B or 1, ceil(N/16), K/32, 16)
-    layout "packed": mask = pack_decode_masks(...) (ceil(N/16), ceil(K/128), 4, 16, t_pad), B <= t_pad tenants, B*M <= 16."""
-    require_gpu(x, weight, mask, alpha, residual)
+    layout "packed": mask = pack_decode_masks(...) (ceil(N/16), ceil(K/128), 4, 16, t_pad), B <= t_pad tenants, B*M <= 16.
+    Packed layout only: norm_weight (B or 1, K) fuses the HF RMSNorm of x (x = the un-normalised residual stream) into the launch;
+    swiglu=True (with norm_weight) treats weight/mask as a gate|up pair interleaved in blocks of 8 output rows, alpha (B or 1, 2) =
+    (gate, up) scales, and returns act_fn(gate) * up, (B, M, N/2).  Both bit-identical to the separate launches."""
+    require_gpu(x, weight, mask, alpha, residual, norm_weight)
     B, M, K = x.shape
     N = weight.shape[0]
     assert mask.dtype == torch.int32 and mask.is_contiguous()
@@ -223,11 +232,25 @@ def binary_linear_decode(x, weight, mask, alpha, *, layout="tile", out_dtype=Non
     alpha = alpha.reshape(-1, groups)
     assert alpha.shape[0] in (1, B)
     sAlb = 0 if alpha.shape[0] == 1 else groups
+    if norm_weight is not None or swiglu:
+        assert layout == "packed" and norm_weight is not None and fused_norm_ok(B, M, K)
+        assert norm_weight.dim() == 2 and norm_weight.shape[1] == K and norm_weight.shape[0] in (1, B)
+        assert norm_weight.dtype == x.dtype and norm_weight.stride(1) == 1
+        assert not swiglu or (groups == 2 and N % 16 == 0 and residual is None and out_dtype == x.dtype)
+        s_norm = 0 if (norm_weight.shape[0] == 1 and B > 1) else norm_weight.stride(0)
     if residual is not None:
         assert residual.shape == (B, M, N) and residual.dtype == out_dtype and residual.stride(2) == 1
         y = residual
     else:
-        y = torch.empty((B, M, N), device=x.device, dtype=out_dtype)
+        y = torch.empty((B, M, N // 2 if swiglu else N), device=x.device, dtype=out_dtype)
+    if norm_weight is not None:
+        with torch.cuda.device(x.device):
+            check(lib().bd_binary_linear_decode_fused(ptr(x), ptr(weight), ptr(mask), t_pad, ptr(alpha), ptr(y), B, M, N, K,
+                                                      x.stride(0), x.stride(1), weight.stride(0), sPb, sAlb, groups, y.stride(0),
+                                                      y.stride(1), DTYPE_CODE[x.dtype], DTYPE_CODE[out_dtype],
+                                                      1 if residual is not None else 0, ptr(norm_weight), s_norm, float(eps),
+                                                      1 if swiglu else 0, stream_ptr()), "binary_linear_decode_fused")
+        return y
     with torch.cuda.device(x.device):
         check(lib().bd_binary_linear_decode(ptr(x), ptr(weight), ptr(mask), code, t_pad, ptr(alpha), ptr(y), B, M, N, K,
                                             x.stride(0), x.stride(1), weight.stride(0), sPb, sAlb, groups, y.stride(0),

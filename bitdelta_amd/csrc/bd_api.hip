@@ -14,6 +14,7 @@
 #include "bd_gemv.h"
 #include "bd_gemv_stream.h"
 #include "bd_serving.h"
+#include <algorithm>
 #include <atomic>
 
 using namespace bd;
@@ -121,6 +122,10 @@ struct Problem {
     int mask_tiled;           // 0: P is [B or 1, K/32, N] (reference layout); 1: tile-major [B or 1, ceil(N/16), K/32, 16];
                               // 2: packed decode layout [ceil(N/16), ceil(K/128), 4, 16, t_pad] (decode kernel only, see bd_gemv_stream.h)
     int t_pad;                // layout 2: dwords per (tile, iteration, lane group, column) = tenants padded to 1 / 2 / 4 / 6 / 8
+    const void* norm_w;       // layout 2 only: fused RMSNorm prologue (A is the un-normalised residual stream); [B or 1, K], stride sNw
+    int64_t sNw;
+    float eps;
+    int epilogue;             // layout 2 only: 1 = SwiGLU over an 8-interleaved gate|up projection (C has N/2 columns)
     void* ws;
     int64_t ws_bytes;
     hipStream_t st;
@@ -311,12 +316,15 @@ inline bool stream_ok(const Problem& q, int rows, int nmask) {
     return xb > 0 && xb < lim && wb < lim && pb < lim && q.sAb >= 0 && q.sAm >= 0;
 }
 
-template <int DT, int NM, bool HASW, int NS, int NW = 8, int WNAT = 0, int AUX = 2, int PK = 0>
+constexpr int STREAM_LDS_MAX = 160 * 1024;        // LDS of a gfx950 CU: the fused-norm kernels add R activation rows to STREAM_LDS_BYTES
+template <int DT, int NM, bool HASW, int NS, int NW = 8, int WNAT = 0, int AUX = 2, int PK = 0, int XL = 0, int EPI = 0>
 int launch_stream_inst(const StreamParams& sp, dim3 grid, hipStream_t st) {
-    auto kern = gemv_stream_kernel<DT, NM, HASW, NS, NW, WNAT, AUX, PK>;
+    auto kern = gemv_stream_kernel<DT, NM, HASW, NS, NW, WNAT, AUX, PK, XL, EPI>;
     static std::atomic<uint64_t> lds_done{0};
-    if (!ensure_dyn_lds((const void*)kern, STREAM_LDS_BYTES, lds_done)) return BD_E_LAUNCH;
-    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), STREAM_LDS_BYTES, st, sp);
+    const int lds = XL ? std::max((int)(sp.xs_off + (uint32_t)sp.g.R * sp.xrow), STREAM_LDS_BYTES) : STREAM_LDS_BYTES;
+    if (lds > STREAM_LDS_MAX) return BD_E_BAD_SHAPE;
+    if (!ensure_dyn_lds((const void*)kern, XL ? STREAM_LDS_MAX : STREAM_LDS_BYTES, lds_done)) return BD_E_LAUNCH;
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, sp);
     return BD_OK;
 }
 
@@ -370,6 +378,12 @@ int launch_gemv_stream_chunk(const Problem& q) {
     sp.pts = q.mask_tiled == 1 ? 16u * (uint32_t)(q.K / 32) : 16u;
     sp.prs = q.mask_tiled == 1 ? 16u : (uint32_t)q.N;
     sp.tp = (uint32_t)q.t_pad;
+    sp.nw = (const unsigned short*)q.norm_w; sp.sNw = q.sNw; sp.eps = q.eps;
+    sp.n_bytes = q.norm_w ? (uint32_t)(((int64_t)(q.B - 1) * q.sNw + q.K) * 2) : 0u;
+    sp.xs_off = (uint32_t)STREAM_XS_OFF; sp.xrow = (uint32_t)q.K * 2u + 16u;
+    sp.jsh = 0;
+    while ((2048 << sp.jsh) < q.K) ++sp.jsh;
+    if (q.epilogue == 1) { cpb = (cpb + 15) & ~15; sp.cpb = cpb; }      // whole [8 gate | 8 up] tiles per block
     const unsigned grid = (unsigned)((q.N + cpb - 1) / cpb);
     sp.x_bytes = (uint32_t)(((int64_t)(q.B - 1) * q.sAb + (int64_t)(q.M - 1) * q.sAm + q.K) * 2);
     sp.w_bytes = q.W ? (uint32_t)(((int64_t)(q.N - 1) * q.ldw + q.K) * 2) : 0u;
@@ -377,8 +391,11 @@ int launch_gemv_stream_chunk(const Problem& q) {
     int rc;
     if (q.mask_tiled == 2) {      // packed layout: all tenants of the call in one chunk, interleaved; extent from the pack's own geometry
         sp.p_bytes = (uint32_t)((int64_t)((q.N + 15) / 16) * ((q.K + 127) / 128) * 4 * 16 * q.t_pad * 4);
-#define BD_PK(NM, NS4) rc = q.W ? launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1>(sp, dim3(grid), q.st) \
-                                : launch_stream_inst<DT, NM, false, NS4, 4, 1, 0, 1>(sp, dim3(grid), q.st)
+#define BD_PK(NM, NS4) rc = q.norm_w ? (q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1, 1, 1>(sp, dim3(grid), q.st)   \
+                                                        : launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1, 1, 0>(sp, dim3(grid), q.st))  \
+                     : q.epilogue == 1 ? BD_E_BAD_SHAPE                                                                           \
+                     : q.W ? launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1>(sp, dim3(grid), q.st)                              \
+                           : launch_stream_inst<DT, NM, false, NS4, 4, 1, 0, 1>(sp, dim3(grid), q.st)
         switch (q.t_pad) {
             case 1: BD_PK(1, 8); break;
             case 2: BD_PK(2, 6); break;
@@ -790,7 +807,8 @@ extern "C" int bd_delta_bmm(const void* A, const int32_t* P, void* C, int B, int
 static int binary_linear_impl(const void* X, const void* W, const int32_t* P, const float* alpha, void* Y, int B, int M,
                               int N, int K, int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb, int64_t sAlb, int G,
                               int64_t sYb, int64_t sYm, int dtype, int out_dtype, int accumulate, int mask_tiled, int t_pad,
-                              void* ws, int64_t ws_bytes, void* stream) {
+                              void* ws, int64_t ws_bytes, void* stream, const void* norm_w = nullptr, int64_t sNw = 0,
+                              float eps = 0.f, int epilogue = 0) {
     if (B > 0 && M > 0 && N > 0 && !W) return BD_E_NULL;
     Problem q{};
     q.A = X; q.P = P; q.C = Y; q.W = W; q.alpha = alpha;
@@ -798,6 +816,17 @@ static int binary_linear_impl(const void* X, const void* W, const int32_t* P, co
     q.sAb = sXb; q.sAm = sXm; q.sPb = sPb; q.sCb = sYb; q.sCm = sYm; q.ldw = ldw; q.sAlb = sAlb;
     q.G = G; q.dtype = dtype; q.out_dtype = out_dtype; q.round_mode = 0; q.accumulate = accumulate ? 1 : 0;
     q.mask_tiled = mask_tiled; q.t_pad = t_pad;
+    q.norm_w = norm_w; q.sNw = sNw; q.eps = eps; q.epilogue = epilogue;
+    if (norm_w || epilogue) {
+        // fused prologue / epilogue of the packed streaming kernel: see gemv_stream_kernel (XL, EPI)
+        if (mask_tiled != 2 || (epilogue != 0 && epilogue != 1) || (epilogue && !norm_w)) return BD_E_BAD_SHAPE;
+        if (!aligned16(norm_w) || sNw % 8 || sNw < 0) return BD_E_BAD_SHAPE;
+        // one row per tenant (M == 1: the decode step), K = 2048 * 2^s, all rows in 16 x 16-byte chunks per thread
+        if (M != 1 || K < 2048 || (K & (K - 1)) || (int64_t)B * K > 16 * 2048) return BD_E_BAD_SHAPE;
+        if ((int64_t)STREAM_XS_OFF + (int64_t)B * M * (2 * (int64_t)K + 16) > STREAM_LDS_MAX) return BD_E_BAD_SHAPE;
+        if ((int64_t)(B - 1) * sNw + K >= (1ll << 30)) return BD_E_BAD_SHAPE;
+        if (epilogue && (N % 16 || G != 2 || out_dtype != dtype || accumulate)) return BD_E_BAD_SHAPE;
+    }
     q.ws = ws; q.ws_bytes = ws_bytes; q.st = (hipStream_t)stream;
     // tile-major masks exist for the streaming decode kernel only (serving-side repack; the reference layout works everywhere)
     if (q.mask_tiled) {
@@ -833,6 +862,17 @@ extern "C" int bd_binary_linear_decode(const void* X, const void* W, const int32
     if (mask_layout != 1 && mask_layout != 2) return BD_E_BAD_SHAPE;
     return binary_linear_impl(X, W, P, alpha, Y, B, M, N, K, sXb, sXm, ldw, sPb, sAlb, G, sYb, sYm, dtype, out_dtype,
                               accumulate, mask_layout, t_pad, nullptr, 0, stream);
+}
+
+extern "C" int bd_binary_linear_decode_fused(const void* X, const void* W, const int32_t* P, int t_pad, const float* alpha, void* Y,
+                                             int B, int M, int N, int K, int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb,
+                                             int64_t sAlb, int G, int64_t sYb, int64_t sYm, int dtype, int out_dtype,
+                                             int accumulate, const void* norm_w, int64_t s_norm, float eps, int epilogue,
+                                             void* stream) {
+    if (!norm_w) return BD_E_NULL;
+    if (B < 1 || M < 1 || N < 1 || K < 1) return BD_E_BAD_SHAPE;
+    return binary_linear_impl(X, W, P, alpha, Y, B, M, N, K, sXb, sXm, ldw, sPb, sAlb, G, sYb, sYm, dtype, out_dtype, accumulate, 2,
+                              t_pad, nullptr, 0, stream, norm_w, s_norm, eps, epilogue);
 }
 
 extern "C" int bd_binary_linear_residual(const void* X, const void* W, const int32_t* P, const float* alpha, void* Y, int B,
@@ -900,21 +940,22 @@ extern "C" int bd_srv_rmsnorm(const void* X, const void* Wt, void* Y, int rows, 
     return launch_status();
 }
 
-extern "C" int bd_srv_swiglu(const void* G, const void* U, void* Y, int rows, int I, int64_t sg, int64_t su, int64_t sy, int dtype,
-                             void* stream) {
+extern "C" int bd_srv_swiglu(const void* G, const void* U, void* Y, int rows, int I, int64_t sg, int64_t su, int64_t sy,
+                             int interleaved8, int dtype, void* stream) {
     if (rows < 0 || I < 0 || rows > 65535) return BD_E_BAD_SHAPE;
     if (dtype != BD_F16 && dtype != BD_BF16) return BD_E_BAD_DTYPE;
     if (rows == 0 || I == 0) return BD_OK;
     if (!G || !U || !Y) return BD_E_NULL;
     if (I % 8 || sg % 8 || su % 8 || sy % 8 || !aligned16(G) || !aligned16(U) || !aligned16(Y)) return BD_E_BAD_SHAPE;
+    if (interleaved8 && G == Y) return BD_E_BAD_SHAPE;       // (in place is fine for the split form only)
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)((I / 8 + 255) / 256), (unsigned)rows);
     if (dtype == BD_BF16)
         hipLaunchKernelGGL((swiglu_kernel<DT_BF16>), grid, dim3(256), 0, st, (const unsigned short*)G, (const unsigned short*)U,
-                           (unsigned short*)Y, I, (long long)sg, (long long)su, (long long)sy);
+                           (unsigned short*)Y, I, (long long)sg, (long long)su, (long long)sy, interleaved8 ? 1 : 0);
     else
         hipLaunchKernelGGL((swiglu_kernel<DT_F16>), grid, dim3(256), 0, st, (const unsigned short*)G, (const unsigned short*)U,
-                           (unsigned short*)Y, I, (long long)sg, (long long)su, (long long)sy);
+                           (unsigned short*)Y, I, (long long)sg, (long long)su, (long long)sy, interleaved8 ? 1 : 0);
     return launch_status();
 }
 
@@ -935,9 +976,14 @@ extern "C" int bd_srv_rope(void* X, const void* cos_t, const void* sin_t, int ro
     return launch_status();
 }
 
+extern "C" int64_t bd_srv_decode_attention_workspace_bytes(int T, int H, int KVH, int head_dim, int Lc) {
+    if (T <= 0 || H <= 0 || KVH <= 0 || Lc < 256) return 0;       // short caches run unsplit
+    return (int64_t)T * H * 4 /* splits */ * (head_dim + 2) * 4;
+}
+
 extern "C" int bd_srv_decode_attention(const void* QKV, const void* cos_t, const void* sin_t, void* kcache, void* vcache,
                                        void* valid, const int64_t* pos, void* out, int T, int H, int KVH, int head_dim, int Lc,
-                                       int64_t s_qkv, int64_t s_out, int dtype, void* stream) {
+                                       int64_t s_qkv, int64_t s_out, int dtype, void* ws, int64_t ws_bytes, void* stream) {
     if (T < 0 || H < 1 || KVH < 1 || H % KVH || Lc < 1) return BD_E_BAD_SHAPE;
     if (dtype != BD_F16 && dtype != BD_BF16) return BD_E_BAD_DTYPE;
     if (T == 0) return BD_OK;
@@ -950,9 +996,19 @@ extern "C" int bd_srv_decode_attention(const void* QKV, const void* cos_t, const
     p.kc = (unsigned short*)kcache; p.vc = (unsigned short*)vcache; p.valid = (unsigned char*)valid; p.pos = (const long long*)pos;
     p.out = (unsigned short*)out; p.T = T; p.H = H; p.KVH = KVH; p.Lc = Lc; p.s_qkv = s_qkv; p.s_out = s_out;
     p.scale = 1.0f / sqrtf((float)head_dim);
+    // split the key range over 4 blocks per (tenant, kv head) when the cache is long enough and a workspace is given: T * KVH blocks
+    // alone leave most CUs (and most of HBM) idle -- one CU streams only ~12-25 GB/s
+    const int64_t need = bd_srv_decode_attention_workspace_bytes(T, H, KVH, head_dim, Lc);
+    p.nsplit = (need > 0 && ws && ws_bytes >= need) ? 4 : 1;
+    p.ws = (float*)ws;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)(T * KVH));
-#define BD_ATT(DT, GG) hipLaunchKernelGGL((decode_attn_kernel<DT, GG>), grid, dim3(512), 0, st, p)
+    dim3 grid((unsigned)(T * KVH), (unsigned)p.nsplit);
+#define BD_ATT(DT, GG)                                                                                      \
+    do {                                                                                                    \
+        hipLaunchKernelGGL((decode_attn_kernel<DT, GG>), grid, dim3(512), 0, st, p);                        \
+        if (p.nsplit > 1)                                                                                   \
+            hipLaunchKernelGGL((decode_attn_combine_kernel<DT, GG>), dim3(T * KVH), dim3(GG * 128), 0, st, p); \
+    } while (0)
     if (dtype == BD_BF16) { if (G == 1) BD_ATT(DT_BF16, 1); else BD_ATT(DT_BF16, 4); }
     else { if (G == 1) BD_ATT(DT_F16, 1); else BD_ATT(DT_F16, 4); }
 #undef BD_ATT

@@ -32,6 +32,7 @@
 // Algorithmic bytes per launch: 2*N*K (W) + nmask*N*K/8 (signs) + 2*R*K (x) + out; HBM roofline.
 #pragma once
 #include "bd_gemv.h"
+#include "bd_serving.h"
 
 namespace bd {
 
@@ -52,8 +53,18 @@ constexpr int STREAM_LUT_BYTES = 65536;
 constexpr int STREAM_RED_BYTES = 2 * 8 * 64 * 8 * 4;          // [2 buffers][<= 8 waves][64 lanes][4 base + 4 delta] fp32
 constexpr int STREAM_ALPHA_MAX = 512;                          // (row, scale group) pairs of one block kept in LDS
 constexpr int STREAM_LDS_BYTES = STREAM_LUT_BYTES + STREAM_RED_BYTES + STREAM_ALPHA_MAX * 4;
+constexpr int stream_red_bytes(int nw) { return 2 * nw * 64 * 8 * 4; }                            // what an nw-wave block uses of it
+constexpr int STREAM_XS_OFF = STREAM_LUT_BYTES + stream_red_bytes(4) + STREAM_ALPHA_MAX * 4;      // XL kernels (4 waves): activation rows
 constexpr uint32_t STREAM_OOB = 0x80000000u;                   // a byte offset that is out of range for every descriptor (extents are < 2 GiB:
                                                                // checked on the host) and cannot wrap when an immediate offset is added
+
+// alpha * delta + base with the product rounded on its own: the same two roundings in every epilogue form (left to the compiler,
+// one form was contracted to an fma and the other -- scale applied inside a branch -- was not: 1 ulp apart before the final rounding)
+__device__ __forceinline__ float scale_then_add(float d, float a, float b) {
+#pragma clang fp contract(off)
+    const float m = d * a;
+    return m + b;
+}
 
 struct StreamParams {
     GemvParams g;
@@ -67,6 +78,13 @@ struct StreamParams {
     uint32_t pts, prs;
     // packed decode layout (PK kernels): tenants interleaved, `tp` dwords per (tile, iteration, lane group, column) -- see PK below
     uint32_t tp;
+    // fused RMSNorm prologue (XL kernels): X is the residual stream; the block normalises the R rows into LDS rows of `xrow` bytes
+    // at LDS offset `xs_off` and reads its activation fragments from there.  nw = norm weight [tenants or 1, K], stride sNw elements
+    const unsigned short* nw;
+    long long sNw;
+    uint32_t n_bytes, xs_off, xrow;
+    int jsh;                 // K = 2048 << jsh
+    float eps;
 };
 
 // NW = waves per block (8: two per SIMD, 256 VGPRs each; 4: one per SIMD, the whole register file, deeper prefetch).
@@ -86,9 +104,19 @@ struct StreamParams {
 //   adjacent: one or two wide loads instead of NM dword loads.  Why: the PMC passes of the word-row kernel
 //   (profiles/r02_decode_pmc.txt) show its waves 37 % issue-stalled and 35 % busy -- one wave per SIMD, and 14 load instructions per
 //   5.5 KB stage that each touch 32-64 cache lines -- not 70 % waiting on memory as an HBM-bound kernel should be.
-template <int DT, int NM, bool HASW, int NS, int NW = 4, int WNAT = 0, int AUX = 0, int PK = 0>
+// XL = 1 (packed layout, 4-wave blocks): FUSED RMSNorm.  X is the un-normalised residual stream h [R rows, K]; every block computes
+//   w[tenant] * round16(h * rsqrt(mean(h^2) + eps)) for all R rows itself (R*K*2 bytes from L2 -- 48 KB for 6 tenants of a 4096-wide
+//   model -- while its first weight stages are in flight), keeps the result in LDS and reads its activation fragments from there.
+//   Same arithmetic, same order as rmsnorm_tenant_kernel (bd_serving.h: shared helpers), so the result is bit-identical to
+//   "rmsnorm launch, then Linear launch"; what disappears is a 4 us launch + gap in front of two of the four Linears of a layer.
+// EPI = 1 (packed layout): SwiGLU epilogue for a fused gate|up projection whose output rows are interleaved in blocks of 8
+//   ([g0..7 | u0..7 | g8..15 | ...]): a 16-column tile holds 8 gate and the 8 matching up columns, the reducing wave rounds both to
+//   16 bits (what the separate Linear would have stored), and stores round16(silu(g)) * u -- N/2 output columns.  Scale group of
+//   a column = gate (0) or up (1).  Bit-identical to "Linear launch, then swiglu launch".
+template <int DT, int NM, bool HASW, int NS, int NW = 4, int WNAT = 0, int AUX = 0, int PK = 0, int XL = 0, int EPI = 0>
 __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams sp) {
     static_assert(!PK || (WNAT == 1 && NM > 0), "packed layout = natural order, with a sign operand");
+    static_assert(!(XL || EPI) || (PK && NW == 4), "fused prologue / epilogue: packed layout, 256-thread blocks");
     GemvParams p = sp.g;
     if constexpr (NM == 0) {       // blockIdx.y = tenant: its own activation rows, weight matrix and output rows
         p.X += (long long)blockIdx.y * sp.sXt;
@@ -100,7 +128,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
     constexpr bool XN = PK || (HASW && WNAT);                  // activation fragments in natural order (W operand; signs too when PK)
     extern __shared__ __attribute__((aligned(256))) char dyn_lds[];     // [64 KiB sign LUT][32 KiB reduction buffers]
     float* const red = (float*)(dyn_lds + STREAM_LUT_BYTES);
-    float* const a_lds = (float*)(dyn_lds + STREAM_LUT_BYTES + STREAM_RED_BYTES);
+    float* const a_lds = (float*)(dyn_lds + STREAM_LUT_BYTES + stream_red_bytes(NW));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, g = lane >> 4;
@@ -128,7 +156,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
     // The scales this block can need -- (row, scale group) for the groups its column range touches -- are fetched by the first threads
     // BEFORE the stream starts: the oldest entry of the wave's in-order load queue, so waiting for it never drains a weight load.
     // (A load issued at the end of a tile would be the youngest: s_waitcnt vmcnt(0), the whole prefetch lost once per tile.)
-    const int g0 = c_lo / p.gsz, ng = (c_hi - 1) / p.gsz - g0 + 1;
+    const int g0 = EPI ? 0 : c_lo / p.gsz, ng = EPI ? 2 : (c_hi - 1) / p.gsz - g0 + 1;
     const bool al_lds = p.alpha != nullptr && p.R * ng <= (STREAM_ALPHA_MAX < 64 * NW ? STREAM_ALPHA_MAX : 64 * NW);
     float a_pre = 0.f;
     if (al_lds) {
@@ -136,7 +164,24 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
         a_pre = p.alpha[(long long)(r / p.M) * p.sAlb + g0 + j];
     }
 
-    struct Stage { u32x4_t xf[XP ? 4 : 1]; u32x4_t xn[XN ? 4 : 1]; u32x4_t wf[4]; uint32_t wd[NMA]; };
+    // XL: the R raw rows (and their norm weights) are the OLDEST loads of the wave -- like the scales above, consuming them never
+    // waits for a weight stage.  Thread t owns the 16-byte chunks c = 8 t + 2048 i of every row: rmsnorm_tenant_kernel's mapping.
+    constexpr int XCH = 16;                                              // chunks per thread: R * K <= 16 * 2048 (host-checked)
+    [[maybe_unused]] u32x4_t xraw[XL ? XCH : 1], graw[XL ? XCH : 1];
+    [[maybe_unused]] const int jsh = sp.jsh;                             // log2(chunks per row per thread): K = 2048 << jsh (host-checked)
+    if constexpr (XL) {
+        const __amdgpu_buffer_rsrc_t rn = make_rsrc(sp.nw, sp.n_bytes);
+#pragma unroll
+        for (int j = 0; j < XCH; ++j) {
+            const int r = j >> jsh, c = ((int)threadIdx.x + 256 * (j - (r << jsh))) * 8;      // M == 1 (host-checked): row = tenant
+            const bool ok = r < p.R;
+            xraw[j] = buf_load16<0>(rx, ok ? (uint32_t)(((long long)r * p.sXb + c) * 2) : STREAM_OOB);
+            graw[j] = buf_load16<0>(rn, ok ? (uint32_t)(((long long)r * sp.sNw + c) * 2) : STREAM_OOB);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    struct Stage { u32x4_t xf[XP ? 4 : 1]; u32x4_t xn[(XN && !XL) ? 4 : 1]; u32x4_t wf[4]; uint32_t wd[NMA]; };
     // one stage = (tile, iteration): 4 x 16 B of the lane's x row, 4 x 16 B of its W row, one sign word per mask
     auto issue = [&](Stage& st, int tile, int it) {
         const int irow = 4 * it + g;                                     // this lane group's word row
@@ -156,7 +201,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const bool ok = it_ok && (k0 + 32 * s < p.K);
-                st.xn[s] = buf_load16<0>(rx, ok ? x_off + (uint32_t)(k0 + 32 * s) * 2u : STREAM_OOB);
+                if constexpr (!XL) st.xn[s] = buf_load16<0>(rx, ok ? x_off + (uint32_t)(k0 + 32 * s) * 2u : STREAM_OOB);
                 if constexpr (HASW)
                     st.wf[s] = buf_load16<AUX>(rw, (ok && col_ok) ? (uint32_t)n * (uint32_t)p.ldw * 2u + (uint32_t)(k0 + 32 * s) * 2u : STREAM_OOB);
             }
@@ -223,6 +268,30 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
             *(u32x4_t*)(dyn_lds + slot * 16) = w;
         }
     }
+    if constexpr (XL) {
+        float* const part = red;                  // [row][wave] partial sums (the reduction buffers are idle until the first tile ends)
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < XCH; ++j) {
+            ss = sumsq8<DT>(xraw[j], ss);
+            if (((j + 1) & ((1 << jsh) - 1)) == 0) {          // row complete (uniform)
+                const float w = wave_sum(ss);
+                if (lane == 0) part[(j >> jsh) * 4 + wave] = w;
+                ss = 0.f;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < XCH; ++j) {
+            const int r = j >> jsh, c = ((int)threadIdx.x + 256 * (j - (r << jsh))) * 8;
+            if (r < p.R) {
+                const float rs = rms_scale(part[r * 4], part[r * 4 + 1], part[r * 4 + 2], part[r * 4 + 3], p.K, sp.eps);
+                *(u32x4_t*)(dyn_lds + sp.xs_off + (uint32_t)r * sp.xrow + (uint32_t)c * 2u) = norm8<DT>(xraw[j], graw[j], rs);
+            }
+        }
+    }
     if (al_lds && (int)threadIdx.x < p.R * ng) a_lds[threadIdx.x] = a_pre;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -242,8 +311,20 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
     // stage to its top (16*NM VGPRs of fragments in flight; with NS stages of loads in registers that spilled the in-flight load
     // destinations to scratch, and scratch traffic shares vmcnt with the weight stream).  One step of NM + 1 MFMAs (>= 110 cycles of
     // matrix pipe) covers the LDS latency of the next step's reads.
-    auto compute = [&](const Stage& cur) {
-        constexpr bool SFDB = !(WNAT && NW == 8);       // sign fragments double-buffered across MFMA steps (not when the second
+    // XL: activation fragment of step s of iteration `it` = 16 bytes at k = 128 it + 32 s + 8 g of LDS row min(li, R-1); the rows are
+    // 2K + 16 bytes apart, so the 16 lanes of a ds_read_b128 service group (same g) hit 16 different 16-byte slots
+    [[maybe_unused]] const uint32_t xl_base = XL ? sp.xs_off + (uint32_t)min(li, p.R - 1) * sp.xrow + (uint32_t)g * 16u : 0u;
+    auto lds16 = [&](uint32_t off) -> u32x4_t { return *(const u32x4_t*)(dyn_lds + off); };
+    // XL: the fragments of the NEXT stage are read while this one computes (two register sets, stage parity): with one wave per SIMD
+    // an LDS round trip at the top of every stage would be exposed
+    [[maybe_unused]] u32x4_t xq[XL ? 2 : 1][XL ? 4 : 1];
+    auto read_xq = [&](int set, int it) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xq[XL ? set : 0][XL ? s : 0] = lds16(xl_base + (uint32_t)min(it, nit - 1) * 256u + 64u * s);   // (run-ahead stages: any row)
+    };
+    auto compute = [&](const Stage& cur, [[maybe_unused]] int par, [[maybe_unused]] int it_next) {
+        constexpr bool SFDB = !(WNAT && NW == 8);
+        if constexpr (XL) read_xq(par ^ 1, it_next);       // sign fragments double-buffered across MFMA steps (not when the second
                                                          // activation fragment set already fills the 256-VGPR budget)
         u32x4_t sf[SFDB ? 2 : 1][NMA];
         if constexpr (SFDB) {
@@ -261,9 +342,11 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
 #pragma unroll
                 for (int t = 0; t < NM; ++t) sf[0][t] = lut(cur.wd[t], s);
             }
-            if constexpr (HASW) accB = mfma16<DT>(cur.wf[s], XN ? cur.xn[s] : cur.xf[s], accB);
+            const u32x4_t xw = XL ? xq[XL ? par : 0][XL ? s : 0] : (XN ? cur.xn[XL ? 0 : s] : cur.xf[XP ? s : 0]);
+            const u32x4_t xs_ = XL ? xq[XL ? par : 0][XL ? s : 0] : (PK ? cur.xn[XL ? 0 : s] : cur.xf[XP ? s : 0]);
+            if constexpr (HASW) accB = mfma16<DT>(cur.wf[s], xw, accB);
 #pragma unroll
-            for (int t = 0; t < NM; ++t) accD[t] = mfma16<DT>(sf[SFDB ? (s & 1) : 0][t], PK ? cur.xn[s] : cur.xf[s], accD[t]);
+            for (int t = 0; t < NM; ++t) accD[t] = mfma16<DT>(sf[SFDB ? (s & 1) : 0][t], xs_, accD[t]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -296,15 +379,33 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
                 sb += *(const f32x4_t*)&rb[(w * 64 + lane) * 8];
                 sd += *(const f32x4_t*)&rb[(w * 64 + lane) * 8 + 4];
             }
+            if constexpr (EPI == 1) {
+                // tile = [8 gate | 8 up] columns (host: N % 16 == 0, cpb % 16 == 0): lane groups 0,1 hold gate columns 4g + e, groups
+                // 2,3 the matching up columns; both are rounded to 16 bits as the separate Linear would have stored them
+                const int grp = g >> 1;
+                float a = 1.f;
+                if (al_lds) a = a_lds[li * 2 + grp];
+                else if (p.alpha) a = p.alpha[(long long)b * p.sAlb + grp];
+                const int n_out = ((c_lo + tile * 16) >> 1) + 4 * (g & 1);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int n = c_lo + tile * 16 + 4 * g + e;
-                if (n < c_hi) {
-                    float v = sd[e];
-                    if (al_lds) v *= a_lds[li * ng + (n / p.gsz - g0)];
-                    else if (p.alpha) v *= p.alpha[(long long)b * p.sAlb + n / p.gsz];
-                    if constexpr (HASW) v += sb[e];
-                    store_out<DT>(p, li, n, v);
+                for (int e = 0; e < 4; ++e) {
+                    const float v = round16<DT>(scale_then_add(sd[e], a, HASW ? sb[e] : 0.f));
+                    const float u = __shfl(v, (lane + 32) & 63, 64);
+                    if (g < 2) {
+                        const long long off = (long long)b * p.sCb + (long long)(li - b * p.M) * p.sCm + n_out + e;
+                        ((unsigned short*)p.C)[off] = (unsigned short)swiglu1<DT>(v, u);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = c_lo + tile * 16 + 4 * g + e;
+                    if (n < c_hi) {
+                        float a = 1.f;
+                        if (al_lds) a = a_lds[li * ng + (n / p.gsz - g0)];
+                        else if (p.alpha) a = p.alpha[(long long)b * p.sAlb + n / p.gsz];
+                        store_out<DT>(p, li, n, scale_then_add(sd[e], a, HASW ? sb[e] : 0.f));
+                    }
                 }
             }
         }
@@ -324,10 +425,12 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
     const int total = ntile * cntb;
     int tc = 0, ic = it_lo;                                              // stage being consumed
     int f = 0;
+    static_assert(!XL || NS % 2 == 0, "stage parity selects the activation fragment set");
+    if constexpr (XL) read_xq(0, it_lo);
     do {
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
-            compute(st[u]);
+            compute(st[u], u & 1, ic + 1 >= it_hi ? it_lo : ic + 1);
             __builtin_amdgcn_sched_barrier(0);
             issue(st[u], ti, ii);
             advance(ti, ii);

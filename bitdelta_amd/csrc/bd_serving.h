@@ -26,10 +26,46 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// sum over the wave, result in every lane: DPP within the 16-lane rows, then the four row sums through SGPRs in a fixed order
+// (six dependent ds_bpermute round trips of a __shfl_xor butterfly cost ~400 cycles; this is ~12 VALU ops)
 __device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    const int i = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+// The three pieces of HF RMSNorm / SwiGLU arithmetic, shared with the fused prologue / epilogue of the streaming decode kernel
+// (bd_gemv_stream.h, XL / EPI) so that the fused and the stand-alone forms are bit-identical: explicit fmaf, fixed order.
+template <int DT> __device__ __forceinline__ float sumsq8(u32x4_t v, float ss) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    for (int d = 0; d < 4; ++d) {
+        const float a = half_bits_to_f32<DT>(v[d] & 0xffffu), b = half_bits_to_f32<DT>(v[d] >> 16);
+        ss = __builtin_fmaf(a, a, ss);
+        ss = __builtin_fmaf(b, b, ss);
+    }
+    return ss;
+}
+// w * round16(x * rs), 8 elements
+template <int DT> __device__ __forceinline__ u32x4_t norm8(u32x4_t v, u32x4_t g, float rs) {
+    u32x4_t o;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const float a = round16<DT>(half_bits_to_f32<DT>(v[d] & 0xffffu) * rs), b = round16<DT>(half_bits_to_f32<DT>(v[d] >> 16) * rs);
+        const uint32_t lo = f32_to_half_bits<DT>(a * half_bits_to_f32<DT>(g[d] & 0xffffu));
+        const uint32_t hi = f32_to_half_bits<DT>(b * half_bits_to_f32<DT>(g[d] >> 16));
+        o[d] = lo | (hi << 16);
+    }
+    return o;
+}
+// round16(silu(g)) * u  for 16-bit g, u (already rounded projection outputs); result as 16-bit pattern
+template <int DT> __device__ __forceinline__ uint32_t swiglu1(float g, float u) {
+    const float a = round16<DT>(g / (1.f + __expf(-g)));
+    return f32_to_half_bits<DT>(a * u);
+}
+__device__ __forceinline__ float rms_scale(float p0, float p1, float p2, float p3, int H, float eps) {
+    return rsqrtf((p0 + p1 + p2 + p3) / (float)H + eps);
 }
 
 // one block (256 threads) per row; H % 8 == 0
@@ -43,48 +79,32 @@ __global__ void __launch_bounds__(256) rmsnorm_tenant_kernel(const unsigned shor
     const unsigned short* wr = w + (long long)t * sw;
     unsigned short* yr = y + (long long)r * sy;
     float ss = 0.f;
-    for (int c = threadIdx.x * 8; c < H; c += 256 * 8) {
-        const u32x4_t v = *(const u32x4_t*)(xr + c);
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const float a = half_bits_to_f32<DT>(v[d] & 0xffffu), b = half_bits_to_f32<DT>(v[d] >> 16);
-            ss += a * a + b * b;
-        }
-    }
+    for (int c = threadIdx.x * 8; c < H; c += 256 * 8) ss = sumsq8<DT>(*(const u32x4_t*)(xr + c), ss);
     ss = wave_sum(ss);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
     __syncthreads();
-    const float rs = rsqrtf((part[0] + part[1] + part[2] + part[3]) / (float)H + eps);
-    for (int c = threadIdx.x * 8; c < H; c += 256 * 8) {
-        const u32x4_t v = *(const u32x4_t*)(xr + c), g = *(const u32x4_t*)(wr + c);
-        u32x4_t o;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const float a = round16<DT>(half_bits_to_f32<DT>(v[d] & 0xffffu) * rs), b = round16<DT>(half_bits_to_f32<DT>(v[d] >> 16) * rs);
-            const uint32_t lo = f32_to_half_bits<DT>(a * half_bits_to_f32<DT>(g[d] & 0xffffu));
-            const uint32_t hi = f32_to_half_bits<DT>(b * half_bits_to_f32<DT>(g[d] >> 16));
-            o[d] = lo | (hi << 16);
-        }
-        *(u32x4_t*)(yr + c) = o;
-    }
+    const float rs = rms_scale(part[0], part[1], part[2], part[3], H, eps);
+    for (int c = threadIdx.x * 8; c < H; c += 256 * 8)
+        *(u32x4_t*)(yr + c) = norm8<DT>(*(const u32x4_t*)(xr + c), *(const u32x4_t*)(wr + c), rs);
 }
 
-// g, u [rows, I] (row strides sg, su; the fused gate|up output passes u = g + I) -> y [rows, I];  I % 8 == 0
+// g, u [rows, I] (row strides sg, su; the fused gate|up output passes u = g + I) -> y [rows, I];  I % 8 == 0.
+// il8 = 1: the projection output is interleaved in blocks of 8 ([g0..7 | u0..7 | g8..15 | u8..15 ...], the row order
+// FusedDeltaLinear gives a gate|up pair so that the decode kernel can apply SwiGLU in its epilogue): g = gp + 2c, u = gp + 2c + 8.
 template <int DT>
 __global__ void __launch_bounds__(256) swiglu_kernel(const unsigned short* __restrict__ gp, const unsigned short* __restrict__ up,
-                                                     unsigned short* __restrict__ y, int I, long long sg, long long su, long long sy) {
+                                                     unsigned short* __restrict__ y, int I, long long sg, long long su, long long sy,
+                                                     int il8) {
     const int r = blockIdx.y;
     const int c = (blockIdx.x * 256 + threadIdx.x) * 8;
     if (c >= I) return;
-    const u32x4_t g = *(const u32x4_t*)(gp + (long long)r * sg + c), u = *(const u32x4_t*)(up + (long long)r * su + c);
+    const u32x4_t g = *(const u32x4_t*)(gp + (long long)r * sg + (il8 ? 2 * c : c));
+    const u32x4_t u = il8 ? *(const u32x4_t*)(gp + (long long)r * sg + 2 * c + 8) : *(const u32x4_t*)(up + (long long)r * su + c);
     u32x4_t o;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        float a = half_bits_to_f32<DT>(g[d] & 0xffffu), b = half_bits_to_f32<DT>(g[d] >> 16);
-        a = round16<DT>(a / (1.f + __expf(-a)));
-        b = round16<DT>(b / (1.f + __expf(-b)));
-        const uint32_t lo = f32_to_half_bits<DT>(a * half_bits_to_f32<DT>(u[d] & 0xffffu));
-        const uint32_t hi = f32_to_half_bits<DT>(b * half_bits_to_f32<DT>(u[d] >> 16));
+        const uint32_t lo = swiglu1<DT>(half_bits_to_f32<DT>(g[d] & 0xffffu), half_bits_to_f32<DT>(u[d] & 0xffffu));
+        const uint32_t hi = swiglu1<DT>(half_bits_to_f32<DT>(g[d] >> 16), half_bits_to_f32<DT>(u[d] >> 16));
         o[d] = lo | (hi << 16);
     }
     *(u32x4_t*)(y + (long long)r * sy + c) = o;
@@ -139,6 +159,8 @@ struct AttnParams {
     int T, H, KVH, Lc;
     long long s_qkv, s_out;        // row strides (elements)
     float scale;                   // 1 / sqrt(head_dim)
+    float* ws;                     // nsplit > 1: partial (acc[128], max, sum) per (tenant, kv head, split, query head): [.., G, 130] fp32
+    int nsplit;                    // key range split over blockIdx.y (one CU streams only ~12-25 GB/s: 48 blocks cannot feed on HBM)
 };
 
 // One block of 8 waves per (tenant, kv head): its G = H / KVH query heads share the K / V stream.  Lane (kq = l >> 4, d8 = l & 15)
@@ -165,10 +187,15 @@ __global__ void __launch_bounds__(512) decode_attn_kernel(const AttnParams p) {
     const unsigned char* vld = p.valid + (long long)t * p.Lc;
     const int kq = lane >> 4, d8 = lane & 15;
     const int slot = 4 * wave + kq;                      // this lane group's row slot (0 .. RPI-1)
+    // this block's key rows [l_lo, l_hi) of 0 .. pos (whole iterations of RPI rows per split)
+    const long long nrows_all = pos + 1;
+    const long long per_split = ((nrows_all + p.nsplit - 1) / p.nsplit + RPI - 1) / RPI * RPI;
+    const long long l_lo = (long long)blockIdx.y * per_split, l_hi = l_lo + per_split < nrows_all ? l_lo + per_split : nrows_all;
+    const bool owns_new = l_lo <= pos && pos < l_hi;      // the split that holds the new token appends it to the cache
 
     struct Rows { u32x4_t kk, vv; bool ok; };
     auto load_row = [&](long long l, Rows& r) {
-        const bool in = l < pos;                          // row `pos` itself comes from LDS (it is being written by this block)
+        const bool in = l < pos && l < l_hi;              // row `pos` itself comes from LDS (it is being written by its block)
         const long long lc = in ? l : 0;
         r.kk = *(const u32x4_t*)(kbase + lc * HD + 8 * d8);
         r.vv = *(const u32x4_t*)(vbase + lc * HD + 8 * d8);
@@ -177,7 +204,7 @@ __global__ void __launch_bounds__(512) decode_attn_kernel(const AttnParams p) {
     // the first DEPTH iterations' rows go in flight before anything else (they do not depend on the new token)
     Rows ring[DEPTH];
 #pragma unroll
-    for (int u = 0; u < DEPTH; ++u) load_row((long long)u * RPI + slot, ring[u]);
+    for (int u = 0; u < DEPTH; ++u) load_row(l_lo + (long long)u * RPI + slot, ring[u]);
 
     // ---- phase 0: RoPE of the G query heads and of the new key (torch: round16(round16(x*cos) + rot*sin)), cache append
     auto rope = [&](const unsigned short* v, int d) {
@@ -189,7 +216,7 @@ __global__ void __launch_bounds__(512) decode_attn_kernel(const AttnParams p) {
         const int g = i / HD, d = i % HD;
         q_lds[g][d] = rope(row + (long long)(kvh * G + g) * HD, d) * p.scale;
     }
-    if (threadIdx.x >= 64 * NWV - HD) {                  // the last two waves (the first ones may be busy with the q heads)
+    if (owns_new && threadIdx.x >= 64 * NWV - HD) {      // the last two waves (the first ones may be busy with the q heads)
         const int d = threadIdx.x - (64 * NWV - HD);
         const float kr = rope(row + (long long)(p.H + kvh) * HD, d);
         const unsigned short vn = row[(long long)(p.H + p.KVH + kvh) * HD + d];
@@ -233,15 +260,14 @@ __global__ void __launch_bounds__(512) decode_attn_kernel(const AttnParams p) {
             }
         }
     };
-    const long long nrows = pos + 1;                                       // rows 0 .. pos
-    const long long niter = (nrows + RPI - 1) / RPI;                       // uniform over the block
+    const long long niter = l_hi > l_lo ? (l_hi - l_lo + RPI - 1) / RPI : 0;   // uniform over the block
     for (long long it0 = 0; it0 < niter; it0 += DEPTH) {
 #pragma unroll
         for (int u = 0; u < DEPTH; ++u) {
-            const long long l = (it0 + u) * RPI + slot;
+            const long long l = l_lo + (it0 + u) * RPI + slot;
             float kf[8], vf[8];
             bool use = ring[u].ok;
-            if (l == pos) {
+            if (l == pos && owns_new) {
                 use = true;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { kf[e] = kn_lds[8 * d8 + e]; vf[e] = vn_lds[8 * d8 + e]; }
@@ -290,8 +316,33 @@ __global__ void __launch_bounds__(512) decode_attn_kernel(const AttnParams p) {
             ssum += s_lds[j][g] * f;
             a += a_lds[j][g][d] * f;
         }
-        p.out[(long long)t * p.s_out + (long long)(kvh * G + g) * HD + d] = (unsigned short)f32_to_half_bits<DT>(a / ssum);
+        if (p.nsplit == 1) {
+            p.out[(long long)t * p.s_out + (long long)(kvh * G + g) * HD + d] = (unsigned short)f32_to_half_bits<DT>(a / ssum);
+        } else {                                         // partial of this split: un-normalised accumulator, running max, sum
+            float* w = p.ws + (((long long)blockIdx.x * p.nsplit + blockIdx.y) * G + g) * (HD + 2);
+            w[d] = a;
+            if (d == 0) { w[HD] = mm; w[HD + 1] = ssum; }
+        }
     }
+}
+
+// merges the nsplit partials of decode_attn_kernel: one block per (tenant, kv head), one thread per (query head, dim)
+template <int DT, int G>
+__global__ void __launch_bounds__(G * 128) decode_attn_combine_kernel(const AttnParams p) {
+    constexpr int HD = 128;
+    const int t = blockIdx.x / p.KVH, kvh = blockIdx.x % p.KVH;
+    const int g = threadIdx.x / HD, d = threadIdx.x % HD;
+    const float* w = p.ws + ((long long)blockIdx.x * p.nsplit * G + g) * (HD + 2);
+    float mm = -1e30f;
+    for (int c = 0; c < p.nsplit; ++c) mm = fmaxf(mm, w[(long long)c * G * (HD + 2) + HD]);
+    float ssum = 0.f, a = 0.f;
+    for (int c = 0; c < p.nsplit; ++c) {
+        const float* wc = w + (long long)c * G * (HD + 2);
+        const float f = __expf(wc[HD] - mm);
+        ssum += wc[HD + 1] * f;
+        a += wc[d] * f;
+    }
+    p.out[(long long)t * p.s_out + (long long)(kvh * G + g) * HD + d] = (unsigned short)f32_to_half_bits<DT>(a / ssum);
 }
 
 }  // namespace bd

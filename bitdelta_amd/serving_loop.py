@@ -23,7 +23,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .binary_gemm_kernel import binary_linear, binary_linear_decode, decode_shape_ok, pack_decode_masks, tenant_linear
+from .binary_gemm_kernel import (binary_linear, binary_linear_decode, decode_shape_ok, fused_norm_ok, pack_decode_masks,
+                                 tenant_linear)
 from .diff import binarize
 from . import serving_ops as ops
 
@@ -34,6 +35,7 @@ MODEL_CONFIGS = {
     "llama-2-70b": (8192, 28672, 80, 64, 8, 32000),
     "tiny": (256, 512, 2, 4, 2, 512),
     "tiny128": (512, 1024, 2, 4, 1, 512),        # head_dim 128, 4 query heads per kv head: exercises the decode glue kernels
+    "tiny2048": (2048, 1024, 2, 16, 4, 512),     # hidden % 2048 == 0: exercises the fused RMSNorm / SwiGLU launches
 }
 
 MAX_PROMPT = 1024      # demo/demo_backend.py:300-302
@@ -47,32 +49,76 @@ def padded_length(longest):
 
 class FusedDeltaLinear(nn.Module):
     """Several DiffCompress Linears that read the same input, launched as ONE:  W = cat(W_i), masks = cat(masks_i) along N,
-    alpha[t, g] = coeff of the projection that owns scale group g (group size = gcd of the output widths)."""
+    alpha[t, g] = coeff of the projection that owns scale group g (group size = gcd of the output widths).
 
-    def __init__(self, weights, masks, coeffs):
+    interleave8=True (two projections of equal width, a gate|up pair): the output rows are stored interleaved in blocks of 8
+    ([g0..7 | u0..7 | g8..15 | u8..15 | ...]) so that a 16-column tile of the decode kernel holds 8 gate columns and the 8 matching
+    up columns and SwiGLU can run in its epilogue.  `split()` undoes the order for callers that want the separate outputs."""
+
+    def __init__(self, weights, masks, coeffs, interleave8=False):
         super().__init__()
         widths = [w.shape[0] for w in weights]
-        gsz = 0
-        for n in widths:
-            gsz = math.gcd(gsz, n)
         self.widths = widths
-        self.register_buffer("weight", torch.cat(weights, 0).contiguous())                       # [N, K]
-        self.register_buffer("mask", torch.cat(masks, 2).contiguous())                           # [T, K/32, N]
-        alpha = torch.cat([c.float().reshape(-1, 1).expand(-1, n // gsz) for c, n in zip(coeffs, widths)], 1)
+        self.interleave8 = bool(interleave8)
+        weight, mask = torch.cat(weights, 0), torch.cat(masks, 2)                               # [N, K], [T, K/32, N]
+        if self.interleave8:
+            assert len(widths) == 2 and widths[0] == widths[1] and widths[0] % 8 == 0
+            inter = widths[0]
+            perm = torch.arange(2 * inter, device=weight.device).view(2, inter // 8, 8).transpose(0, 1).reshape(-1)
+            weight, mask = weight[perm], mask[:, :, perm]
+            gsz = 8
+            alpha = torch.stack([c.float().reshape(-1) for c in coeffs], 1)                     # [T, 2] (gate, up)
+            self.register_buffer("alpha_pair", alpha.contiguous())
+            alpha = alpha.repeat(1, inter // 8)                                                  # [T, N/8]: g, u, g, u, ...
+        else:
+            gsz = 0
+            for n in widths:
+                gsz = math.gcd(gsz, n)
+            alpha = torch.cat([c.float().reshape(-1, 1).expand(-1, n // gsz) for c, n in zip(coeffs, widths)], 1)
+            self.alpha_pair = None
+        self.register_buffer("weight", weight.contiguous())
+        self.register_buffer("mask", mask.contiguous())
         self.register_buffer("alpha", alpha.contiguous())                                        # [T, G]
         self.groups = alpha.shape[1]
         # decode copy of the sign words in the streaming kernel's packed order (tenants interleaved, natural k order); prefill keeps
         # the reference layout
         self.register_buffer("mask_packed", pack_decode_masks(self.mask) if self.mask.shape[0] <= 8 else None)
 
-    def forward(self, x, residual=None):
+    def _decode_ok(self, x):
         B, M, K = x.shape
-        if self.mask_packed is not None and B == self.mask.shape[0] and B * M <= 16 and \
-                decode_shape_ok(B, M, self.weight.shape[0], K, B) and x.data_ptr() % 16 == 0 and \
-                x.stride(0) % 8 == 0 and x.stride(1) % 8 == 0:
+        return self.mask_packed is not None and B == self.mask.shape[0] and B * M <= 16 and \
+            decode_shape_ok(B, M, self.weight.shape[0], K, B) and x.data_ptr() % 16 == 0 and \
+            x.stride(0) % 8 == 0 and x.stride(1) % 8 == 0 and x.stride(2) == 1
+
+    def fusable(self, x, swiglu=False):
+        """True when forward_fused can take this input: decode shape inside the fused-norm envelope (and an interleaved pair for SwiGLU)"""
+        B, M, K = x.shape
+        return self._decode_ok(x) and fused_norm_ok(B, M, K) and (not swiglu or self.interleave8)
+
+    def forward(self, x, residual=None):
+        if self._decode_ok(x):
             return binary_linear_decode(x, self.weight, self.mask_packed, self.alpha, layout="packed", groups=self.groups,
                                         residual=residual)
         return binary_linear(x, self.weight, self.mask, self.alpha, groups=self.groups, residual=residual)
+
+    def forward_fused(self, x, norm_weight, eps, swiglu=False):
+        """RMSNorm(x; norm_weight) -> this Linear (-> SwiGLU) in ONE launch; x is the un-normalised residual stream (`fusable(x)`)."""
+        if swiglu:
+            return binary_linear_decode(x, self.weight, self.mask_packed, self.alpha_pair, layout="packed", groups=2,
+                                        norm_weight=norm_weight, eps=eps, swiglu=True)
+        return binary_linear_decode(x, self.weight, self.mask_packed, self.alpha, layout="packed", groups=self.groups,
+                                    norm_weight=norm_weight, eps=eps)
+
+    def split(self, y):
+        """per-projection outputs of y = forward(x)  (undoes the interleaved row order)"""
+        if self.interleave8:
+            v = y.reshape(*y.shape[:-1], self.widths[0] // 8, 2, 8)
+            return v[..., 0, :].reshape(*y.shape[:-1], -1), v[..., 1, :].reshape(*y.shape[:-1], -1)
+        return y.split(self.widths, dim=-1)
+
+    def column_alpha(self, t):
+        """tenant t's scale of every stored output row, [N]"""
+        return self.alpha[t].repeat_interleave(self.weight.shape[0] // self.groups)
 
     def linear_bytes(self):
         """algorithmic HBM bytes of one decode launch: base once + every tenant's signs (activations / outputs are noise)"""
@@ -115,6 +161,7 @@ class TenantDecoder(nn.Module):
         self.register_buffer("sin", sin, persistent=False)
         self._graph = None
         self.fast_glue = True       # decode steps use the HIP glue kernels (serving_ops); False = stock torch ops everywhere
+        self.fuse_glue = True       # ... and fold RMSNorm / SwiGLU into the Linear launches where the shapes allow (bit-identical)
 
     # ---------------------------------------------------------------- construction
     @classmethod
@@ -139,9 +186,9 @@ class TenantDecoder(nn.Module):
                 coeffs.append(c)
             return w, torch.stack(masks, 0), torch.stack(coeffs, 0)
 
-        def fused(*shapes):
+        def fused(*shapes, interleave8=False):
             parts = [delta_linear(o, i) for o, i in shapes]
-            return FusedDeltaLinear([p[0] for p in parts], [p[1] for p in parts], [p[2] for p in parts])
+            return FusedDeltaLinear([p[0] for p in parts], [p[1] for p in parts], [p[2] for p in parts], interleave8=interleave8)
 
         def per_tenant(*shape, scale=None):
             reps = 1 if shared_heads else tenants
@@ -156,7 +203,7 @@ class TenantDecoder(nn.Module):
             layer = nn.Module()
             layer.qkv = fused((heads * hd, hid), (kvh * hd, hid), (kvh * hd, hid))
             layer.o = fused((hid, heads * hd))
-            layer.gate_up = fused((inter, hid), (inter, hid))
+            layer.gate_up = fused((inter, hid), (inter, hid), interleave8=(inter % 8 == 0))
             layer.down = fused((hid, inter))
             layer.norm1 = per_tenant(hid)
             layer.norm2 = per_tenant(hid)
@@ -192,14 +239,17 @@ class TenantDecoder(nn.Module):
         T, S, hid = x.shape
         _, inter, _, heads, kvh, _ = self.cfg
         hd = self.hd
-        h = self._norm(x, layer.norm1)
-        qkv = layer.qkv(h)
+        fuse = S == 1 and self.fast_glue and self.fuse_glue and x.is_contiguous()
+        if fuse and layer.qkv.fusable(x):
+            qkv = layer.qkv.forward_fused(x, layer.norm1, self.eps)              # RMSNorm in the Linear's prologue: one launch
+        else:
+            qkv = layer.qkv(self._norm(x, layer.norm1))
         ck, cv = cache["k"][li], cache["v"][li]
         if S == 1 and self.fast_glue and ops.decode_attention_supported(heads, kvh, hd):
             # decode: RoPE + cache append + attention over the valid keys in ONE launch (pos_idx is a one-element device tensor)
             a = ops.decode_attention(qkv, self.cos, self.sin, ck, cv, cache["valid"], pos_idx, heads, kvh)
         else:
-            q, k, v = qkv.split(layer.qkv.widths, dim=-1)
+            q, k, v = layer.qkv.split(qkv)
             q = _rope(q.view(T, S, heads, hd).transpose(1, 2), cos, sin)
             k = _rope(k.view(T, S, kvh, hd).transpose(1, 2), cos, sin)
             v = v.view(T, S, kvh, hd).transpose(1, 2)
@@ -208,13 +258,15 @@ class TenantDecoder(nn.Module):
             a = F.scaled_dot_product_attention(q, ck, cv, attn_mask=attn_mask, enable_gqa=(kvh != heads))
             a = a.transpose(1, 2).reshape(T, S, heads * hd)
         x = layer.o(a, residual=x)
-        h = self._norm(x, layer.norm2)
-        gu = layer.gate_up(h)
-        if S <= 16 and self.fast_glue and inter % 8 == 0:
-            act = ops.swiglu(gu, inter)
+        if fuse and layer.gate_up.fusable(x, swiglu=True):
+            act = layer.gate_up.forward_fused(x, layer.norm2, self.eps, swiglu=True)   # RMSNorm -> gate|up -> SwiGLU: one launch
         else:
-            g, u = gu.split(layer.gate_up.widths, dim=-1)
-            act = F.silu(g) * u
+            gu = layer.gate_up(self._norm(x, layer.norm2))
+            if S <= 16 and self.fast_glue and inter % 8 == 0:
+                act = ops.swiglu_interleaved8(gu) if layer.gate_up.interleave8 else ops.swiglu(gu, inter)
+            else:
+                g, u = layer.gate_up.split(gu)
+                act = F.silu(g) * u
         x = layer.down(act, residual=x)
         return x
 

@@ -33,8 +33,22 @@ def swiglu2(g, u):
     assert g.stride(0) == S * g.stride(1) and u.stride(0) == S * u.stride(1)
     y = torch.empty((B, S, I), device=g.device, dtype=g.dtype)
     with torch.cuda.device(g.device):
-        check(lib().bd_srv_swiglu(ptr(g), ptr(u), ptr(y), B * S, I, g.stride(1), u.stride(1), I, DTYPE_CODE[g.dtype], stream_ptr()),
+        check(lib().bd_srv_swiglu(ptr(g), ptr(u), ptr(y), B * S, I, g.stride(1), u.stride(1), I, 0, DTYPE_CODE[g.dtype], stream_ptr()),
               "srv_swiglu")
+    return y
+
+
+def swiglu_interleaved8(gu):
+    """gu [B, S, 2*I]: the output of a gate|up projection whose rows are interleaved in blocks of 8 ([g0..7 | u0..7 | g8..15 | ...],
+    FusedDeltaLinear(interleave8=True)) -> round(silu(gate)) * up, [B, S, I]"""
+    require_gpu(gu)
+    B, S, I2 = gu.shape
+    I = I2 // 2
+    assert I2 % 16 == 0 and gu.stride(2) == 1 and gu.stride(0) == S * gu.stride(1)
+    y = torch.empty((B, S, I), device=gu.device, dtype=gu.dtype)
+    with torch.cuda.device(gu.device):
+        check(lib().bd_srv_swiglu(ptr(gu), ptr(gu), ptr(y), B * S, I, gu.stride(1), gu.stride(1), I, 1, DTYPE_CODE[gu.dtype],
+                                  stream_ptr()), "srv_swiglu")
     return y
 
 
@@ -49,10 +63,13 @@ def decode_attention(qkv, cos, sin, kcache, vcache, valid, pos, heads, kv_heads)
     assert kcache.is_contiguous() and vcache.is_contiguous() and valid.is_contiguous() and valid.dtype == torch.bool
     assert cos.is_contiguous() and sin.is_contiguous() and cos.dtype == qkv.dtype and pos.dtype == torch.int64
     out = torch.empty((T, 1, heads * hd), device=qkv.device, dtype=qkv.dtype)
+    L = lib()
+    need = L.bd_srv_decode_attention_workspace_bytes(T, heads, kv_heads, hd, kcache.shape[2])
+    ws = torch.empty(need, dtype=torch.uint8, device=qkv.device) if need > 0 else None
     with torch.cuda.device(qkv.device):
-        check(lib().bd_srv_decode_attention(ptr(qkv), ptr(cos), ptr(sin), ptr(kcache), ptr(vcache), ptr(valid), ptr(pos), ptr(out),
-                                            T, heads, kv_heads, hd, kcache.shape[2], qkv.stride(0), out.stride(0),
-                                            DTYPE_CODE[qkv.dtype], stream_ptr()), "srv_decode_attention")
+        check(L.bd_srv_decode_attention(ptr(qkv), ptr(cos), ptr(sin), ptr(kcache), ptr(vcache), ptr(valid), ptr(pos), ptr(out),
+                                        T, heads, kv_heads, hd, kcache.shape[2], qkv.stride(0), out.stride(0),
+                                        DTYPE_CODE[qkv.dtype], ptr(ws), need, stream_ptr()), "srv_decode_attention")
     return out
 
 

@@ -95,6 +95,24 @@ int bd_binary_linear_decode(const void* X, const void* W, const int32_t* P, int 
                             int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb, int64_t sAlb, int G,
                             int64_t sYb, int64_t sYm, int dtype, int out_dtype, int accumulate, void* stream);
 
+/* packed-layout decode Linear with the neighbouring glue of a decoder layer FUSED into the launch (bit-identical to the separate
+ * launches; what disappears is a ~4 us kernel + a launch gap per fused op, on a step of a few hundred 15-65 us Linears):
+ *   norm_w != NULL (required): X is the UN-NORMALISED residual stream; every block computes HF RMSNorm
+ *     norm_w[b] * round(X[b,m] * rsqrt(mean(X[b,m]^2) + eps))  for the B*M rows itself while its first weight stages are in flight and
+ *     reads its activations from LDS (bd_srv_rmsnorm's arithmetic, same order).  norm_w [B or 1, K], stride s_norm elements.
+ *     Needs M == 1 (one new token per tenant), K a power of two >= 2048, B*K <= 32768 and B*(2K+16) bytes of LDS next to the
+ *     kernel's 82 KB (8 tenants x 4096, 4 x 8192).
+ *   epilogue = 1: SwiGLU.  W / P / alpha describe a fused gate|up projection whose OUTPUT ROWS are interleaved in blocks of 8
+ *     ([g0..7 | u0..7 | g8..15 | u8..15 | ...]; G = 2 scale groups: alpha[b][0] gate, alpha[b][1] up); Y [B, M, N/2] receives
+ *     round(silu(round(gate))) * round(up)  -- the HF MLP's act_fn(gate_proj(x)) * up_proj(x) (bd_srv_swiglu's arithmetic).
+ *     N % 16 == 0, out_dtype == dtype, accumulate = 0.
+ * Shapes outside the envelope return BD_E_BAD_SHAPE and the caller runs the separate launches. */
+int bd_binary_linear_decode_fused(const void* X, const void* W, const int32_t* P, int t_pad, const float* alpha, void* Y,
+                                  int B, int M, int N, int K,
+                                  int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb, int64_t sAlb, int G,
+                                  int64_t sYb, int64_t sYm, int dtype, int out_dtype, int accumulate,
+                                  const void* norm_w, int64_t s_norm, float eps, int epilogue, void* stream);
+
 /* the same Linear with the residual connection folded into its epilogue:  Y[b] = Y_in[b] + X[b] . W^T + alpha * (X[b] . S[b])
  * (fp32 sum, one rounding) -- the `hidden = residual + o_proj(...)` / `+ down_proj(...)` of the decoder layers that call the
  * reference's modules.  Decode shapes only (B*M <= 64 rows, M <= 16: where the add would otherwise be a launch of its own);
@@ -118,21 +136,26 @@ int bd_tenant_linear(const void* X, const void* W, void* Y, int T, int M, int N,
  * between two of the reference's Linears).  Not the hot path: they exist because at decode every stock op is a launch.
  * bd_srv_rmsnorm: Y[r] = Wt[r / rows_per_tenant] * round(X[r] * rsqrt(mean(X[r]^2) + eps))   (HF RMSNorm with per-tenant weights,
  *   the DataParallelModule-wrapped norms of demo_backend.py:62-79); X, Y [rows, H] (strides sx, sy), Wt [tenants, H] (stride sw).
- * bd_srv_swiglu:  Y = round(silu(G)) * U, G / U [rows, I] (row strides sg / su; the fused gate|up output passes U = G + I) -> Y [rows, I].
+ * bd_srv_swiglu:  Y = round(silu(G)) * U, G / U [rows, I] (row strides sg / su; the fused gate|up output passes U = G + I) -> Y [rows, I];
+ *   interleaved8 = 1: G is a [rows, 2I] projection output interleaved in blocks of 8 (see bd_binary_linear_decode_fused), U ignored.
  * bd_srv_decode_attention: one new token per tenant: RoPE of q and the new k (tables cos/sin [Lmax, 128], rotate-half sign folded
  *   into sin), append k/v at *pos to the caches [T, KVH, Lc, 128], mark valid[t, *pos], then softmax(q.K^T/sqrt(128)).V over the
  *   valid keys 0..*pos (left padding = 0 in valid [T, Lc] bytes), grouped-query (H/KVH in {1, 4}); QKV [T, (H+2*KVH)*128] is the
  *   fused q+k+v Linear's output; out [T, H*128].  `pos` is a DEVICE scalar so the step replays inside a hipGraph. */
 int bd_srv_rmsnorm(const void* X, const void* Wt, void* Y, int rows, int H, int64_t sx, int64_t sy, int64_t sw,
                    int rows_per_tenant, float eps, int dtype, void* stream);
-int bd_srv_swiglu(const void* G, const void* U, void* Y, int rows, int I, int64_t sg, int64_t su, int64_t sy, int dtype, void* stream);
+int bd_srv_swiglu(const void* G, const void* U, void* Y, int rows, int I, int64_t sg, int64_t su, int64_t sy, int interleaved8,
+                  int dtype, void* stream);
 /* bd_srv_rope: in-place rotary embedding of X [rows, heads*128] (row stride sx), position of row r = pos0 + r % seq, tables as for
  * bd_srv_decode_attention; rounds where `torch.addcmul(x * cos, rotate_half(x), sin)` rounds. */
 int bd_srv_rope(void* X, const void* cos_t, const void* sin_t, int rows, int heads, int head_dim, int64_t sx, int seq, int pos0,
                 int dtype, void* stream);
 int bd_srv_decode_attention(const void* QKV, const void* cos_t, const void* sin_t, void* kcache, void* vcache, void* valid,
                             const int64_t* pos, void* out, int T, int H, int KVH, int head_dim, int Lc,
-                            int64_t s_qkv, int64_t s_out, int dtype, void* stream);
+                            int64_t s_qkv, int64_t s_out, int dtype, void* ws, int64_t ws_bytes, void* stream);
+/* scratch for bd_srv_decode_attention's split of the key range over 4 blocks per (tenant, kv head) + a combine launch (0 = the
+ * cache is short enough to run unsplit; ws may then be NULL).  Without a workspace the kernel runs unsplit. */
+int64_t bd_srv_decode_attention_workspace_bytes(int T, int H, int KVH, int head_dim, int Lc);
 
 /* bytes of scratch bd_delta_bmm / bd_binary_linear may need for this problem (split-k partials of the decode path) */
 int64_t bd_gemm_workspace_bytes(int B, int M, int N, int K);

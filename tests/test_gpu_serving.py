@@ -190,7 +190,7 @@ def _dense_reference_logits(bd, dec, t, ids, am):
 
     def merged(fl):
         S = (bd.unpack(fl.mask[t]).float() * 2 - 1).T                              # [N, K]
-        a = fl.alpha[t].repeat_interleave(fl.weight.shape[0] // fl.groups)         # [N]
+        a = fl.column_alpha(t)                                                      # [N]
         return fl.weight.float() + a[:, None] * S
 
     def rms(x, w):
@@ -204,7 +204,7 @@ def _dense_reference_logits(bd, dec, t, ids, am):
     for layer in dec.layers:
         h = rms(x, layer.norm1[t])
         qkv = h @ merged(layer.qkv).T
-        q, k, v = qkv.split(layer.qkv.widths, dim=-1)
+        q, k, v = layer.qkv.split(qkv)
         q = _rope(q.view(L, heads, hd).transpose(0, 1)[None], cos, sin)[0]         # [H, L, hd]
         k = _rope(k.view(L, kvh, hd).transpose(0, 1)[None], cos, sin)[0]
         v = v.view(L, kvh, hd).transpose(0, 1)
@@ -215,7 +215,7 @@ def _dense_reference_logits(bd, dec, t, ids, am):
         a = (s.softmax(-1) @ v).transpose(0, 1).reshape(L, heads * hd)
         x = x + a @ merged(layer.o).T
         h = rms(x, layer.norm2[t])
-        g, u = (h @ merged(layer.gate_up).T).split(layer.gate_up.widths, dim=-1)
+        g, u = layer.gate_up.split(h @ merged(layer.gate_up).T)
         x = x + (F.silu(g) * u) @ merged(layer.down).T
     return rms(x[-1], dec.final_norm[t]) @ dec.lm_head[t].float().T
 
@@ -292,8 +292,10 @@ def test_decode_glue_kernels_vs_torch_ops(bd):
         assert torch.equal(got, want)
         g2, u2 = torch.randn(2, 9, 264, device=dev).to(dtype), torch.randn(2, 9, 264, device=dev).to(dtype)
         assert torch.allclose(ops.swiglu2(g2, u2).float(), (F.silu(g2) * u2).float(), rtol=2 ** -7 if dtype == torch.bfloat16 else 2 ** -9, atol=1e-3)
-        for heads, kvh in ((8, 2), (4, 4)):                              # G = 4 (Mistral-style GQA) and G = 1 (Llama-2-7B-style MHA)
-            hd, Lc, pos = 128, 96, 70
+        # G = 4 (Mistral-style GQA) and G = 1 (Llama-2-7B-style MHA); short cache (one block per kv head) and long cache (key range
+        # split over 4 blocks + combine launch), position in the first / a middle / the last split
+        for heads, kvh, Lc, pos in ((8, 2, 96, 70), (4, 4, 96, 70), (8, 2, 320, 300), (8, 2, 1088, 40), (4, 4, 512, 511), (8, 2, 640, 129)):
+            hd = 128
             cos, sin = _rope_tables(Lc, hd, dev, dtype)
             kc = torch.randn(T, kvh, Lc, hd, device=dev).to(dtype)
             vc = torch.randn(T, kvh, Lc, hd, device=dev).to(dtype)
@@ -333,3 +335,93 @@ def test_serving_loop_fast_glue_matches_torch_glue(bd):
     agree = (fast == slow).float().mean().item()
     assert agree >= 0.9, (agree, fast, slow)                              # greedy paths may fork at a near-tie; they must not diverge wholesale
     assert torch.equal(fast[:, 0], slow[:, 0])                            # the prefill token is produced by identical code
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("T,M,K,N", [(6, 1, 4096, 6144), (8, 1, 4096, 1024), (3, 1, 2048, 2560), (1, 1, 4096, 4096), (4, 1, 8192, 1024),
+                                     (2, 1, 2048, 512)])
+def test_fused_rmsnorm_prologue_is_bit_identical_to_separate_launches(bd, dtype, T, M, K, N):
+    """bd_binary_linear_decode_fused(norm_w) == bd_srv_rmsnorm then bd_binary_linear_decode, bit for bit (same arithmetic, same order;
+    the activations come from LDS instead of L2).  Also with the residual epilogue and a broadcast norm weight."""
+    from bitdelta_amd import serving_ops as ops
+    from bitdelta_amd.binary_gemm_kernel import binary_linear_decode, fused_norm_ok, pack_decode_masks
+    assert fused_norm_ok(T, M, K) and not fused_norm_ok(T, 2, K) and not fused_norm_ok(T, 1, 6144) and not fused_norm_ok(9, 1, 4096)
+    g = torch.Generator(device="cuda").manual_seed(K + N + T)
+    x = (torch.randn(T, M, K, device="cuda", generator=g) * 1.5).to(dtype)
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.02).to(dtype)
+    mask = torch.randint(-2**31, 2**31 - 1, (T, K // 32, N), device="cuda", generator=g, dtype=torch.int64).to(torch.int32)
+    alpha = torch.rand(T, 1, device="cuda", generator=g) * 1e-3
+    nw = (1 + 0.1 * torch.randn(T, K, device="cuda", generator=g)).to(dtype)
+    pk = pack_decode_masks(mask)
+    for norm in (nw, nw[:1]):
+        normed = ops.rmsnorm_tenant(x, norm.expand(T, K).contiguous(), 1e-5)
+        ref = binary_linear_decode(normed, w, pk, alpha, layout="packed")
+        got = binary_linear_decode(x, w, pk, alpha, layout="packed", norm_weight=norm, eps=1e-5)
+        assert torch.equal(got, ref)
+    res = torch.randn(T, M, N, device="cuda", generator=g).to(dtype)
+    ref = binary_linear_decode(ops.rmsnorm_tenant(x, nw, 1e-5), w, pk, alpha, layout="packed", residual=res.clone())
+    got = binary_linear_decode(x, w, pk, alpha, layout="packed", residual=res.clone(), norm_weight=nw, eps=1e-5)
+    assert torch.equal(got, ref)
+    # and against stock torch RMSNorm (tolerance: torch reduces in a different order)
+    t_norm = torch.nn.functional.rms_norm(x.float(), (K,), None, 1e-5).to(dtype) * nw[:, None, :]
+    t_ref = binary_linear_decode(t_norm.contiguous(), w, pk, alpha, layout="packed")
+    assert (got - res - t_ref).abs().max().item() <= 0.02 * t_ref.abs().max().item() + 0.02 * res.abs().max().item()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("T,K,inter", [(6, 4096, 14336), (3, 2048, 1024), (8, 4096, 512), (1, 4096, 11008)])
+def test_fused_swiglu_epilogue_is_bit_identical_to_separate_launches(bd, dtype, T, K, inter):
+    """RMSNorm -> gate|up (rows interleaved in blocks of 8) -> SwiGLU in one launch == the three separate launches, and == the
+    un-interleaved fused gate|up Linear followed by act_fn(gate) * up."""
+    from bitdelta_amd import serving_ops as ops
+    from bitdelta_amd.serving_loop import FusedDeltaLinear
+    g = torch.Generator(device="cuda").manual_seed(K + inter + T)
+    ws = [(torch.randn(inter, K, device="cuda", generator=g) * 0.02).to(dtype) for _ in range(2)]
+    masks = [torch.randint(-2**31, 2**31 - 1, (T, K // 32, inter), device="cuda", generator=g, dtype=torch.int64).to(torch.int32)
+             for _ in range(2)]
+    coeffs = [torch.rand(T, device="cuda", generator=g) * 1e-3 for _ in range(2)]
+    il = FusedDeltaLinear(ws, masks, coeffs, interleave8=True)
+    plain = FusedDeltaLinear(ws, masks, coeffs)
+    x = (torch.randn(T, 1, K, device="cuda", generator=g) * 1.5).to(dtype)
+    nw = (1 + 0.1 * torch.randn(T, K, device="cuda", generator=g)).to(dtype)
+    assert il.fusable(x, swiglu=True) and not plain.fusable(x, swiglu=True)
+    h = ops.rmsnorm_tenant(x, nw, 1e-5)
+    gu_il, gu_plain = il(h), plain(h)
+    g_il, u_il = il.split(gu_il)
+    assert torch.equal(torch.cat([g_il, u_il], -1), gu_plain)                       # the interleave is a pure row permutation
+    sep = ops.swiglu_interleaved8(gu_il)
+    assert torch.equal(sep, ops.swiglu(gu_plain, inter))
+    fused = il.forward_fused(x, nw, 1e-5, swiglu=True)
+    assert fused.shape == (T, 1, inter) and torch.equal(fused, sep)
+    t_ref = torch.nn.functional.silu(gu_plain[..., :inter]) * gu_plain[..., inter:]
+    assert (fused.float() - t_ref.float()).abs().max().item() <= 0.01 * t_ref.float().abs().max().item() + 1e-3
+
+
+def test_serving_loop_fused_glue_matches_separate_launches(bd):
+    """hidden = 2048 decoder: the decode step with RMSNorm / SwiGLU folded into the Linear launches produces the same tokens AND the
+    same logits (bit for bit) as the step with separate glue launches; eager and hipGraph."""
+    from bitdelta_amd.serving_loop import TenantDecoder
+    T = 3
+    dec = TenantDecoder.synthetic("tiny2048", T, "cuda", dtype=torch.float16, seed=5, max_len=160)
+    g = torch.Generator().manual_seed(3)
+    prompts = [torch.randint(1, 512, (n,), generator=g).tolist() for n in (12, 64, 40)]
+    outs = {}
+    for fuse in (True, False):
+        dec.fuse_glue = fuse
+        for graph in (True, False):
+            outs[(fuse, graph)], _ = dec.generate(prompts, max_new_tokens=6, use_graph=graph)
+    ref = outs[(False, False)]
+    for k, v in outs.items():
+        assert torch.equal(v, ref), k
+    # one decode step, logits compared exactly
+    ids, am = dec.prepare(prompts)
+    logits = {}
+    for fuse in (True, False):
+        dec.fuse_glue = fuse
+        cache = dec.new_cache()
+        dec.prefill(ids, am, cache)
+        pos = torch.tensor([ids.shape[1]], device="cuda")
+        cache["valid"].index_fill_(1, pos, True)
+        tok = torch.full((T, 1), 7, dtype=torch.long, device="cuda")
+        logits[fuse] = dec.forward(tok, pos, cache, cache["valid"][:, None, None, :])
+    assert torch.equal(logits[True], logits[False])
