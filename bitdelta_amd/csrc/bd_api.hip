@@ -976,9 +976,11 @@ extern "C" int bd_srv_rope(void* X, const void* cos_t, const void* sin_t, int ro
     return launch_status();
 }
 
+constexpr int ATTN_SPLITS = 4;
+constexpr int64_t ATTN_TICKET_BYTES = 16384;       // one arrival counter per (tenant, kv head): T * KVH <= 4096
 extern "C" int64_t bd_srv_decode_attention_workspace_bytes(int T, int H, int KVH, int head_dim, int Lc) {
     if (T <= 0 || H <= 0 || KVH <= 0 || Lc < 256) return 0;       // short caches run unsplit
-    return (int64_t)T * H * 4 /* splits */ * (head_dim + 2) * 4;
+    return ATTN_TICKET_BYTES + (int64_t)T * H * ATTN_SPLITS * (head_dim + 2) * 4;
 }
 
 extern "C" int bd_srv_decode_attention(const void* QKV, const void* cos_t, const void* sin_t, void* kcache, void* vcache,
@@ -999,15 +1001,14 @@ extern "C" int bd_srv_decode_attention(const void* QKV, const void* cos_t, const
     // split the key range over 4 blocks per (tenant, kv head) when the cache is long enough and a workspace is given: T * KVH blocks
     // alone leave most CUs (and most of HBM) idle -- one CU streams only ~12-25 GB/s
     const int64_t need = bd_srv_decode_attention_workspace_bytes(T, H, KVH, head_dim, Lc);
-    p.nsplit = (need > 0 && ws && ws_bytes >= need) ? 4 : 1;
-    p.ws = (float*)ws;
+    p.nsplit = (need > 0 && ws && ws_bytes >= need && (int64_t)T * KVH * 4 <= ATTN_TICKET_BYTES) ? ATTN_SPLITS : 1;
+    p.tickets = (unsigned*)ws;
+    p.ws = (float*)((char*)ws + ATTN_TICKET_BYTES);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)(T * KVH), (unsigned)p.nsplit);
 #define BD_ATT(DT, GG)                                                                                      \
     do {                                                                                                    \
         hipLaunchKernelGGL((decode_attn_kernel<DT, GG>), grid, dim3(512), 0, st, p);                        \
-        if (p.nsplit > 1)                                                                                   \
-            hipLaunchKernelGGL((decode_attn_combine_kernel<DT, GG>), dim3(T * KVH), dim3(GG * 128), 0, st, p); \
     } while (0)
     if (dtype == BD_BF16) { if (G == 1) BD_ATT(DT_BF16, 1); else BD_ATT(DT_BF16, 4); }
     else { if (G == 1) BD_ATT(DT_F16, 1); else BD_ATT(DT_F16, 4); }

@@ -160,6 +160,7 @@ struct AttnParams {
     long long s_qkv, s_out;        // row strides (elements)
     float scale;                   // 1 / sqrt(head_dim)
     float* ws;                     // nsplit > 1: partial (acc[128], max, sum) per (tenant, kv head, split, query head): [.., G, 130] fp32
+    unsigned* tickets;             // nsplit > 1: one arrival counter per (tenant, kv head), zero when the launch is enqueued
     int nsplit;                    // key range split over blockIdx.y (one CU streams only ~12-25 GB/s: 48 blocks cannot feed on HBM)
 };
 
@@ -169,6 +170,11 @@ struct AttnParams {
 // its issue rate instead of one HBM round trip per iteration.  Online softmax per head in fp32; the 4 row slots of a wave are merged
 // with lane shuffles, the 8 waves through LDS.  head_dim = 128, G in {1, 4}.
 // (History, profiles/r02_decode_step.txt: 4 waves, no prefetch -> 16 waves, one iteration ahead: 21 us per layer -> this form.)
+__device__ __forceinline__ void attn_ws_store(float* dst, float v) { __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float attn_ws_load(const float* src) {
+    return __hip_atomic_load(const_cast<float*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int DT, int G>
 __global__ void __launch_bounds__(512) decode_attn_kernel(const AttnParams p) {
     constexpr int HD = 128, NWV = 8, RPI = 4 * NWV, DEPTH = 4;
@@ -320,29 +326,38 @@ __global__ void __launch_bounds__(512) decode_attn_kernel(const AttnParams p) {
             p.out[(long long)t * p.s_out + (long long)(kvh * G + g) * HD + d] = (unsigned short)f32_to_half_bits<DT>(a / ssum);
         } else {                                         // partial of this split: un-normalised accumulator, running max, sum
             float* w = p.ws + (((long long)blockIdx.x * p.nsplit + blockIdx.y) * G + g) * (HD + 2);
-            w[d] = a;
-            if (d == 0) { w[HD] = mm; w[HD + 1] = ssum; }
+            attn_ws_store(&w[d], a);
+            if (d == 0) { attn_ws_store(&w[HD], mm); attn_ws_store(&w[HD + 1], ssum); }
         }
     }
-}
-
-// merges the nsplit partials of decode_attn_kernel: one block per (tenant, kv head), one thread per (query head, dim)
-template <int DT, int G>
-__global__ void __launch_bounds__(G * 128) decode_attn_combine_kernel(const AttnParams p) {
-    constexpr int HD = 128;
-    const int t = blockIdx.x / p.KVH, kvh = blockIdx.x % p.KVH;
-    const int g = threadIdx.x / HD, d = threadIdx.x % HD;
-    const float* w = p.ws + ((long long)blockIdx.x * p.nsplit * G + g) * (HD + 2);
-    float mm = -1e30f;
-    for (int c = 0; c < p.nsplit; ++c) mm = fmaxf(mm, w[(long long)c * G * (HD + 2) + HD]);
-    float ssum = 0.f, a = 0.f;
-    for (int c = 0; c < p.nsplit; ++c) {
-        const float* wc = w + (long long)c * G * (HD + 2);
-        const float f = __expf(wc[HD] - mm);
-        ssum += wc[HD + 1] * f;
-        a += wc[d] * f;
+    if (p.nsplit == 1) return;
+    // In-launch merge of the splits (same protocol as gemv_ticket_reduce, bd_gemv.h): the partials and the ticket are only ever
+    // touched by agent-scope relaxed atomics (they go to the coherence point; the XCDs' L2s are not coherent for plain stores), the
+    // order is explicit -- every partial store of this block acknowledged (vmcnt(0), barrier) -> ticket increment -> the block that
+    // arrives LAST reads all partials and merges them in split order (the result does not depend on which block that is) and puts
+    // the ticket back to 0 for the next launch.  Contract: the ticket words are zero when the launch is enqueued.
+    __shared__ int s_last;
+    __builtin_amdgcn_s_waitcnt(0x0f70);               // vmcnt(0)
+    __syncthreads();
+    if (threadIdx.x == 0)
+        s_last = __hip_atomic_fetch_add(&p.tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(p.nsplit - 1);
+    __syncthreads();
+    if (!s_last) return;
+    for (int i = threadIdx.x; i < G * HD; i += 64 * NWV) {
+        const int g = i / HD, d = i % HD;
+        const float* w = p.ws + ((long long)blockIdx.x * p.nsplit * G + g) * (HD + 2);
+        float mm = -1e30f;
+        for (int c = 0; c < p.nsplit; ++c) mm = fmaxf(mm, attn_ws_load(&w[(long long)c * G * (HD + 2) + HD]));
+        float ssum = 0.f, a = 0.f;
+        for (int c = 0; c < p.nsplit; ++c) {
+            const float* wc = w + (long long)c * G * (HD + 2);
+            const float f = __expf(attn_ws_load(&wc[HD]) - mm);
+            ssum += attn_ws_load(&wc[HD + 1]) * f;
+            a += attn_ws_load(&wc[d]) * f;
+        }
+        p.out[(long long)t * p.s_out + (long long)(kvh * G + g) * HD + d] = (unsigned short)f32_to_half_bits<DT>(a / ssum);
     }
-    p.out[(long long)t * p.s_out + (long long)(kvh * G + g) * HD + d] = (unsigned short)f32_to_half_bits<DT>(a / ssum);
+    if (threadIdx.x == 0) __hip_atomic_store(&p.tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace bd

@@ -3,7 +3,7 @@ and single-token attention with RoPE + KV-cache append.  Callers of the hot path
 each has a stock-torch equivalent in that module (used at prefill and as the test reference)."""
 import torch
 
-from ._lib import DTYPE_CODE, check, lib, ptr, require_gpu, stream_ptr
+from ._lib import DTYPE_CODE, check, lib, ptr, require_gpu, stream_ptr, workspace
 
 
 def rmsnorm_tenant(x, w, eps):
@@ -65,7 +65,8 @@ def decode_attention(qkv, cos, sin, kcache, vcache, valid, pos, heads, kv_heads)
     out = torch.empty((T, 1, heads * hd), device=qkv.device, dtype=qkv.dtype)
     L = lib()
     need = L.bd_srv_decode_attention_workspace_bytes(T, heads, kv_heads, hd, kcache.shape[2])
-    ws = torch.empty(need, dtype=torch.uint8, device=qkv.device) if need > 0 else None
+    # persistent per-stream scratch, zero-filled once: the kernel's arrival counters must be zero at launch and it restores them
+    ws, need = workspace(need, qkv.device, zeroed=True) if need > 0 else (None, 0)
     with torch.cuda.device(qkv.device):
         check(L.bd_srv_decode_attention(ptr(qkv), ptr(cos), ptr(sin), ptr(kcache), ptr(vcache), ptr(valid), ptr(pos), ptr(out),
                                         T, heads, kv_heads, hd, kcache.shape[2], qkv.stride(0), out.stride(0),

@@ -153,8 +153,10 @@ int bd_srv_rope(void* X, const void* cos_t, const void* sin_t, int rows, int hea
 int bd_srv_decode_attention(const void* QKV, const void* cos_t, const void* sin_t, void* kcache, void* vcache, void* valid,
                             const int64_t* pos, void* out, int T, int H, int KVH, int head_dim, int Lc,
                             int64_t s_qkv, int64_t s_out, int dtype, void* ws, int64_t ws_bytes, void* stream);
-/* scratch for bd_srv_decode_attention's split of the key range over 4 blocks per (tenant, kv head) + a combine launch (0 = the
- * cache is short enough to run unsplit; ws may then be NULL).  Without a workspace the kernel runs unsplit. */
+/* scratch for bd_srv_decode_attention's split of the key range over 4 blocks per (tenant, kv head), merged inside the launch by the
+ * block that finishes last (0 = the cache is short enough to run unsplit; ws may then be NULL).  Without a workspace the kernel
+ * runs unsplit.  CONTRACT: the first 16 KiB of ws (arrival counters) are ZERO when the launch is enqueued; the kernel puts them
+ * back to zero, so a buffer that is zero-filled once and used by one stream at a time can be reused by every call. */
 int64_t bd_srv_decode_attention_workspace_bytes(int T, int H, int KVH, int head_dim, int Lc);
 
 /* bytes of scratch bd_delta_bmm / bd_binary_linear may need for this problem (split-k partials of the decode path) */
