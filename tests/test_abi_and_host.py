@@ -121,3 +121,35 @@ def test_product_never_imports_the_oracle():
                     assert not any(m.split(".")[0] == "oracle" for m in mods), path
             if f.endswith((".h", ".hip", ".cpp", ".py")):
                 assert "bd_oracle" not in open(path, errors="ignore").read(), path
+
+
+def test_build_gate_is_a_content_hash_of_every_source(tmp_path, monkeypatch):
+    """Editing ANY source the library is compiled from -- including the header of the headline fused kernel, which round 1's
+    hand-kept dependency list missed -- must make the build stale; restoring the bytes must make it fresh again (content, not mtime)."""
+    import shutil
+    from bitdelta_amd import build as b
+    names = {os.path.basename(f) for f in b.sources()}
+    for must in ("bd_api.hip", "bd_gemm_fx.h", "bd_gemm_pf.h", "bd_gemv_stream.h", "bd_serving.h", "bitdelta_hip.h"):
+        assert must in names, must
+    # work on a copy of the package's source tree so the real stamp / sources are never touched
+    root = tmp_path / "pkg"
+    shutil.copytree(os.path.join(b.HERE, "csrc"), root / "bitdelta_amd" / "csrc")
+    shutil.copytree(os.path.join(os.path.dirname(b.HERE), "include"), root / "include")
+    os.makedirs(root / "bitdelta_amd" / "lib")
+    monkeypatch.setattr(b, "HERE", str(root / "bitdelta_amd"))
+    monkeypatch.setattr(b, "OUT", str(root / "bitdelta_amd" / "lib" / "libbitdelta_hip.so"))
+    monkeypatch.setattr(b, "STAMP", str(root / "bitdelta_amd" / "lib" / "libbitdelta_hip.so.srchash"))
+    assert b.needs_build()                                   # no library yet
+    open(b.OUT, "wb").write(b"\0")
+    open(b.STAMP, "w").write(b.source_hash() + "\n")
+    assert not b.needs_build()
+    hdr = root / "bitdelta_amd" / "csrc" / "bd_gemm_fx.h"
+    orig = hdr.read_bytes()
+    hdr.write_bytes(orig + b"\n// touched\n")
+    assert b.needs_build()                                   # a header edit is seen
+    hdr.write_bytes(orig)
+    os.utime(hdr, None)                                      # newer mtime, same bytes
+    assert not b.needs_build()
+    api = root / "include" / "bitdelta_hip.h"
+    api.write_bytes(api.read_bytes() + b"\n")
+    assert b.needs_build()

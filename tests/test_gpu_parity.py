@@ -535,3 +535,26 @@ def test_binary_linear_decode_layouts_vs_oracle(bd, oracle, dtype, shape):
         want = (r.float() + ref32).to(dtype)
         d = (out.cpu().float() - want.float()).abs()
         assert (d <= (r.float().abs() + ref32.abs()) * (2 ** -7 if dtype == torch.bfloat16 else 2 ** -10) + 1e-4).all()
+
+
+@pytest.mark.gpu
+def test_per_device_kernel_attributes_on_second_gpu(bd):
+    """hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the CU count are per-device properties: the one-pass fused GEMM (151 KB
+    of LDS) and the streaming decode kernel (98 KB) must launch on cuda:1 after they have run on cuda:0 (round 1 raised the limit
+    once per process, i.e. only on the first device).  Needs two visible GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    outs = []
+    for dev in ("cuda:0", "cuda:1", "cuda:0"):
+        g = torch.Generator(device=dev).manual_seed(7)
+        x = torch.randn(1, 256, 512, device=dev, generator=g).to(torch.bfloat16)
+        w = (torch.randn(640, 512, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+        mask = torch.randint(-2**31, 2**31 - 1, (1, 16, 640), device=dev, generator=g, dtype=torch.int64).to(torch.int32)
+        alpha = torch.full((1, 1), 3e-4, device=dev)
+        y_big = bd.binary_linear(x, w, mask, alpha)                              # fused MFMA GEMM
+        y_dec = bd.binary_linear(x[:, :1].contiguous(), w, mask, alpha)          # streaming decode kernel
+        torch.cuda.synchronize(dev)
+        outs.append((y_big.cpu(), y_dec.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][0], outs[2][0])
+    assert torch.equal(outs[0][1], outs[0][0][:, :1]) or (outs[0][1].float() - outs[0][0][:, :1].float()).abs().max() < 1e-2
