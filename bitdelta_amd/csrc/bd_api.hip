@@ -606,14 +606,14 @@ inline int splitk_factor(int B, int M, int N, int K) {
     return ks < 2 ? 1 : (int)ks;
 }
 
-template <int DT>
-int launch_fused_splitk(const Problem& q, int KS) {
+template <int DT, int BM>
+int launch_fused_splitk_bm(const Problem& q, int KS) {
     const int64_t need = GEMV_TICKET_BYTES + (int64_t)q.B * KS * q.M * q.N * 4;
     if (!q.ws || q.ws_bytes < need) return BD_E_WORKSPACE;
     float* part = (float*)((char*)q.ws + GEMV_TICKET_BYTES);
     Problem c = q;
     c.C = part; c.out_dtype = BD_F32; c.sCm = q.N; c.sCb = (int64_t)q.M * q.N;     // slab y = b * KS + ks
-    using Cfg = FxCfg<DT, 128, 128, 4, true, 1>;
+    using Cfg = FxCfg<DT, BM, 128, 4, true, 1>;
     GemmParams p = make_params(c, Cfg::BM, Cfg::BN);
     p.ksplit = KS;
     auto kern = delta_gemm_fx_kernel<Cfg>;
@@ -626,6 +626,11 @@ int launch_fused_splitk(const Problem& q, int KS) {
     hipLaunchKernelGGL((splitk_reduce_kernel<DT>), g2, dim3(256), 0, q.st, (const float*)part, q.C, q.B, KS, q.M, q.N,
                        (long long)q.sCb, (int)q.sCm, q.out_dtype == BD_F32 ? 1 : 0);
     return launch_status();
+}
+// up to 64 rows per mask: 64-row tiles (half the MFMA / LDS work of a padded 128-row tile)
+template <int DT>
+int launch_fused_splitk(const Problem& q, int KS) {
+    return q.M <= 64 ? launch_fused_splitk_bm<DT, 64>(q, KS) : launch_fused_splitk_bm<DT, 128>(q, KS);
 }
 
 template <int DT, bool FUSED, bool OUT_F32>
@@ -641,6 +646,10 @@ int dispatch3(const Problem& q) {
         else if (!fast_ok(q)) v = 100;
         else if (FUSED && q.M > 16 && q.sCm % 4 == 0 && q.sCb % 4 == 0 && splitk_factor(q.B, q.M, q.N, q.K) > 1 && q.ws &&
                  q.ws_bytes >= GEMV_TICKET_BYTES + (int64_t)q.B * splitk_factor(q.B, q.M, q.N, q.K) * q.M * q.N * 4) v = 10;
+        else if (FUSED && q.M > 16 && q.M <= 64)                  // (not split: there are enough 64-row tiles)
+            // 64x256 tiles (twice the MFMAs per X fragment read) once they fill at least half the CUs, else 64x128 for the parallelism:
+            // 6 tenants x 64 rows: q+k+v 56 vs 76 us, gate+up 207 vs 253 us, but o 54 vs 38 us (tools/bench_mt_prefill.py)
+            v = ((long long)((q.N + 255) / 256) * q.B * 2 >= num_cus()) ? 12 : 11;
         else if (FUSED && q.M > 16) v = choose_fused_tile(q);     // fused: one-pass kernel (profiles/r01_fx_vs_two_loop.txt, r01_small_m.txt,
                                                                   // r01_mid_m.txt: also for 16 < M <= 64, rows padded to the 128-row tile)
         else if (q.M > 128) v = choose_big_tile(q);
@@ -649,8 +658,8 @@ int dispatch3(const Problem& q) {
         else v = 3;
     } else {
         if ((v == 200 || v == 300 || v == 400 || v == 500 || v == 600) && !gemv_ok(q)) return BD_E_BAD_SHAPE;
-        if (v >= 0 && v <= 10 && !fast_ok(q)) return BD_E_BAD_SHAPE;
-        if ((v == 8 || v == 9 || v == 10) && !FUSED) return BD_E_BAD_SHAPE;
+        if (v >= 0 && v <= 12 && !fast_ok(q)) return BD_E_BAD_SHAPE;
+        if ((v == 8 || v == 9 || v == 10 || v == 11 || v == 12) && !FUSED) return BD_E_BAD_SHAPE;
         if (v == 10 && (q.N % 8 || q.sCm % 4 || q.sCb % 4)) return BD_E_BAD_SHAPE;
     }
     t_last_variant = v;
@@ -689,6 +698,13 @@ int dispatch3(const Problem& q) {
                 return launch_fused_splitk<DT>(q, ks);
             } else return BD_E_BAD_SHAPE;
         }
+        case 11:     // one-pass fused, 64x128 tile: up to 64 rows per mask (multi-tenant prefill of short prompts, demo_backend.py:297-299:
+                     // M = 64 x 6 tenants) -- the 128-row tile does twice the MFMA and LDS work for rows that do not exist
+            if constexpr (FUSED) return launch_tile<FxCfg<DT, 64, 128, 4, OUT_F32, 1>, 3>(q);
+            else return BD_E_BAD_SHAPE;
+        case 12:     // one-pass fused, 64x256 tile: wide outputs / many tenants (see the rule above)
+            if constexpr (FUSED) return launch_tile<FxCfg<DT, 64, 256, 3, OUT_F32, 1>, 3>(q);
+            else return BD_E_BAD_SHAPE;
         case 9:      // one-pass fused, 128x128 tile, 4-slot ring: twice the tiles when 256x128 cannot fill the CUs (128 < M <~ 768)
             if constexpr (FUSED) return launch_tile<FxCfg<DT, 128, 128, 4, OUT_F32, 1>, 3>(q);
             else return BD_E_BAD_SHAPE;

@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(256) gemv_mfma_kernel(const GemvParams p) {
     f32x4_t accB = {0.f, 0.f, 0.f, 0.f}, accD[NM];
 #pragma unroll
     for (int t = 0; t < NM; ++t) accD[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const char* xl = xs_lds + li * XROW + 64 * g;                     // (32 (4 it + g) + 8 s) * 2 bytes = 256 it + 64 g + 16 s
+    const char* xl = xs_lds + min(li, p.R - 1) * XROW + 64 * g;                     // (32 (4 it + g) + 8 s) * 2 bytes = 256 it + 64 g + 16 s
     const uint32_t copy_off = LC == 16 ? (uint32_t)li * 16u : 0u;
 
     auto compute = [&](const Stage& cur, int it) {
@@ -500,7 +500,7 @@ __global__ void __launch_bounds__(512) gemv_col16_kernel(const GemvParams p) {
     f32x4_t accB = {0.f, 0.f, 0.f, 0.f}, accD[NM];
 #pragma unroll
     for (int t = 0; t < NM; ++t) accD[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const char* xl = xs_lds + li * xrow + 64 * g;
+    const char* xl = xs_lds + min(li, p.R - 1) * xrow + 64 * g;
     const uint32_t copy_off = (uint32_t)li * 16u;
 
     auto compute = [&](const Stage& cur, int it) {

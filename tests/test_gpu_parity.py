@@ -218,7 +218,11 @@ LINEAR_SHAPES = [sh for sh in SHAPES if not (sh[5] in (0, 5))] + [(3, 130, 128, 
                           (2, 200, 256, 520, 2, 8), (1, 257, 64, 136, 1, 8), (3, 300, 128, 264, 1, 8), (1, 512, 1024, 384, 1, 8),
                           (2, 200, 256, 520, 2, 9), (1, 257, 64, 136, 1, 9), (3, 300, 128, 264, 1, 9), (1, 512, 1024, 384, 1, 9),   # 9 = 128x128 tile
                           (2, 200, 256, 520, 2, 10), (1, 128, 512, 384, 1, 10), (1, 40, 1024, 264, 1, None), (3, 33, 2048, 1024, 3, None),  # split-k (mid M)
-                          (1, 96, 4096, 1024, 1, None)]
+                          (1, 96, 4096, 1024, 1, None),
+                          # 11 = 64x128 tile (up to 64 rows per mask: multi-tenant prefill of short prompts; also under split-k)
+                          (6, 64, 512, 640, 6, None), (6, 64, 512, 640, 6, 11), (3, 33, 256, 264, 3, 11), (2, 200, 256, 520, 2, 11),
+                          (1, 64, 1024, 384, 1, 10), (4, 17, 192, 136, 4, 11), (6, 64, 4096, 512, 6, None),
+                          (6, 64, 512, 640, 6, 12), (3, 33, 256, 264, 3, 12), (2, 200, 256, 520, 2, 12), (4, 64, 256, 8200, 4, None)]
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -545,11 +549,12 @@ def test_per_device_kernel_attributes_on_second_gpu(bd):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two visible GPUs")
     outs = []
+    g = torch.Generator().manual_seed(7)                                      # same host data on every device
+    x_h = torch.randn(1, 256, 512, generator=g).to(torch.bfloat16)
+    w_h = (torch.randn(640, 512, generator=g) * 0.02).to(torch.bfloat16)
+    m_h = torch.randint(-2**31, 2**31 - 1, (1, 16, 640), generator=g, dtype=torch.int64).to(torch.int32)
     for dev in ("cuda:0", "cuda:1", "cuda:0"):
-        g = torch.Generator(device=dev).manual_seed(7)
-        x = torch.randn(1, 256, 512, device=dev, generator=g).to(torch.bfloat16)
-        w = (torch.randn(640, 512, device=dev, generator=g) * 0.02).to(torch.bfloat16)
-        mask = torch.randint(-2**31, 2**31 - 1, (1, 16, 640), device=dev, generator=g, dtype=torch.int64).to(torch.int32)
+        x, w, mask = x_h.to(dev), w_h.to(dev), m_h.to(dev)
         alpha = torch.full((1, 1), 3e-4, device=dev)
         y_big = bd.binary_linear(x, w, mask, alpha)                              # fused MFMA GEMM
         y_dec = bd.binary_linear(x[:, :1].contiguous(), w, mask, alpha)          # streaming decode kernel
