@@ -221,10 +221,11 @@ def run_mt_decode(dev, timer, model_name, tenants, kv_len, steps, warmup, layers
     ab = None
     if ab_glue and graph_ms is not None:
         # same process, same box, alternating: the step with RMSNorm / SwiGLU folded into the Linear launches vs separate glue launches
-        ab = {"fused_glue_ms": [], "separate_glue_ms": []}
+        ab = {"persistent_chain_ms": [], "fused_glue_ms": [], "separate_glue_ms": []}
         runners = {}
-        for name, flag in (("fused_glue_ms", True), ("separate_glue_ms", False)):
-            dec.fuse_glue = flag
+        keep = (dec.persistent, dec.fuse_glue)
+        for name, pers, flag in (("persistent_chain_ms", True, True), ("fused_glue_ms", False, True), ("separate_glue_ms", False, False)):
+            dec.persistent, dec.fuse_glue = pers, flag
             restore()
             runners[name] = dec._graph_runner(st)
         for _ in range(3):
@@ -232,7 +233,7 @@ def run_mt_decode(dev, timer, model_name, tenants, kv_len, steps, warmup, layers
                 restore()
                 run()
                 ab[name].append(bdd.timed_region(run, steps, device_sync=torch.cuda.synchronize) / steps * 1e3)
-        dec.fuse_glue = True
+        dec.persistent, dec.fuse_glue = keep
     lin_bytes, head_bytes = dec.linear_bytes_per_step()
     best_ms = graph_ms if graph_ms is not None else eager_s / steps * 1e3
     out = {

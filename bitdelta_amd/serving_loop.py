@@ -23,8 +23,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .binary_gemm_kernel import (binary_linear, binary_linear_decode, decode_shape_ok, fused_norm_ok, pack_decode_masks,
-                                 tenant_linear)
+from .binary_gemm_kernel import (binary_linear, binary_linear_decode, decode_chain, decode_shape_ok, fused_norm_ok,
+                                 pack_decode_masks, tenant_linear)
 from .diff import binarize
 from . import serving_ops as ops
 
@@ -35,7 +35,7 @@ MODEL_CONFIGS = {
     "llama-2-70b": (8192, 28672, 80, 64, 8, 32000),
     "tiny": (256, 512, 2, 4, 2, 512),
     "tiny128": (512, 1024, 2, 4, 1, 512),        # head_dim 128, 4 query heads per kv head: exercises the decode glue kernels
-    "tiny2048": (2048, 1024, 2, 16, 4, 512),     # hidden % 2048 == 0: exercises the fused RMSNorm / SwiGLU launches
+    "tiny2048": (2048, 2048, 2, 16, 4, 512),     # hidden % 2048 == 0: exercises the fused RMSNorm / SwiGLU launches
 }
 
 MAX_PROMPT = 1024      # demo/demo_backend.py:300-302
@@ -162,6 +162,10 @@ class TenantDecoder(nn.Module):
         self._graph = None
         self.fast_glue = True       # decode steps use the HIP glue kernels (serving_ops); False = stock torch ops everywhere
         self.fuse_glue = True       # ... and fold RMSNorm / SwiGLU into the Linear launches where the shapes allow (bit-identical)
+        # ... or run [o, gate|up, down, next layer's q|k|v] as ONE persistent launch per layer (bit-identical).  OFF by default: measured
+        # 5.91 vs 5.33 ms per step -- a grid barrier plus the dependent reload behind it is a chain of 5-6 memory round trips (~8 us)
+        # and the 4 stages of weights prefetched across it cover 4.4 us
+        self.persistent = False
 
     # ---------------------------------------------------------------- construction
     @classmethod
@@ -270,6 +274,48 @@ class TenantDecoder(nn.Module):
         x = layer.down(act, residual=x)
         return x
 
+    def _chain_ok(self, x):
+        """the persistent chain takes this decode step: fused envelope for every phase of every layer (bd_decode_chain)"""
+        T, S, hid = x.shape
+        _, inter, _, heads, kvh, _ = self.cfg
+        if not (self.persistent and self.fast_glue and self.fuse_glue and S == 1 and x.is_contiguous()):
+            return False
+        if not ops.decode_attention_supported(heads, kvh, self.hd) or hid % 16 or inter % 16:
+            return False
+        l0 = self.layers[0]
+        if l0.qkv.mask_packed is None or l0.qkv.mask_packed.shape[4] < 4:
+            return False
+        ns = 4
+        return all(l.qkv.fusable(x) and l.gate_up.fusable(x, swiglu=True) and l.o.mask_packed is not None and
+                   l.down.mask_packed is not None for l in self.layers) and hid >= 512 * ns and inter >= 512 * ns and inter % 128 == 0
+
+    def _decode_layers_chain(self, x, cache, pos_idx):
+        """decode step over all layers with one persistent launch per layer for [o, gate|up, down, q|k|v of the next layer]"""
+        T, _, hid = x.shape
+        _, inter, _, heads, kvh, _ = self.cfg
+        first = self.layers[0]
+        qkv = first.qkv.forward_fused(x, first.norm1, self.eps)
+        h = x
+        for li, layer in enumerate(self.layers):
+            a = ops.decode_attention(qkv, self.cos, self.sin, cache["k"][li], cache["v"][li], cache["valid"], pos_idx, heads, kvh)
+            nxt = self.layers[li + 1] if li + 1 < len(self.layers) else None
+            h_mid, h_out = torch.empty_like(h), torch.empty_like(h)
+            act = torch.empty((T, 1, inter), device=x.device, dtype=x.dtype)
+            phases = [
+                dict(x=a, weight=layer.o.weight, mask_packed=layer.o.mask_packed, alpha=layer.o.alpha, out=h_mid, residual=h),
+                dict(x=h_mid, weight=layer.gate_up.weight, mask_packed=layer.gate_up.mask_packed, alpha=layer.gate_up.alpha_pair,
+                     out=act, norm_weight=layer.norm2, eps=self.eps),
+                dict(x=act, weight=layer.down.weight, mask_packed=layer.down.mask_packed, alpha=layer.down.alpha, out=h_out,
+                     residual=h_mid),
+            ]
+            if nxt is not None:
+                qkv = torch.empty((T, 1, nxt.qkv.weight.shape[0]), device=x.device, dtype=x.dtype)
+                phases.append(dict(x=h_out, weight=nxt.qkv.weight, mask_packed=nxt.qkv.mask_packed, alpha=nxt.qkv.alpha, out=qkv,
+                                   norm_weight=nxt.norm1, eps=self.eps))
+            decode_chain(phases, tenants=T)
+            h = h_out
+        return h
+
     @torch.no_grad()
     def forward(self, ids, pos_idx, cache, attn_mask):
         """ids [T, S]; pos_idx [S] (device, positions of these tokens in the cache); attn_mask [T, 1, S, L] bool.
@@ -278,8 +324,11 @@ class TenantDecoder(nn.Module):
         cos, sin = self.cos[pos_idx], self.sin[pos_idx]
         t_idx = torch.arange(T, device=ids.device).view(T, 1)
         x = self.embed[t_idx, ids]                                            # per-tenant embedding: one gather
-        for li, layer in enumerate(self.layers):
-            x = self._layer(layer, x, cos, sin, cache, li, pos_idx, attn_mask)
+        if self._chain_ok(x):
+            x = self._decode_layers_chain(x, cache, pos_idx)
+        else:
+            for li, layer in enumerate(self.layers):
+                x = self._layer(layer, x, cos, sin, cache, li, pos_idx, attn_mask)
         last = self._norm(x[:, -1:, :], self.final_norm)
         return tenant_linear(last, self.lm_head)[:, 0, :]                     # per-tenant lm_head: one launch
 
