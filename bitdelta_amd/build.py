@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "bd_api.hip")
 OUT = os.path.join(HERE, "lib", "libbitdelta_hip.so")
 STAMP = OUT + ".srchash"
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-pass-failed"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-pass-failed"] + os.environ.get("HIPCC_EXTRA", "").split()
 
 
 def sources():

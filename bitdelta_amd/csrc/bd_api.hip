@@ -893,6 +893,10 @@ extern "C" int bd_binary_linear_decode_fused(const void* X, const void* W, const
 }
 
 // ------------------------------------------------------------------ persistent chain of decode Linears (bd_gemv_chain.h)
+// stages in flight per wave.  What crosses a phase boundary should cover the barrier + reload latency behind it (~8 us ~ 8 stages
+// chip-wide), and 6 is the most the 6-bit vmcnt allows a plain phase (5 x 10 loads outstanding) -- but 6 makes every phase's loop
+// ~10 % slower (as the stream kernel's own A/B found) and the step went 5.91 -> 6.63 ms: 4 it is.
+constexpr int CHAIN_NS = 4;
 template <int DT, int NM, int NS>
 static int launch_chain_inst(const ChainParams& cp, int grid, int lds, hipStream_t st) {
     auto kern = decode_chain_kernel<DT, NM, NS>;
@@ -923,11 +927,16 @@ extern "C" int bd_decode_chain(const bd_chain_phase_t* phases, int n_phases, int
     const bool tp_ok = t_pad == 4 || t_pad == 6 || t_pad == 8;
     if (!tp_ok || tenants < 1 || tenants > t_pad || !aligned16(sync) || num_cus() > 1024) return BD_E_BAD_SHAPE;
     static const int kinds[4] = {0, 2, 0, 1};
-    const int ns = 4;
+    const int ns = CHAIN_NS;
     const int cus = num_cus();
     const int grid = cus;
     ChainParams cp{};
     cp.nph = n_phases; cp.R = tenants; cp.tp = (uint32_t)t_pad; cp.sync = (unsigned*)sync;
+#ifdef BD_CHAIN_TRACE
+    cp.trace = (unsigned long long*)((char*)sync + CHAIN_SYNC_BYTES);      // the probe's buffer follows the sync area (caller: + 64 KiB)
+#else
+    cp.trace = nullptr;
+#endif
     cp.xs_off = (uint32_t)STREAM_XS_OFF; cp.xrow = 0;
     const int64_t lim = (1ll << 31) - 64;
     for (int i = 0; i < n_phases; ++i) {
@@ -970,9 +979,9 @@ extern "C" int bd_decode_chain(const bd_chain_phase_t* phases, int n_phases, int
     hipStream_t st = (hipStream_t)stream;
 #define BD_CH(NM, NS) (dtype == BD_BF16 ? launch_chain_inst<DT_BF16, NM, NS>(cp, grid, (int)lds, st) : launch_chain_inst<DT_F16, NM, NS>(cp, grid, (int)lds, st))
     switch (t_pad) {
-        case 4: return BD_CH(4, 4);
-        case 6: return BD_CH(6, 4);
-        default: return BD_CH(8, 4);
+        case 4: return BD_CH(4, CHAIN_NS);
+        case 6: return BD_CH(6, CHAIN_NS);
+        default: return BD_CH(8, CHAIN_NS);
     }
 #undef BD_CH
 }

@@ -57,6 +57,7 @@ struct ChainParams {
     int R;                               // tenants = activation rows (one token each)
     uint32_t tp;                         // dwords per (tile, iteration, lane group, column) of the sign packs
     uint32_t xs_off, xrow;               // LDS: normalised activation rows (XL phases)
+    unsigned long long* trace;           // BD_CHAIN_TRACE builds only (else unused)
     unsigned* sync;                      // [0] epoch, [1] error, [CHAIN_FLAG_WORD0 + block] arrival flags; zero-filled ONCE by the host
 };
 
@@ -69,6 +70,20 @@ __device__ __forceinline__ unsigned long long chain_load4(const unsigned short* 
 }
 
 constexpr int AUX_SC1 = 16;       // raw buffer load cache policy bit 4 on gfx940+: agent-coherent (bypasses this XCD's stale L2 lines)
+
+// Development probe (build with -DBD_CHAIN_TRACE): the owner wave of every block stamps s_memtime at 6 points of every phase into
+// trace[block][phase][6] = { phase entry, first compute, loop end, stores acknowledged, flag published, barrier passed }.
+#ifdef BD_CHAIN_TRACE
+#define BD_CT(slot)                                                                                                   \
+    do {                                                                                                              \
+        if (owner && cp.trace) {                                                                                      \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                               \
+            if (lane == 0) cp.trace[((long long)blockIdx.x * CHAIN_MAX_PHASES + I) * 6 + (slot)] = t_;                 \
+        }                                                                                                             \
+    } while (0)
+#else
+#define BD_CT(slot) do {} while (0)
+#endif
 
 template <int NM> struct ChainStage { u32x4_t xn[4]; u32x4_t wf[4]; uint32_t wd[NM]; };
 
@@ -111,6 +126,7 @@ __device__ __forceinline__ void chain_phase(const ChainParams& cp, ChainStage<NM
     const __amdgpu_buffer_rsrc_t rw2 = make_rsrc(qn.W, has_next ? qn.w_bytes : 0u), rp2 = make_rsrc(qn.P, has_next ? qn.p_bytes : 0u);
     const uint32_t x_off = li < R ? (uint32_t)((long long)li * q.sX * 2) : STREAM_OOB;
 
+    BD_CT(0);
     // ---- scales of this block's columns -> LDS table (first load of the phase)
     const int g0 = (EPI || ntile == 0) ? 0 : c_lo / q.gsz, ng = EPI ? 2 : (ntile > 0 ? (c_hi - 1) / q.gsz - g0 + 1 : 1);
     const bool al_lds = R * ng <= 256;
@@ -130,7 +146,9 @@ __device__ __forceinline__ void chain_phase(const ChainParams& cp, ChainStage<NM
         for (int j = 0; j < XCH; ++j) {
             const int r = j >> jsh, c = ((int)threadIdx.x + 256 * (j - (r << jsh))) * 8;
             const bool ok = r < R;
-            xraw[j] = buf_load16<AUX_SC1>(rx, ok ? (uint32_t)(((long long)r * q.sX + c) * 2) : STREAM_OOB);
+            // (default cache policy, like the plain phases' fragments: with sc1 every one of the 256 blocks fetched the same 96 KB from
+            //  the memory side -- 8-10 us from phase entry to the first MFMA instead of ~3, measured with the BD_CHAIN_TRACE probe)
+            xraw[j] = buf_load16<0>(rx, ok ? (uint32_t)(((long long)r * q.sX + c) * 2) : STREAM_OOB);
             graw[j] = buf_load16<0>(rn, ok ? (uint32_t)(((long long)r * q.sNw + c) * 2) : STREAM_OOB);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -232,6 +250,7 @@ __device__ __forceinline__ void chain_phase(const ChainParams& cp, ChainStage<NM
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
+    BD_CT(1);
     f32x4_t accB = {0.f, 0.f, 0.f, 0.f}, accD[NM];
 #pragma unroll
     for (int t = 0; t < NM; ++t) accD[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -363,9 +382,11 @@ __device__ __forceinline__ void chain_phase(const ChainParams& cp, ChainStage<NM
     }
 
     // ---- phase boundary
+    BD_CT(2);
     if (has_next) {
         if (owner) {
             __builtin_amdgcn_s_waitcnt(0x0f70);                          // vmcnt(0): every output store of this block is acknowledged
+            BD_CT(3);
 #pragma unroll
             for (int u = 0; u < NS; ++u) {                               // its own first NS stages of the next phase, only now
                 ChainStage<NM>& s_ = st[u];
@@ -403,6 +424,7 @@ __device__ __forceinline__ void chain_phase(const ChainParams& cp, ChainStage<NM
             const unsigned target = epoch * 4u + (unsigned)I + 1u;
             unsigned* const flags = cp.sync + CHAIN_FLAG_WORD0;
             if (lane == 0) __hip_atomic_store(&flags[blockIdx.x], target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            BD_CT(4);
             const __amdgpu_buffer_rsrc_t rf = make_rsrc(flags, gridDim.x * 4u);
             int spins = 0;
             for (;;) {
@@ -420,6 +442,7 @@ __device__ __forceinline__ void chain_phase(const ChainParams& cp, ChainStage<NM
                     break;
                 }
             }
+            BD_CT(5);
         }
         __builtin_amdgcn_s_barrier();                                    // waves 0-2 sleep here until the owner has seen the barrier
         asm volatile("" ::: "memory");

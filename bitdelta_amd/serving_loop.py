@@ -35,6 +35,7 @@ MODEL_CONFIGS = {
     "llama-2-70b": (8192, 28672, 80, 64, 8, 32000),
     "tiny": (256, 512, 2, 4, 2, 512),
     "tiny128": (512, 1024, 2, 4, 1, 512),        # head_dim 128, 4 query heads per kv head: exercises the decode glue kernels
+    "tiny4096": (4096, 4096, 2, 32, 8, 512),     # two Llama-width layers: exercises the persistent chain launch (K >= 3072)
     "tiny2048": (2048, 2048, 2, 16, 4, 512),     # hidden % 2048 == 0: exercises the fused RMSNorm / SwiGLU launches
 }
 

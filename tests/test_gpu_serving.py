@@ -474,12 +474,12 @@ def test_persistent_chain_is_bit_identical_to_separate_launches(bd, dtype, T, hi
 
 
 def test_serving_loop_persistent_chain_matches_separate_launches(bd):
-    """hidden = 2048 decoder: the decode step with one persistent launch per layer produces the same logits (bit for bit) and tokens as
+    """hidden = 4096 decoder: the decode step with one persistent launch per layer produces the same logits (bit for bit) and tokens as
     the step made of separate launches; eager and hipGraph replay."""
     from bitdelta_amd.binary_gemm_kernel import decode_chain_error
     from bitdelta_amd.serving_loop import TenantDecoder
     T = 3
-    dec = TenantDecoder.synthetic("tiny2048", T, "cuda", dtype=torch.float16, seed=5, max_len=160)
+    dec = TenantDecoder.synthetic("tiny4096", T, "cuda", dtype=torch.float16, seed=5, max_len=160)
     g = torch.Generator().manual_seed(3)
     prompts = [torch.randint(1, 512, (n,), generator=g).tolist() for n in (12, 64, 40)]
     ids, am = dec.prepare(prompts)
