@@ -70,9 +70,10 @@ class SingleTenantLinear(nn.Module):
         self.lin = BinaryDiff(w, fine)
         self.lin.coeff.requires_grad_(False)
         self.flops_per_row = 4 * n_out * n_in
+        self.residual_epilogue = True
 
-    def forward(self, x):
-        return self.lin(x)
+    def forward(self, x, residual=None):
+        return self.lin(x, residual=residual)
 
 
 class MultiTenantLinear(nn.Module):
@@ -92,9 +93,11 @@ class MultiTenantLinear(nn.Module):
         base.weight.requires_grad_(False)
         self.lin = DiffCompressModule(base, torch.stack(masks, 0).contiguous(), torch.stack(coeffs, 0).to(dtype))
         self.flops_per_row = 4 * n_out * n_in
+        self.residual_epilogue = False
 
-    def forward(self, x):
-        return self.lin(x)
+    def forward(self, x, residual=None):
+        y = self.lin(x)
+        return y if residual is None else residual.add_(y)
 
 
 class DecoderLayer(nn.Module):
@@ -139,12 +142,17 @@ class DecoderLayer(nn.Module):
             v = v.repeat_interleave(rep, dim=1)
         a = F.scaled_dot_product_attention(q, k, v, is_causal=(S > 1 and k.shape[2] == S))
         a = a.transpose(1, 2).reshape(B, S, self.heads * self.hd)
-        x = x + self.o_proj(a)
+        x = self.o_proj(a, residual=x) if self._res_epilogue(x, self.o_proj) else x + self.o_proj(a)
         h = self.post_attention_layernorm(x)
         g, u = self.gate_proj(h), self.up_proj(h)
         act = ops.swiglu2(g, u) if g.shape[-1] % 8 == 0 else F.silu(g) * u       # one pass: round(silu(g)) * u
-        x = x + self.down_proj(act)
+        x = self.down_proj(act, residual=x) if self._res_epilogue(x, self.down_proj) else x + self.down_proj(act)
         return x
+
+    @staticmethod
+    def _res_epilogue(x, proj):
+        # the residual stream is updated in place by the Linear's epilogue (inference, contiguous [B, S, hidden])
+        return proj.residual_epilogue and (not torch.is_grad_enabled()) and x.is_contiguous()
 
 
 class Decoder(nn.Module):

@@ -120,7 +120,8 @@ def binary_linear(x, weight, mask, alpha, *, out_dtype=None, groups=1, residual=
     Replaces the four launches of BinaryDiff.forward (bitdelta/diff.py:38-39) / DiffCompressModule.forward
     (demo/demo_backend.py:95-98).  fp32 accumulation, one rounding to ``out_dtype`` (default: x.dtype).
     residual: optional (B, M, N) tensor of out_dtype that is updated IN PLACE to residual + y and returned (the decoder layer's
-    `hidden = residual + proj(...)`): folded into the kernel epilogue at decode shapes, a separate add otherwise.
+    `hidden = residual + proj(...)`): folded into the kernel epilogue at decode shapes (fp32 sum, one rounding) and on the fast
+    path of the fused GEMM at M > 16 (output rounded, then the sum: the two roundings of the separate ops); a separate add otherwise.
     """
     require_gpu(x, weight, mask, alpha, residual)
     assert x.dim() == 3 and mask.dim() == 3 and weight.dim() == 2
@@ -138,8 +139,9 @@ def binary_linear(x, weight, mask, alpha, *, out_dtype=None, groups=1, residual=
     sPb = 0 if (mask.shape[0] == 1 and B > 1) else mask.stride(0)
     sAlb = 0 if alpha.shape[0] == 1 else groups
     L = lib()
-    fused_residual = (residual is not None and M <= 16 and B * M <= 64 and K % 32 == 0 and x.data_ptr() % 16 == 0 and
-                      x.stride(0) % 8 == 0 and x.stride(1) % 8 == 0 and weight.data_ptr() % 16 == 0 and weight.stride(0) % 8 == 0)
+    aligned = (x.data_ptr() % 16 == 0 and x.stride(0) % 8 == 0 and x.stride(1) % 8 == 0 and weight.data_ptr() % 16 == 0 and
+               weight.stride(0) % 8 == 0)
+    fused_residual = residual is not None and aligned and ((M <= 16 and B * M <= 64 and K % 32 == 0) or (M > 16 and K % 64 == 0))
     if residual is not None:
         assert residual.shape == (B, M, N) and residual.dtype == out_dtype and residual.stride(2) == 1
     y = residual if fused_residual else torch.empty((B, M, N), device=x.device, dtype=out_dtype)

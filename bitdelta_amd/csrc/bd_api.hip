@@ -645,7 +645,7 @@ int dispatch3(const Problem& q) {
     if (v < 0) {
         if (gemv_ok(q)) v = 200;
         else if (!fast_ok(q)) v = 100;
-        else if (FUSED && q.M > 16 && q.sCm % 4 == 0 && q.sCb % 4 == 0 && splitk_factor(q.B, q.M, q.N, q.K) > 1 && q.ws &&
+        else if (FUSED && q.M > 16 && !q.accumulate && q.sCm % 4 == 0 && q.sCb % 4 == 0 && splitk_factor(q.B, q.M, q.N, q.K) > 1 && q.ws &&
                  q.ws_bytes >= GEMV_TICKET_BYTES + (int64_t)q.B * splitk_factor(q.B, q.M, q.N, q.K) * q.M * q.N * 4) v = 10;
         else if (FUSED && q.M > 16 && q.M <= 64)                  // (not split: there are enough 64-row tiles)
             // 64x256 tiles (twice the MFMAs per X fragment read) once they fill at least half the CUs, else 64x128 for the parallelism:
@@ -661,7 +661,9 @@ int dispatch3(const Problem& q) {
         if ((v == 200 || v == 300 || v == 400 || v == 500 || v == 600) && !gemv_ok(q)) return BD_E_BAD_SHAPE;
         if (v >= 0 && v <= 12 && !fast_ok(q)) return BD_E_BAD_SHAPE;
         if ((v == 8 || v == 9 || v == 10 || v == 11 || v == 12) && !FUSED) return BD_E_BAD_SHAPE;
-        if (v == 10 && (q.N % 8 || q.sCm % 4 || q.sCb % 4)) return BD_E_BAD_SHAPE;
+        if (v == 10 && (q.N % 8 || q.sCm % 4 || q.sCb % 4 || q.accumulate)) return BD_E_BAD_SHAPE;
+        if (FUSED && q.accumulate && !(v == 8 || v == 9 || v == 11 || v == 12 || v == 200 || v == 300 || v == 400 || v == 500 || v == 600))
+            return BD_E_BAD_SHAPE;            // residual epilogue: one-pass fused tiles and the decode kernels only
     }
     t_last_variant = v;
     switch (v) {
@@ -860,7 +862,8 @@ static int binary_linear_impl(const void* X, const void* W, const int32_t* P, co
     }
     // Y += ... is an epilogue of the decode kernels only (a residual add costs a launch per Linear there; at prefill sizes it is
     // noise next to the GEMM and stays with the caller)
-    if (q.accumulate && !(gemv_ok(q) && g_forced_variant < 0 || (g_forced_variant >= 200 && gemv_ok(q)))) return BD_E_BAD_SHAPE;
+    // Y += ... (residual epilogue): the decode kernels and the one-pass fused tile kernels (M > 16 on their fast path)
+    if (q.accumulate && !gemv_ok(q) && !(M > 16 && fast_ok(q))) return BD_E_BAD_SHAPE;
     return dispatch(q);
 }
 

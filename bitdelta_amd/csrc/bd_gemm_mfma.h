@@ -103,6 +103,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
     const int h = lane >> 5, l31 = lane & 31;
     const long long c_b = (long long)b * p.sCb;
     const bool acc_mode = !Cfg::FUSED && p.accumulate;
+    // fused Linear with the residual connection in its epilogue (prefill: `hidden = residual + proj(x)`): C holds the residual; the
+    // Linear's output is rounded to the output type first and the sum is rounded again -- the two roundings of the separate
+    // `y = proj(x); hidden = residual + y` it replaces (one pass over [M, N] less).
+    const bool res_mode = Cfg::FUSED && p.accumulate;
     const float* al = (acc_mode) ? p.alpha + (long long)b * p.sAlb : nullptr;
     const bool fast = STAGE_OK && (p.N % 8 == 0) && (p.sCm % 8 == 0) && (p.sCb % 8 == 0) && (((uintptr_t)p.C & 15) == 0);
 
@@ -113,6 +117,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
             return cin + al[n / p.gsz] * v;
         }
         if (!Cfg::FUSED && p.round_mode == 1) return round_through_f16(v);
+        if (res_mode) {
+            if constexpr (Cfg::OUT_F32) return ((const float*)p.C)[off] + v;
+            else return half_bits_to_f32<DT>(((const unsigned short*)p.C)[off]) + half_bits_to_f32<DT>(f32_to_half_bits<DT>(v));
+        }
         return v;
     };
 
@@ -158,9 +166,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
                 const int r = r0 + lane / SEG, sg = lane % SEG;
                 const int m = m0 + wm * WM + i0 * 32 + r;
                 const int n = n0 + wn * WN + sg * (16 / ESZ);
-                const u32x4_t val = *(const u32x4_t*)(buf + r * ROWB + sg * 16);
+                u32x4_t val = *(const u32x4_t*)(buf + r * ROWB + sg * 16);
                 if (m < p.M && n < p.N) {   // N % 8 == 0 -> a 16-byte piece is entirely in or out
                     u32x4_t* dst = (u32x4_t*)(p.C + (c_b + (long long)m * p.sCm + n) * ESZ);
+                    if (res_mode) {         // coalesced: the residual piece this lane is about to overwrite
+                        const u32x4_t rsd = *(const u32x4_t*)dst;
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            if constexpr (Cfg::OUT_F32) {
+                                val[d] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(float, val[d]) + __builtin_bit_cast(float, rsd[d]));
+                            } else {
+                                const float lo = half_bits_to_f32<DT>(val[d] & 0xffffu) + half_bits_to_f32<DT>(rsd[d] & 0xffffu);
+                                const float hi = half_bits_to_f32<DT>(val[d] >> 16) + half_bits_to_f32<DT>(rsd[d] >> 16);
+                                val[d] = f32_to_half_bits<DT>(lo) | (f32_to_half_bits<DT>(hi) << 16);
+                            }
+                        }
+                    }
                     if constexpr (Cfg::OPT & 1024) *dst = val;                 // A/B: plain stores
                     else __builtin_nontemporal_store(val, dst);                // C is written once and not re-read by this kernel
                 }

@@ -115,13 +115,20 @@ class BinaryDiff(nn.Module):
             self._mask_t = transpose_mask(self.mask)
         return self._mask_t
 
-    def forward(self, x):
-        # [B, seq, in] @ [in, out] + coeff * ([B, seq, in] @ S),  S = +-1 from the packed mask (broadcast, never repeated)
+    def forward(self, x, *, residual=None):
+        # [B, seq, in] @ [in, out] + coeff * ([B, seq, in] @ S),  S = +-1 from the packed mask (broadcast, never repeated).
+        # `residual` (keyword-only extension of the reference signature; inference only): the decoder layer's
+        # `hidden = residual + proj(x)` in the kernel epilogue; `residual` is updated in place and returned.
         shape = x.shape
         x3 = x.reshape(1, -1, shape[-1])     # one [B*seq, in] problem: the mask is shared by every row
         if x3.stride(-1) != 1:
             x3 = x3.contiguous()
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or self.coeff.requires_grad)
+        if residual is not None:
+            assert not needs_grad and residual.is_contiguous() and residual.shape[:-1] == shape[:-1]
+            r3 = residual.view(1, -1, residual.shape[-1])
+            binary_linear(x3, self._weight_nk(), self.mask.unsqueeze(0), self.coeff.reshape(1, 1), residual=r3)
+            return residual
         if not needs_grad:
             y = binary_linear(x3, self._weight_nk(), self.mask.unsqueeze(0), self.coeff.reshape(1, 1))
         elif self.delta_input_grad:

@@ -139,9 +139,11 @@ int bd_decode_chain(const bd_chain_phase_t* phases, int n_phases, int tenants, i
 int64_t bd_decode_chain_sync_bytes(void);
 
 /* the same Linear with the residual connection folded into its epilogue:  Y[b] = Y_in[b] + X[b] . W^T + alpha * (X[b] . S[b])
- * (fp32 sum, one rounding) -- the `hidden = residual + o_proj(...)` / `+ down_proj(...)` of the decoder layers that call the
- * reference's modules.  Decode shapes only (B*M <= 64 rows, M <= 16: where the add would otherwise be a launch of its own);
- * anything larger returns BD_E_BAD_SHAPE and the caller adds the residual itself. */
+ * -- the `hidden = residual + o_proj(...)` / `+ down_proj(...)` of the decoder layers that call the reference's modules.
+ * Decode shapes (M <= 16, B*M <= 64): fp32 sum, one rounding.  M > 16 on the fused GEMM's fast path (K % 64 == 0, 16-byte aligned
+ * rows): the Linear's output is rounded to the output type and the sum is rounded again, i.e. exactly the two roundings of the
+ * separate `y = proj(x); hidden = residual + y` (bit-identical to it), one pass over [M, N] less.  Anything else returns
+ * BD_E_BAD_SHAPE and the caller adds the residual itself. */
 int bd_binary_linear_residual(const void* X, const void* W, const int32_t* P, const float* alpha, void* Y,
                               int B, int M, int N, int K,
                               int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb, int64_t sAlb, int G,

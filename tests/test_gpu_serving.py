@@ -111,7 +111,10 @@ def test_data_parallel_module_matches_reference_loop(bd):
 
 def test_binary_linear_residual_epilogue(bd, oracle):
     g = torch.Generator().manual_seed(7)
-    for B, M, K, N, T in ((6, 1, 1024, 1000, 6), (2, 3, 512, 520, 1), (2, 40, 256, 520, 2)):
+    # M <= 16: decode kernels; M > 16 with K % 64 == 0: the one-pass fused GEMM's epilogue (64-row, 128-row and 256-row tiles,
+    # ragged M / N, bf16-free fp16 here; bf16 below); K % 64 != 0: caller-side add
+    for B, M, K, N, T in ((6, 1, 1024, 1000, 6), (2, 3, 512, 520, 1), (2, 40, 256, 520, 2), (6, 64, 512, 640, 6), (1, 300, 256, 264, 1),
+                          (1, 130, 128, 136, 1), (1, 600, 1024, 384, 1), (1, 40, 96, 136, 1)):
         a = torch.randn(B, M, K, generator=g).half()
         p = torch.randint(-2 ** 31, 2 ** 31 - 1, (T, K // 32, N), generator=g, dtype=torch.int64).to(torch.int32)
         w = (torch.randn(N, K, generator=g) * 0.02).half()
@@ -128,6 +131,9 @@ def test_binary_linear_residual_epilogue(bd, oracle):
         d = (out.cpu().float() - want.float()).abs()
         # one fp16 ulp at the magnitude of the larger addend (the sum may cancel to something much smaller than its terms)
         assert (d <= (res.float().abs() + y32.abs()) * 2 ** -10 + 1e-4).all()
+        if M > 16 and K % 64 == 0:     # the GEMM epilogue reproduces the separate ops exactly where the Linear output is bit-equal
+            y16 = bd.binary_linear(a.cuda(), w.cuda(), p.cuda(), alpha.cuda())
+            assert torch.equal(out, res.cuda() + y16)
 
 
 def test_differentiable_delta_term(bd):
