@@ -77,10 +77,16 @@ def check_linear(bd, oracle, x, w, p, alpha, cols=None, groups=1):
     assert fro <= 1e-5, fro
     ref16 = ref32.to(x.dtype)
     d = ulp_diff(got16.contiguous(), ref16)
-    ok = (d <= 1) | ((got16.float() - ref16.float()).abs() <= 2e-6 * (K ** 0.5) * 4)
+    ok = (d <= 1) | ((got16.float() - ref16.float()).abs() <= cancel_floor(ref16, K))
     assert bool(ok.all()), d.max().item()
     assert (d == 0).float().mean().item() >= 0.99
     return y16
+
+
+def cancel_floor(ref, K):
+    """absolute floor for outputs that cancel to ~0 (ulp distance is meaningless there): fp32 rounding of partial sums as large as
+    the largest output, random-walked over K terms -- scales with the problem, not a flat constant"""
+    return 2.0 ** -22 * (K ** 0.5) * max(ref.float().abs().max().item(), 1e-30)
 
 
 def check_delta(bd, oracle, x, p, cols=None):
@@ -97,7 +103,7 @@ def check_delta(bd, oracle, x, p, cols=None):
         got = c[:, :, cols].contiguous()
     d = ulp_diff(got, ref)
     K = x.shape[-1]
-    ok = (d <= 1) | ((got.float() - ref.float()).abs() <= 2e-6 * (K ** 0.5) * 4)
+    ok = (d <= 1) | ((got.float() - ref.float()).abs() <= cancel_floor(ref, K))
     assert bool(ok.all()) and (d == 0).float().mean().item() >= 0.99
 
 
@@ -118,7 +124,7 @@ def test_config1_binarylinear_4096x4096_bf16_act_1x128x4096(bd, oracle):
     assert y.dtype == torch.bfloat16 and y.shape == (1, 128, N)
     ref32 = oracle.binary_linear(x, base, mo[None], co.reshape(1, 1), out_dtype=torch.float32, round_mode=0)
     d = ulp_diff(y, ref32.bfloat16())
-    ok = (d <= 1) | ((y.float() - ref32).abs() <= 2e-6 * 64 * 4)
+    ok = (d <= 1) | ((y.float() - ref32).abs() <= cancel_floor(ref32, K))
     assert bool(ok.all()) and (d == 0).float().mean().item() >= 0.99
     # not worse than the reference's own 4-rounding chain (SURVEY.md 7b iv)
     chain = oracle.binary_linear(x, base, mo[None], co.reshape(1, 1), round_mode=1)
