@@ -11,7 +11,7 @@ def rmsnorm_tenant(x, w, eps):
     require_gpu(x, w)
     T, M, H = x.shape
     assert w.shape == (T, H) and w.dtype == x.dtype and x.stride(2) == 1 and w.stride(1) == 1
-    assert x.stride(0) == M * x.stride(1), "rows must be evenly strided"
+    assert T == 1 or x.stride(0) == M * x.stride(1), "rows must be evenly strided"
     y = torch.empty((T, M, H), device=x.device, dtype=x.dtype)
     with torch.cuda.device(x.device):
         check(lib().bd_srv_rmsnorm(ptr(x), ptr(w), ptr(y), T * M, H, x.stride(1), H, w.stride(0), M, float(eps),
@@ -30,7 +30,7 @@ def swiglu2(g, u):
     require_gpu(g, u)
     B, S, I = g.shape
     assert u.shape == g.shape and u.dtype == g.dtype and g.stride(2) == 1 and u.stride(2) == 1
-    assert g.stride(0) == S * g.stride(1) and u.stride(0) == S * u.stride(1)
+    assert B == 1 or (g.stride(0) == S * g.stride(1) and u.stride(0) == S * u.stride(1))
     y = torch.empty((B, S, I), device=g.device, dtype=g.dtype)
     with torch.cuda.device(g.device):
         check(lib().bd_srv_swiglu(ptr(g), ptr(u), ptr(y), B * S, I, g.stride(1), u.stride(1), I, 0, DTYPE_CODE[g.dtype], stream_ptr()),
@@ -44,7 +44,7 @@ def swiglu_interleaved8(gu):
     require_gpu(gu)
     B, S, I2 = gu.shape
     I = I2 // 2
-    assert I2 % 16 == 0 and gu.stride(2) == 1 and gu.stride(0) == S * gu.stride(1)
+    assert I2 % 16 == 0 and gu.stride(2) == 1 and (B == 1 or gu.stride(0) == S * gu.stride(1))
     y = torch.empty((B, S, I), device=gu.device, dtype=gu.dtype)
     with torch.cuda.device(gu.device):
         check(lib().bd_srv_swiglu(ptr(gu), ptr(gu), ptr(y), B * S, I, gu.stride(1), gu.stride(1), I, 1, DTYPE_CODE[gu.dtype],
@@ -82,7 +82,8 @@ def rope_(x, cos, sin, heads, seq, pos0=0):
     """In-place rotary embedding of x [B, S, heads * 128] (a q / k projection output, before the head transpose); row r sits at position
     pos0 + r % seq.  cos / sin [Lmax, 128] in x.dtype with the rotate-half sign folded into sin.  Returns x."""
     require_gpu(x, cos, sin)
-    assert x.dim() == 3 and x.shape[2] == heads * 128 and x.stride(2) == 1 and x.stride(0) == x.shape[1] * x.stride(1)
+    assert x.dim() == 3 and x.shape[2] == heads * 128 and x.stride(2) == 1
+    assert x.shape[0] == 1 or x.stride(0) == x.shape[1] * x.stride(1)
     assert cos.is_contiguous() and sin.is_contiguous() and cos.dtype == x.dtype and cos.shape[0] >= pos0 + seq
     with torch.cuda.device(x.device):
         check(lib().bd_srv_rope(ptr(x), ptr(cos), ptr(sin), x.shape[0] * x.shape[1], heads, 128, x.stride(1), seq, pos0,

@@ -511,3 +511,14 @@ def test_serving_loop_persistent_chain_matches_separate_launches(bd):
     ref = outs[(False, False)]
     for k, v in outs.items():
         assert torch.equal(v, ref), k
+
+
+def test_serving_loop_single_tenant(bd):
+    """T = 1 (config 2's decode steps through the same loop): size-1 batch dims carry arbitrary strides -- prefill, graph decode and
+    eager decode agree token for token."""
+    from bitdelta_amd.serving_loop import TenantDecoder
+    dec = TenantDecoder.synthetic("tiny128", 1, "cuda", dtype=torch.float16, seed=3, max_len=160)
+    prompts = [list(range(1, 41))]
+    a, n1 = dec.generate(prompts, max_new_tokens=6, use_graph=True)
+    b, n2 = dec.generate(prompts, max_new_tokens=6, use_graph=False)
+    assert n1 == n2 == 6 and torch.equal(a, b)
