@@ -20,12 +20,19 @@
 //     the next phase, arrives at the grid barrier (a store to its own flag word), and polls.  Its first poll result returns when its
 //     prefetch has landed, which is about when the barrier completes; then it joins the s_barrier and the block goes on.
 // Outputs are written with agent-scope relaxed atomics (they go to the coherence point; the XCDs' L2s are not coherent for plain
-// stores).  A norm phase reads its rows once, with sc1 loads; a plain phase re-reads its activation fragments in every stage and
-// must hit L2 for them (with sc1 the x traffic equals the weight traffic: measured +38 us per layer), which is safe because the
-// buffer is first touched by this launch after the barrier behind its producer and no 128-byte line of it is written from two XCDs
-// (host-checked).  The residual stream ping-pongs between buffers (out = res + ...), so no phase reads a line that an earlier
-// phase of the same launch already pulled into its L2.  Same arithmetic, same order as the
-// separate launches (gemv_stream_kernel XL / EPI): results are bit-identical to them (tests/test_gpu_serving.py).
+// stores).  Activations are READ with the default cache policy: a plain phase re-reads its fragments in every stage of every wave
+// and a norm phase's 96 KB of rows are wanted by all 32 blocks of an XCD, so both must be served by L2.  That is safe because each
+// such buffer is first touched by this launch after the barrier behind its producer, and no 128-byte line of it is written from
+// two XCDs (host-checked for the one buffer whose block ranges are not line-aligned by construction).  The residual stream
+// ping-pongs between buffers (out = res + ...), so no phase reads a line that an earlier phase of the same launch already pulled
+// into its L2.  Same arithmetic, same order as the separate launches (gemv_stream_kernel XL / EPI): results are bit-identical to
+// them (tests/test_gpu_serving.py).
+//
+// STATUS (profiles/r02_decode_step.txt, r02_decode_chain_timeline.txt): correct and deterministic, but 157 us per Mistral layer
+// against 144.5 us for the four launches it replaces -- the loops run at the streaming ceiling, and a phase boundary (stores
+// acknowledged -> flag visible -> poll -> activation reload queued behind the landing prefetch -> RMSNorm) is 8-10 us of dependent
+// round trips of which the 4 prefetched stages cover 4.4.  Opt-in (TenantDecoder.persistent); DESIGN.md section 8.1 lists what
+// would make it pay.
 #pragma once
 #include "bd_gemv_stream.h"
 
