@@ -221,11 +221,14 @@ def run_mt_decode(dev, timer, model_name, tenants, kv_len, steps, warmup, layers
     ab = None
     if ab_glue and graph_ms is not None:
         # same process, same box, alternating: the step with RMSNorm / SwiGLU folded into the Linear launches vs separate glue launches
-        ab = {"persistent_chain_ms": [], "fused_glue_ms": [], "separate_glue_ms": []}
+        ab = {"persistent_chain_ms": [], "fused_glue_ms": [], "fused_gateup_only_ms": [], "swiglu_epilogue_only_ms": [], "separate_glue_ms": []}
         runners = {}
-        keep = (dec.persistent, dec.fuse_glue)
-        for name, pers, flag in (("persistent_chain_ms", True, True), ("fused_glue_ms", False, True), ("separate_glue_ms", False, False)):
-            dec.persistent, dec.fuse_glue = pers, flag
+        keep = (dec.persistent, dec.fuse_glue, dec.fuse_qkv_norm, dec.fuse_gateup_norm)
+        for name, pers, flag, qn, gn in (("persistent_chain_ms", True, True, True, True), ("fused_glue_ms", False, True, True, True),
+                                         ("fused_gateup_only_ms", False, True, False, True),
+                                         ("swiglu_epilogue_only_ms", False, True, False, False),
+                                         ("separate_glue_ms", False, False, True, True)):
+            dec.persistent, dec.fuse_glue, dec.fuse_qkv_norm, dec.fuse_gateup_norm = pers, flag, qn, gn
             restore()
             runners[name] = dec._graph_runner(st)
         for _ in range(3):
@@ -233,7 +236,7 @@ def run_mt_decode(dev, timer, model_name, tenants, kv_len, steps, warmup, layers
                 restore()
                 run()
                 ab[name].append(bdd.timed_region(run, steps, device_sync=torch.cuda.synchronize) / steps * 1e3)
-        dec.persistent, dec.fuse_glue = keep
+        dec.persistent, dec.fuse_glue, dec.fuse_qkv_norm, dec.fuse_gateup_norm = keep
     lin_bytes, head_bytes = dec.linear_bytes_per_step()
     best_ms = graph_ms if graph_ms is not None else eager_s / steps * 1e3
     out = {

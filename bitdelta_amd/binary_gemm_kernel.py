@@ -211,7 +211,7 @@ def binary_linear_decode(x, weight, mask, alpha, *, layout="tile", out_dtype=Non
     layout "tile":   mask = tile_masks(...)        (B or 1, ceil(N/16), K/32, 16)
     layout "packed": mask = pack_decode_masks(...) (ceil(N/16), ceil(K/128), 4, 16, t_pad), B <= t_pad tenants, B*M <= 16.
     Packed layout only: norm_weight (B or 1, K) fuses the HF RMSNorm of x (x = the un-normalised residual stream) into the launch;
-    swiglu=True (with norm_weight) treats weight/mask as a gate|up pair interleaved in blocks of 8 output rows, alpha (B or 1, 2) =
+    swiglu=True (with or without norm_weight) treats weight/mask as a gate|up pair interleaved in blocks of 8 output rows, alpha (B or 1, 2) =
     (gate, up) scales, and returns act_fn(gate) * up, (B, M, N/2).  Both bit-identical to the separate launches."""
     require_gpu(x, weight, mask, alpha, residual, norm_weight)
     B, M, K = x.shape
@@ -234,18 +234,21 @@ def binary_linear_decode(x, weight, mask, alpha, *, layout="tile", out_dtype=Non
     alpha = alpha.reshape(-1, groups)
     assert alpha.shape[0] in (1, B)
     sAlb = 0 if alpha.shape[0] == 1 else groups
+    s_norm = 0
     if norm_weight is not None or swiglu:
-        assert layout == "packed" and norm_weight is not None and fused_norm_ok(B, M, K)
-        assert norm_weight.dim() == 2 and norm_weight.shape[1] == K and norm_weight.shape[0] in (1, B)
-        assert norm_weight.dtype == x.dtype and norm_weight.stride(1) == 1
+        assert layout == "packed" and M == 1
+        if norm_weight is not None:
+            assert fused_norm_ok(B, M, K)
+            assert norm_weight.dim() == 2 and norm_weight.shape[1] == K and norm_weight.shape[0] in (1, B)
+            assert norm_weight.dtype == x.dtype and norm_weight.stride(1) == 1
+            s_norm = 0 if (norm_weight.shape[0] == 1 and B > 1) else norm_weight.stride(0)
         assert not swiglu or (groups == 2 and N % 16 == 0 and residual is None and out_dtype == x.dtype)
-        s_norm = 0 if (norm_weight.shape[0] == 1 and B > 1) else norm_weight.stride(0)
     if residual is not None:
         assert residual.shape == (B, M, N) and residual.dtype == out_dtype and residual.stride(2) == 1
         y = residual
     else:
         y = torch.empty((B, M, N // 2 if swiglu else N), device=x.device, dtype=out_dtype)
-    if norm_weight is not None:
+    if norm_weight is not None or swiglu:
         with torch.cuda.device(x.device):
             check(lib().bd_binary_linear_decode_fused(ptr(x), ptr(weight), ptr(mask), t_pad, ptr(alpha), ptr(y), B, M, N, K,
                                                       x.stride(0), x.stride(1), weight.stride(0), sPb, sAlb, groups, y.stride(0),

@@ -394,7 +394,7 @@ int launch_gemv_stream_chunk(const Problem& q) {
         sp.p_bytes = (uint32_t)((int64_t)((q.N + 15) / 16) * ((q.K + 127) / 128) * 4 * 16 * q.t_pad * 4);
 #define BD_PK(NM, NS4) rc = q.norm_w ? (q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1, 1, 1>(sp, dim3(grid), q.st)   \
                                                         : launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1, 1, 0>(sp, dim3(grid), q.st))  \
-                     : q.epilogue == 1 ? BD_E_BAD_SHAPE                                                                           \
+                     : q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1, 0, 1>(sp, dim3(grid), q.st)            \
                      : q.W ? launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1>(sp, dim3(grid), q.st)                              \
                            : launch_stream_inst<DT, NM, false, NS4, 4, 1, 0, 1>(sp, dim3(grid), q.st)
         switch (q.t_pad) {
@@ -838,12 +838,14 @@ static int binary_linear_impl(const void* X, const void* W, const int32_t* P, co
     q.norm_w = norm_w; q.sNw = sNw; q.eps = eps; q.epilogue = epilogue;
     if (norm_w || epilogue) {
         // fused prologue / epilogue of the packed streaming kernel: see gemv_stream_kernel (XL, EPI)
-        if (mask_tiled != 2 || (epilogue != 0 && epilogue != 1) || (epilogue && !norm_w)) return BD_E_BAD_SHAPE;
-        if (!aligned16(norm_w) || sNw % 8 || sNw < 0) return BD_E_BAD_SHAPE;
-        // one row per tenant (M == 1: the decode step), K = 2048 * 2^s, all rows in 16 x 16-byte chunks per thread
-        if (M != 1 || K < 2048 || (K & (K - 1)) || (int64_t)B * K > 16 * 2048) return BD_E_BAD_SHAPE;
-        if ((int64_t)STREAM_XS_OFF + (int64_t)B * M * (2 * (int64_t)K + 16) > STREAM_LDS_MAX) return BD_E_BAD_SHAPE;
-        if ((int64_t)(B - 1) * sNw + K >= (1ll << 30)) return BD_E_BAD_SHAPE;
+        if (mask_tiled != 2 || (epilogue != 0 && epilogue != 1)) return BD_E_BAD_SHAPE;
+        if (norm_w) {
+            if (!aligned16(norm_w) || sNw % 8 || sNw < 0) return BD_E_BAD_SHAPE;
+            // one row per tenant (M == 1: the decode step), K = 2048 * 2^s, all rows in 16 x 16-byte chunks per thread
+            if (M != 1 || K < 2048 || (K & (K - 1)) || (int64_t)B * K > 16 * 2048) return BD_E_BAD_SHAPE;
+            if ((int64_t)STREAM_XS_OFF + (int64_t)B * M * (2 * (int64_t)K + 16) > STREAM_LDS_MAX) return BD_E_BAD_SHAPE;
+            if ((int64_t)(B - 1) * sNw + K >= (1ll << 30)) return BD_E_BAD_SHAPE;
+        }
         if (epilogue && (N % 16 || G != 2 || out_dtype != dtype || accumulate)) return BD_E_BAD_SHAPE;
     }
     q.ws = ws; q.ws_bytes = ws_bytes; q.st = (hipStream_t)stream;
@@ -889,7 +891,7 @@ extern "C" int bd_binary_linear_decode_fused(const void* X, const void* W, const
                                              int64_t sAlb, int G, int64_t sYb, int64_t sYm, int dtype, int out_dtype,
                                              int accumulate, const void* norm_w, int64_t s_norm, float eps, int epilogue,
                                              void* stream) {
-    if (!norm_w) return BD_E_NULL;
+    if (!norm_w && epilogue != 1) return BD_E_NULL;
     if (B < 1 || M < 1 || N < 1 || K < 1) return BD_E_BAD_SHAPE;
     return binary_linear_impl(X, W, P, alpha, Y, B, M, N, K, sXb, sXm, ldw, sPb, sAlb, G, sYb, sYm, dtype, out_dtype, accumulate, 2,
                               t_pad, nullptr, 0, stream, norm_w, s_norm, eps, epilogue);

@@ -117,6 +117,7 @@ template <int DT, int NM, bool HASW, int NS, int NW = 4, int WNAT = 0, int AUX =
 __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams sp) {
     static_assert(!PK || (WNAT == 1 && NM > 0), "packed layout = natural order, with a sign operand");
     static_assert(!(XL || EPI) || (PK && NW == 4), "fused prologue / epilogue: packed layout, 256-thread blocks");
+    static_assert(!XL || NS % 2 == 0, "stage parity selects the activation fragment set");
     GemvParams p = sp.g;
     if constexpr (NM == 0) {       // blockIdx.y = tenant: its own activation rows, weight matrix and output rows
         p.X += (long long)blockIdx.y * sp.sXt;

@@ -103,7 +103,8 @@ class FusedDeltaLinear(nn.Module):
         return binary_linear(x, self.weight, self.mask, self.alpha, groups=self.groups, residual=residual)
 
     def forward_fused(self, x, norm_weight, eps, swiglu=False):
-        """RMSNorm(x; norm_weight) -> this Linear (-> SwiGLU) in ONE launch; x is the un-normalised residual stream (`fusable(x)`)."""
+        """[RMSNorm(x; norm_weight) ->] this Linear [-> SwiGLU] in ONE launch.  With norm_weight, x is the un-normalised residual stream
+        (`fusable(x)`); norm_weight=None keeps only the SwiGLU epilogue (x already normalised; needs `_decode_ok(x)`)."""
         if swiglu:
             return binary_linear_decode(x, self.weight, self.mask_packed, self.alpha_pair, layout="packed", groups=2,
                                         norm_weight=norm_weight, eps=eps, swiglu=True)
@@ -163,6 +164,12 @@ class TenantDecoder(nn.Module):
         self._graph = None
         self.fast_glue = True       # decode steps use the HIP glue kernels (serving_ops); False = stock torch ops everywhere
         self.fuse_glue = True       # ... and fold RMSNorm / SwiGLU into the Linear launches where the shapes allow (bit-identical)
+        # Which glue is folded where, by same-process A/B of the whole step (profiles/r02_decode_step.txt; ms per step, Mistral-7B x 6):
+        #   separate launches 5.475 | SwiGLU in gate|up's epilogue 5.197 | + RMSNorm in gate|up's prologue 5.202 | + RMSNorm in
+        #   q|k|v's prologue 5.340.  The epilogue is free; a norm prologue makes 256 blocks each re-read and re-normalise all rows
+        #   (~6 us in front of a 20 us q|k|v launch) to save a 4.4 us kernel -- a wash on the long launch, a loss on the short one.
+        self.fuse_qkv_norm = False      # RMSNorm folded into the q|k|v launch
+        self.fuse_gateup_norm = True    # RMSNorm folded into the gate|up launch (SwiGLU stays in its epilogue either way)
         # ... or run [o, gate|up, down, next layer's q|k|v] as ONE persistent launch per layer (bit-identical).  OFF by default: measured
         # 5.91 vs 5.33 ms per step -- a grid barrier plus the dependent reload behind it is a chain of 5-6 memory round trips (~8 us)
         # and the 4 stages of weights prefetched across it cover 4.4 us
@@ -245,7 +252,7 @@ class TenantDecoder(nn.Module):
         _, inter, _, heads, kvh, _ = self.cfg
         hd = self.hd
         fuse = S == 1 and self.fast_glue and self.fuse_glue and x.is_contiguous()
-        if fuse and layer.qkv.fusable(x):
+        if fuse and self.fuse_qkv_norm and layer.qkv.fusable(x):
             qkv = layer.qkv.forward_fused(x, layer.norm1, self.eps)              # RMSNorm in the Linear's prologue: one launch
         else:
             qkv = layer.qkv(self._norm(x, layer.norm1))
@@ -263,8 +270,10 @@ class TenantDecoder(nn.Module):
             a = F.scaled_dot_product_attention(q, ck, cv, attn_mask=attn_mask, enable_gqa=(kvh != heads))
             a = a.transpose(1, 2).reshape(T, S, heads * hd)
         x = layer.o(a, residual=x)
-        if fuse and layer.gate_up.fusable(x, swiglu=True):
+        if fuse and self.fuse_gateup_norm and layer.gate_up.fusable(x, swiglu=True):
             act = layer.gate_up.forward_fused(x, layer.norm2, self.eps, swiglu=True)   # RMSNorm -> gate|up -> SwiGLU: one launch
+        elif fuse and layer.gate_up.interleave8 and layer.gate_up._decode_ok(x):
+            act = layer.gate_up.forward_fused(self._norm(x, layer.norm2), None, self.eps, swiglu=True)   # gate|up -> SwiGLU: one launch
         else:
             gu = layer.gate_up(self._norm(x, layer.norm2))
             if S <= 16 and self.fast_glue and inter % 8 == 0:

@@ -97,7 +97,7 @@ int bd_binary_linear_decode(const void* X, const void* W, const int32_t* P, int 
 
 /* packed-layout decode Linear with the neighbouring glue of a decoder layer FUSED into the launch (bit-identical to the separate
  * launches; what disappears is a ~4 us kernel + a launch gap per fused op, on a step of a few hundred 15-65 us Linears):
- *   norm_w != NULL (required): X is the UN-NORMALISED residual stream; every block computes HF RMSNorm
+ *   norm_w != NULL (optional when epilogue = 1): X is the UN-NORMALISED residual stream; every block computes HF RMSNorm
  *     norm_w[b] * round(X[b,m] * rsqrt(mean(X[b,m]^2) + eps))  for the B*M rows itself while its first weight stages are in flight and
  *     reads its activations from LDS (bd_srv_rmsnorm's arithmetic, same order).  norm_w [B or 1, K], stride s_norm elements.
  *     Needs M == 1 (one new token per tenant), K a power of two >= 2048, B*K <= 32768 and B*(2K+16) bytes of LDS next to the

@@ -399,6 +399,8 @@ def test_fused_swiglu_epilogue_is_bit_identical_to_separate_launches(bd, dtype, 
     assert torch.equal(sep, ops.swiglu(gu_plain, inter))
     fused = il.forward_fused(x, nw, 1e-5, swiglu=True)
     assert fused.shape == (T, 1, inter) and torch.equal(fused, sep)
+    epi_only = il.forward_fused(h, None, 1e-5, swiglu=True)                          # SwiGLU epilogue without the norm prologue
+    assert torch.equal(epi_only, sep)
     t_ref = torch.nn.functional.silu(gu_plain[..., :inter]) * gu_plain[..., inter:]
     assert (fused.float() - t_ref.float()).abs().max().item() <= 0.01 * t_ref.float().abs().max().item() + 1e-3
 
@@ -412,10 +414,14 @@ def test_serving_loop_fused_glue_matches_separate_launches(bd):
     g = torch.Generator().manual_seed(3)
     prompts = [torch.randint(1, 512, (n,), generator=g).tolist() for n in (12, 64, 40)]
     outs = {}
+    dec.fuse_qkv_norm = dec.fuse_gateup_norm = True                       # every fusion on (the shipped default leaves q|k|v's norm separate)
     for fuse in (True, False):
         dec.fuse_glue = fuse
         for graph in (True, False):
             outs[(fuse, graph)], _ = dec.generate(prompts, max_new_tokens=6, use_graph=graph)
+    dec.fuse_glue, dec.fuse_qkv_norm, dec.fuse_gateup_norm = True, False, False      # SwiGLU epilogue only
+    outs[("epi", True)], _ = dec.generate(prompts, max_new_tokens=6, use_graph=True)
+    dec.fuse_qkv_norm = dec.fuse_gateup_norm = True
     ref = outs[(False, False)]
     for k, v in outs.items():
         assert torch.equal(v, ref), k
