@@ -245,6 +245,20 @@ def run_mt_decode(dev, timer, model_name, tenants, kv_len, steps, warmup, layers
                 run()
                 ab[name].append(bdd.timed_region(run, steps, device_sync=torch.cuda.synchronize) / steps * 1e3)
         dec.persistent, dec.fuse_glue, dec.fuse_qkv_norm, dec.fuse_gateup_norm = keep
+        # shipped defaults with the row-major base weight instead of its tile-major decode copy
+        from bitdelta_amd.serving_loop import FusedDeltaLinear
+        FusedDeltaLinear.use_tiled = False
+        restore()
+        run_rm = dec._graph_runner(st)
+        FusedDeltaLinear.use_tiled = True
+        restore()
+        run_tm = dec._graph_runner(st)
+        ab["row_major_w_ms"], ab["tile_major_w_ms"] = [], []
+        for _ in range(3):
+            for name, run in (("row_major_w_ms", run_rm), ("tile_major_w_ms", run_tm)):
+                restore()
+                run()
+                ab[name].append(bdd.timed_region(run, steps, device_sync=torch.cuda.synchronize) / steps * 1e3)
     lin_bytes, head_bytes = dec.linear_bytes_per_step()
     best_ms = graph_ms if graph_ms is not None else eager_s / steps * 1e3
     out = {

@@ -170,6 +170,17 @@ def tile_masks(mask):
     return mask.view(T, KW, Np // 16, 16).permute(0, 2, 1, 3).contiguous()
 
 
+def tile_weight(weight):
+    """Decode copy of a base weight [N, K] (N % 16 == 0, K % 128 == 0) in the streaming kernel's TILE-MAJOR order
+    [N/16][K/128][4 steps s][16 rows c][4 groups g][8]  with  W'[tile][it][s][c][g][e] = W[16 tile + c][128 it + 32 s + 8 g + e]:
+    one (16-column tile, 128-k iteration) stage is ONE contiguous 4-KiB block read as four 1-KiB runs, and a wave's consecutive
+    stages are consecutive blocks (row-major: 16 rows 2K bytes apart per load instruction).  Same values, same arithmetic; returned
+    with shape [N, K] (a flat reinterpretation) so it can stand in for `weight` in binary_linear_decode(..., weight_tiled=True)."""
+    N, K = weight.shape
+    assert N % 16 == 0 and K % 128 == 0 and weight.stride(1) == 1
+    return weight.reshape(N // 16, 16, K // 128, 4, 4, 8).permute(0, 2, 3, 1, 4, 5).contiguous().view(N, K)
+
+
 def pack_decode_masks(mask):
     """Repack packed sign words [T, K/32, N] (reference / diff.pt layout) into the PACKED layout of the streaming decode kernel:
     int32 [ceil(N/16), ceil(K/128), 4, 16, t_pad] with element [tile][it][g][c][t] = tenant t's dword whose byte s holds the 8 signs
@@ -205,12 +216,13 @@ def fused_norm_ok(B, M, K):
 
 
 def binary_linear_decode(x, weight, mask, alpha, *, layout="tile", out_dtype=None, groups=1, residual=None,
-                         norm_weight=None, eps=1e-5, swiglu=False):
+                         norm_weight=None, eps=1e-5, swiglu=False, weight_tiled=False):
     """binary_linear for decode shapes with repacked masks: one launch of the streaming kernel.
     x: (B, M, K), M <= 16; weight (N, K); alpha fp32 (B or 1, groups);
     layout "tile":   mask = tile_masks(...)        (B or 1, ceil(N/16), K/32, 16)
     layout "packed": mask = pack_decode_masks(...) (ceil(N/16), ceil(K/128), 4, 16, t_pad), B <= t_pad tenants, B*M <= 16.
     Packed layout only: norm_weight (B or 1, K) fuses the HF RMSNorm of x (x = the un-normalised residual stream) into the launch;
+    weight_tiled=True: `weight` is tile_weight(W) (M == 1, N % 16 == 0, K % 128 == 0);
     swiglu=True (with or without norm_weight) treats weight/mask as a gate|up pair interleaved in blocks of 8 output rows, alpha (B or 1, 2) =
     (gate, up) scales, and returns act_fn(gate) * up, (B, M, N/2).  Both bit-identical to the separate launches."""
     require_gpu(x, weight, mask, alpha, residual, norm_weight)
@@ -228,6 +240,10 @@ def binary_linear_decode(x, weight, mask, alpha, *, layout="tile", out_dtype=Non
         sPb = 1
     assert weight.shape[1] == K and weight.stride(1) == 1 and weight.dtype == x.dtype and x.stride(2) == 1
     out_dtype = out_dtype or x.dtype
+    ldw = weight.stride(0)
+    if weight_tiled:
+        assert layout == "packed" and M == 1 and N % 16 == 0 and K % 128 == 0 and weight.is_contiguous()
+        ldw = 0                                     # the C ABI's marker for the tile-major decode copy
     alpha = alpha.detach()
     if alpha.dtype != torch.float32 or not alpha.is_contiguous():
         alpha = alpha.float().contiguous()
@@ -251,14 +267,14 @@ def binary_linear_decode(x, weight, mask, alpha, *, layout="tile", out_dtype=Non
     if norm_weight is not None or swiglu:
         with torch.cuda.device(x.device):
             check(lib().bd_binary_linear_decode_fused(ptr(x), ptr(weight), ptr(mask), t_pad, ptr(alpha), ptr(y), B, M, N, K,
-                                                      x.stride(0), x.stride(1), weight.stride(0), sPb, sAlb, groups, y.stride(0),
+                                                      x.stride(0), x.stride(1), ldw, sPb, sAlb, groups, y.stride(0),
                                                       y.stride(1), DTYPE_CODE[x.dtype], DTYPE_CODE[out_dtype],
                                                       1 if residual is not None else 0, ptr(norm_weight), s_norm, float(eps),
                                                       1 if swiglu else 0, stream_ptr()), "binary_linear_decode_fused")
         return y
     with torch.cuda.device(x.device):
         check(lib().bd_binary_linear_decode(ptr(x), ptr(weight), ptr(mask), code, t_pad, ptr(alpha), ptr(y), B, M, N, K,
-                                            x.stride(0), x.stride(1), weight.stride(0), sPb, sAlb, groups, y.stride(0),
+                                            x.stride(0), x.stride(1), ldw, sPb, sAlb, groups, y.stride(0),
                                             y.stride(1), DTYPE_CODE[x.dtype], DTYPE_CODE[out_dtype],
                                             1 if residual is not None else 0, stream_ptr()), "binary_linear_decode")
     return y

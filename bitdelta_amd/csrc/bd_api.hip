@@ -122,6 +122,7 @@ struct Problem {
     int G, dtype, out_dtype, round_mode, accumulate;
     int mask_tiled;           // 0: P is [B or 1, K/32, N] (reference layout); 1: tile-major [B or 1, ceil(N/16), K/32, 16];
                               // 2: packed decode layout [ceil(N/16), ceil(K/128), 4, 16, t_pad] (decode kernel only, see bd_gemv_stream.h)
+    int w_tiled;              // layout 2 only: W is the tile-major decode copy [N/16][K/128][4 steps][16 rows][4 groups][8] (ldw passed as 0)
     int t_pad;                // layout 2: dwords per (tile, iteration, lane group, column) = tenants padded to 1 / 2 / 4 / 6 / 8
     const void* norm_w;       // layout 2 only: fused RMSNorm prologue (A is the un-normalised residual stream); [B or 1, K], stride sNw
     int64_t sNw;
@@ -318,9 +319,9 @@ inline bool stream_ok(const Problem& q, int rows, int nmask) {
 }
 
 constexpr int STREAM_LDS_MAX = 160 * 1024;        // LDS of a gfx950 CU: the fused-norm kernels add R activation rows to STREAM_LDS_BYTES
-template <int DT, int NM, bool HASW, int NS, int NW = 8, int WNAT = 0, int AUX = 2, int PK = 0, int XL = 0, int EPI = 0>
+template <int DT, int NM, bool HASW, int NS, int NW = 8, int WNAT = 0, int AUX = 2, int PK = 0, int XL = 0, int EPI = 0, int WT = 0>
 int launch_stream_inst(const StreamParams& sp, dim3 grid, hipStream_t st) {
-    auto kern = gemv_stream_kernel<DT, NM, HASW, NS, NW, WNAT, AUX, PK, XL, EPI>;
+    auto kern = gemv_stream_kernel<DT, NM, HASW, NS, NW, WNAT, AUX, PK, XL, EPI, WT>;
     static std::atomic<uint64_t> lds_done{0};
     const int lds = XL ? std::max((int)(sp.xs_off + (uint32_t)sp.g.R * sp.xrow), STREAM_LDS_BYTES) : STREAM_LDS_BYTES;
     if (lds > STREAM_LDS_MAX) return BD_E_BAD_SHAPE;
@@ -388,11 +389,20 @@ int launch_gemv_stream_chunk(const Problem& q) {
     const unsigned grid = (unsigned)((q.N + cpb - 1) / cpb);
     sp.x_bytes = (uint32_t)(((int64_t)(q.B - 1) * q.sAb + (int64_t)(q.M - 1) * q.sAm + q.K) * 2);
     sp.w_bytes = q.W ? (uint32_t)(((int64_t)(q.N - 1) * q.ldw + q.K) * 2) : 0u;
+    if (q.w_tiled)       // tile-major W: [N/16][K/128] blocks of 4 KiB
+        sp.w_bytes = (uint32_t)((int64_t)((q.N + 15) / 16) * ((q.K + 127) / 128) * 4096);
     sp.p_bytes = (uint32_t)(((int64_t)(nmask - 1) * q.sPb + (int64_t)(q.K / 32) * (q.mask_tiled ? (q.N + 15) / 16 * 16 : q.N)) * 4);
     int rc;
     if (q.mask_tiled == 2) {      // packed layout: all tenants of the call in one chunk, interleaved; extent from the pack's own geometry
         sp.p_bytes = (uint32_t)((int64_t)((q.N + 15) / 16) * ((q.K + 127) / 128) * 4 * 16 * q.t_pad * 4);
-#define BD_PK(NM, NS4) rc = q.norm_w ? (q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1, 1, 1>(sp, dim3(grid), q.st)   \
+        // kernel kinds: plain | RMSNorm prologue (XL) | XL + SwiGLU epilogue | SwiGLU epilogue only; tile-major W (WT) for the three
+        // the serving loop uses (a norm prologue without SwiGLU on tile-major W answers BD_E_BAD_SHAPE)
+#define BD_PK(NM, NS4) rc = q.w_tiled                                                                                                   \
+                     ? (q.norm_w ? (q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1, 1, 1, 1>(sp, dim3(grid), q.st)    \
+                                                    : BD_E_BAD_SHAPE)                                                                 \
+                                 : q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1, 0, 1, 1>(sp, dim3(grid), q.st)    \
+                                                   : launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1, 0, 0, 1>(sp, dim3(grid), q.st))   \
+                     : q.norm_w ? (q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1, 1, 1>(sp, dim3(grid), q.st)   \
                                                         : launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1, 1, 0>(sp, dim3(grid), q.st))  \
                      : q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1, 0, 1>(sp, dim3(grid), q.st)            \
                      : q.W ? launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1>(sp, dim3(grid), q.st)                              \
@@ -835,6 +845,12 @@ static int binary_linear_impl(const void* X, const void* W, const int32_t* P, co
     q.sAb = sXb; q.sAm = sXm; q.sPb = sPb; q.sCb = sYb; q.sCm = sYm; q.ldw = ldw; q.sAlb = sAlb;
     q.G = G; q.dtype = dtype; q.out_dtype = out_dtype; q.round_mode = 0; q.accumulate = accumulate ? 1 : 0;
     q.mask_tiled = mask_tiled; q.t_pad = t_pad;
+    q.w_tiled = 0;
+    if (ldw == 0 && W) {      // tile-major base weight (the decode copy made by the serving side): packed sign layout only, whole blocks
+        if (mask_tiled != 2 || N % 16 || K % 128 || M != 1) return BD_E_BAD_SHAPE;
+        q.w_tiled = 1;
+        q.ldw = K;            // (extent checks below; the kernel does not use it)
+    }
     q.norm_w = norm_w; q.sNw = sNw; q.eps = eps; q.epilogue = epilogue;
     if (norm_w || epilogue) {
         // fused prologue / epilogue of the packed streaming kernel: see gemv_stream_kernel (XL, EPI)

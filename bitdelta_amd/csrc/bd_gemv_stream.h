@@ -113,8 +113,12 @@ struct StreamParams {
 //   ([g0..7 | u0..7 | g8..15 | ...]): a 16-column tile holds 8 gate and the 8 matching up columns, the reducing wave rounds both to
 //   16 bits (what the separate Linear would have stored), and stores round16(silu(g)) * u -- N/2 output columns.  Scale group of
 //   a column = gate (0) or up (1).  Bit-identical to "Linear launch, then swiglu launch".
-template <int DT, int NM, bool HASW, int NS, int NW = 4, int WNAT = 0, int AUX = 0, int PK = 0, int XL = 0, int EPI = 0>
+// WT = 1 (packed layout): the base weight is TILE-MAJOR too -- W'[n/16][k/128][s][n%16][g][8] with k = 128 it + 32 s + 8 g + e (the
+//   serving side repacks it once, binary_gemm_kernel.tile_weight): the four load instructions of a stage read four consecutive
+//   1-KiB runs of ONE contiguous 4-KiB block, and a wave's consecutive stages consecutive blocks, instead of 16 rows 2K bytes apart.
+template <int DT, int NM, bool HASW, int NS, int NW = 4, int WNAT = 0, int AUX = 0, int PK = 0, int XL = 0, int EPI = 0, int WT = 0>
 __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams sp) {
+    static_assert(!WT || (PK && HASW), "tile-major W: packed layout");
     static_assert(!PK || (WNAT == 1 && NM > 0), "packed layout = natural order, with a sign operand");
     static_assert(!(XL || EPI) || (PK && NW == 4), "fused prologue / epilogue: packed layout, 256-thread blocks");
     static_assert(!XL || NS % 2 == 0, "stage parity selects the activation fragment set");
@@ -203,7 +207,12 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
             for (int s = 0; s < 4; ++s) {
                 const bool ok = it_ok && (k0 + 32 * s < p.K);
                 if constexpr (!XL) st.xn[s] = buf_load16<0>(rx, ok ? x_off + (uint32_t)(k0 + 32 * s) * 2u : STREAM_OOB);
-                if constexpr (HASW)
+                if constexpr (HASW && WT)
+                    st.wf[s] = buf_load16<AUX>(rw, (it_ok && it < nit && col_ok)
+                                                       ? ((uint32_t)(n >> 4) * (uint32_t)nit + (uint32_t)it) * 4096u + (uint32_t)s * 1024u +
+                                                             (uint32_t)(n & 15) * 64u + (uint32_t)g * 16u
+                                                       : STREAM_OOB);
+                else if constexpr (HASW)
                     st.wf[s] = buf_load16<AUX>(rw, (ok && col_ok) ? (uint32_t)n * (uint32_t)p.ldw * 2u + (uint32_t)(k0 + 32 * s) * 2u : STREAM_OOB);
             }
         } else if constexpr (HASW) {

@@ -24,7 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .binary_gemm_kernel import (binary_linear, binary_linear_decode, decode_chain, decode_shape_ok, fused_norm_ok,
-                                 pack_decode_masks, tenant_linear)
+                                 pack_decode_masks, tenant_linear, tile_weight)
 from .diff import binarize
 from . import serving_ops as ops
 
@@ -56,6 +56,8 @@ class FusedDeltaLinear(nn.Module):
     ([g0..7 | u0..7 | g8..15 | u8..15 | ...]) so that a 16-column tile of the decode kernel holds 8 gate columns and the 8 matching
     up columns and SwiGLU can run in its epilogue.  `split()` undoes the order for callers that want the separate outputs."""
 
+    tile_decode_weight = True     # keep a tile-major decode copy of the base weight (class switch; see DESIGN.md 3)
+
     def __init__(self, weights, masks, coeffs, interleave8=False):
         super().__init__()
         widths = [w.shape[0] for w in weights]
@@ -84,6 +86,10 @@ class FusedDeltaLinear(nn.Module):
         # decode copy of the sign words in the streaming kernel's packed order (tenants interleaved, natural k order); prefill keeps
         # the reference layout
         self.register_buffer("mask_packed", pack_decode_masks(self.mask) if self.mask.shape[0] <= 8 else None)
+        # ... and of the base weight in the kernel's tile-major order (one contiguous 4-KiB block per stage; +2 bytes per weight of HBM)
+        N, K = self.weight.shape
+        tiled = self.mask_packed is not None and self.tile_decode_weight and N % 16 == 0 and K % 128 == 0
+        self.register_buffer("weight_tiled", tile_weight(self.weight) if tiled else None)
 
     def _decode_ok(self, x):
         B, M, K = x.shape
@@ -96,18 +102,28 @@ class FusedDeltaLinear(nn.Module):
         B, M, K = x.shape
         return self._decode_ok(x) and fused_norm_ok(B, M, K) and (not swiglu or self.interleave8)
 
+    def _dec_weight(self, x):
+        """(weight, weight_tiled flag) for a decode launch: the tile-major copy when it exists and the launch has one row per tenant"""
+        if self.weight_tiled is not None and self.use_tiled and x.shape[1] == 1:
+            return self.weight_tiled, True
+        return self.weight, False
+
+    use_tiled = True              # (A/B switch)
+
     def forward(self, x, residual=None):
         if self._decode_ok(x):
-            return binary_linear_decode(x, self.weight, self.mask_packed, self.alpha, layout="packed", groups=self.groups,
-                                        residual=residual)
+            w, wt = self._dec_weight(x)
+            return binary_linear_decode(x, w, self.mask_packed, self.alpha, layout="packed", groups=self.groups,
+                                        residual=residual, weight_tiled=wt)
         return binary_linear(x, self.weight, self.mask, self.alpha, groups=self.groups, residual=residual)
 
     def forward_fused(self, x, norm_weight, eps, swiglu=False):
         """[RMSNorm(x; norm_weight) ->] this Linear [-> SwiGLU] in ONE launch.  With norm_weight, x is the un-normalised residual stream
         (`fusable(x)`); norm_weight=None keeps only the SwiGLU epilogue (x already normalised; needs `_decode_ok(x)`)."""
         if swiglu:
-            return binary_linear_decode(x, self.weight, self.mask_packed, self.alpha_pair, layout="packed", groups=2,
-                                        norm_weight=norm_weight, eps=eps, swiglu=True)
+            w, wt = self._dec_weight(x)
+            return binary_linear_decode(x, w, self.mask_packed, self.alpha_pair, layout="packed", groups=2,
+                                        norm_weight=norm_weight, eps=eps, swiglu=True, weight_tiled=wt)
         return binary_linear_decode(x, self.weight, self.mask_packed, self.alpha, layout="packed", groups=self.groups,
                                     norm_weight=norm_weight, eps=eps)
 
@@ -164,12 +180,12 @@ class TenantDecoder(nn.Module):
         self._graph = None
         self.fast_glue = True       # decode steps use the HIP glue kernels (serving_ops); False = stock torch ops everywhere
         self.fuse_glue = True       # ... and fold RMSNorm / SwiGLU into the Linear launches where the shapes allow (bit-identical)
-        # Which glue is folded where, by same-process A/B of the whole step (profiles/r02_decode_step.txt; ms per step, Mistral-7B x 6):
-        #   separate launches 5.475 | SwiGLU in gate|up's epilogue 5.197 | + RMSNorm in gate|up's prologue 5.202 | + RMSNorm in
-        #   q|k|v's prologue 5.340.  The epilogue is free; a norm prologue makes 256 blocks each re-read and re-normalise all rows
-        #   (~6 us in front of a 20 us q|k|v launch) to save a 4.4 us kernel -- a wash on the long launch, a loss on the short one.
+        # Which glue is folded where, by same-process A/B of the whole step (profiles/r02_decode_step.txt; ms per step, Mistral-7B x 6,
+        # tile-major weights): separate launches 5.35 | SwiGLU in gate|up's epilogue 5.11 | + RMSNorm in gate|up's prologue 5.17 |
+        # + RMSNorm in q|k|v's prologue 5.28.  The epilogue is free; a norm prologue makes 256 blocks each re-read and re-normalise
+        # all rows (~6 us in front of the launch) to save a 4.4 us kernel -- at best a wash on the long launch, a loss on the short one.
         self.fuse_qkv_norm = False      # RMSNorm folded into the q|k|v launch
-        self.fuse_gateup_norm = True    # RMSNorm folded into the gate|up launch (SwiGLU stays in its epilogue either way)
+        self.fuse_gateup_norm = False   # RMSNorm folded into the gate|up launch (SwiGLU stays in its epilogue either way)
         # ... or run [o, gate|up, down, next layer's q|k|v] as ONE persistent launch per layer (bit-identical).  OFF by default: measured
         # 5.91 vs 5.33 ms per step -- a grid barrier plus the dependent reload behind it is a chain of 5-6 memory round trips (~8 us)
         # and the 4 stages of weights prefetched across it cover 4.4 us

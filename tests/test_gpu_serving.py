@@ -528,3 +528,31 @@ def test_serving_loop_single_tenant(bd):
     a, n1 = dec.generate(prompts, max_new_tokens=6, use_graph=True)
     b, n2 = dec.generate(prompts, max_new_tokens=6, use_graph=False)
     assert n1 == n2 == 6 and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("T,K,N", [(6, 4096, 6144), (1, 4096, 4096), (2, 1024, 1024), (4, 14336, 4096), (8, 2048, 512), (3, 128, 528)])
+def test_tile_major_weight_is_bit_identical(bd, dtype, T, K, N):
+    """the tile-major decode copy of the base weight (ldw = 0 at the C ABI) gives the same bits as the row-major operand: plain,
+    with the residual epilogue, with the SwiGLU epilogue and with RMSNorm + SwiGLU"""
+    from bitdelta_amd import serving_ops as ops
+    from bitdelta_amd.binary_gemm_kernel import binary_linear_decode, fused_norm_ok, pack_decode_masks, tile_weight
+    g = torch.Generator(device="cuda").manual_seed(K + N + T)
+    x = (torch.randn(T, 1, K, device="cuda", generator=g) * 1.5).to(dtype)
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.02).to(dtype)
+    mask = torch.randint(-2**31, 2**31 - 1, (T, K // 32, N), device="cuda", generator=g, dtype=torch.int64).to(torch.int32)
+    alpha = torch.rand(T, 2, device="cuda", generator=g) * 1e-3
+    pk, wt = pack_decode_masks(mask), tile_weight(w)
+    assert not torch.equal(wt, w)
+    a1 = alpha[:, :1].contiguous()
+    assert torch.equal(binary_linear_decode(x, wt, pk, a1, layout="packed", weight_tiled=True),
+                       binary_linear_decode(x, w, pk, a1, layout="packed"))
+    res = torch.randn(T, 1, N, device="cuda", generator=g).to(dtype)
+    assert torch.equal(binary_linear_decode(x, wt, pk, a1, layout="packed", weight_tiled=True, residual=res.clone()),
+                       binary_linear_decode(x, w, pk, a1, layout="packed", residual=res.clone()))
+    assert torch.equal(binary_linear_decode(x, wt, pk, alpha, layout="packed", groups=2, swiglu=True, weight_tiled=True),
+                       binary_linear_decode(x, w, pk, alpha, layout="packed", groups=2, swiglu=True))
+    if fused_norm_ok(T, 1, K):
+        nw = (1 + 0.1 * torch.randn(T, K, device="cuda", generator=g)).to(dtype)
+        assert torch.equal(binary_linear_decode(x, wt, pk, alpha, layout="packed", groups=2, swiglu=True, norm_weight=nw, weight_tiled=True),
+                           binary_linear_decode(x, w, pk, alpha, layout="packed", groups=2, swiglu=True, norm_weight=nw))

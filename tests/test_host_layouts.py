@@ -4,7 +4,7 @@ bitdelta/binary_gemm_kernel.py:109-111), through the oracle's unpack."""
 import pytest
 import torch
 
-from bitdelta_amd.binary_gemm_kernel import pack_decode_masks, tile_masks
+from bitdelta_amd.binary_gemm_kernel import pack_decode_masks, tile_masks, tile_weight
 from bitdelta_amd.serving_loop import FusedDeltaLinear, padded_length
 
 
@@ -84,3 +84,20 @@ def test_fused_delta_linear_interleave_is_a_row_permutation():
 def test_padded_length_rule():
     """demo/demo_backend.py:297-299: next power of two, at least 64"""
     assert [padded_length(n) for n in (1, 63, 64, 65, 128, 129, 1000, 1024)] == [64, 64, 64, 128, 128, 256, 1024, 1024]
+
+
+@pytest.mark.parametrize("N,K", [(16, 128), (48, 384), (32, 1024)])
+def test_tile_major_weight_layout(N, K):
+    """W'[tile][it][s][c][g][e] = W[16 tile + c][128 it + 32 s + 8 g + e]; a pure permutation, returned flat as [N, K]"""
+    w = torch.arange(N * K, dtype=torch.float32).reshape(N, K).half()            # distinct small integers are exact in fp16 up to 2048 ...
+    w = (torch.arange(N * K) % 2039).float().reshape(N, K).half()                 # ... so use residues: still a strong permutation check
+    t = tile_weight(w)
+    assert t.shape == (N, K) and t.is_contiguous()
+    v = t.view(N // 16, K // 128, 4, 16, 4, 8)
+    for tile in range(N // 16):
+        for it in range(K // 128):
+            for s_ in range(4):
+                for g in range(4):
+                    k0 = 128 * it + 32 * s_ + 8 * g
+                    assert torch.equal(v[tile, it, s_, :, g, :], w[16 * tile:16 * tile + 16, k0:k0 + 8])
+    assert torch.equal(torch.sort(t.flatten())[0], torch.sort(w.flatten())[0])
