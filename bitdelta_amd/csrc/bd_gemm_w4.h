@@ -1,0 +1,557 @@
+// W1A16 binary-delta GEMM / fused binary-delta Linear, FOUR-WAVE PERSISTENT schedule (one wave per SIMD, whole 512-register file).
+//
+//   delta-only :  C[b] = X[b] . S[b]                               (binary_bmm, reference bitdelta/binary_gemm_kernel.py:186-335)
+//   fused      :  C[b] = X[b] . W^T + alpha[b] * (X[b] . S[b])     (BinaryDiff.forward, bitdelta/diff.py:33-39)
+//
+// Why another schedule (bd_gemm_pf.h / bd_gemm_fx.h are 8-wave ping-pong): their counters say MFMA-busy 62..69 %, two barrier
+// hand-offs of ~220 idle cycles per k-tile, 21 ds_read_b128 per 32 MFMAs per wave.  Here a workgroup is 4 waves, each alone on its
+// SIMD with a 128 x 128 (delta) or 128 x 64 x {W, S} (fused) wave tile = 16 accumulators = 256 AGPRs:
+//   * MFMAs are issued back to back by ONE in-order stream per SIMD; everything else (X-fragment ds_reads, sign expansion,
+//     LDS-DMA issue) is placed in the <= 5 issue slots each v_mfma_f32_32x32x16 leaves free (MI355X_MICROARCH.md, "one wave per
+//     SIMD" row).  A k-tile (64 k) is 16 REGIONS of 4 MFMAs (one B-operand fragment x 4 X fragments); region g
+//         - multiplies B fragment f = g (k-step s = g/4, fragment b = g%4),
+//         - PRODUCES B fragment f+3 (sign expansion by VALU or by LUT read; W fragment ds_read in fused mode),
+//         - reads its share of the NEXT k-step's X fragments (regions b = 0, 1 read two each),
+//         - issues its share of the LDS-DMA pieces of k-tile kt+2 (regions 0..11).
+//   * half the LDS reads per MFMA of the 8-wave tile (16 X reads per 64 MFMAs), ONE s_barrier per k-tile (at region 12, where
+//     the read stream crosses into the next ring slot), no partner group.
+//   * PERSISTENT: grid = min(tiles, CUs); the (tile, k-tile) pairs of a workgroup form one flat stream, the DMA runs two k-tiles
+//     ahead ACROSS tile boundaries, and the epilogue has its own LDS staging area, so the C store of tile t overlaps the first
+//     k-tiles of tile t+1 (the 8-wave kernels pay ~11 us of un-overlapped C store + ~4 us of prologue per launch at 4096^3).
+// Operand layout, k permutation, LDS image / swizzle: identical to bd_gemm_mfma.h (see its header); the MFMA operand order is the
+// natural one here (X fragment first -- see w4_epilogue), so the accumulator holds D[m][n] with lane <-> n.
+//
+// Ring (NS = 3 slots): k-tile c lives in slot c % 3.  Reads of k-tile c happen between barrier B(c-1) and B(c) (B(c) sits at
+// region 12 of k-tile c; regions 12..15 already read k-tile c+1's first fragments).  The refill of slot c % 3 with k-tile c+3 is
+// issued in regions 0..11 of k-tile c+1, i.e. after B(c), which every wave passes only after lgkmcnt(0) on its reads of k-tile c.
+// The only B fragment produced AFTER B(c) from k-tile c is fragment 15 (region 12): it must not read the slot, so it is always a sign
+// fragment made by VALU (or read from the LUT area) -- hence the fused fragment order W0 S0 W1 S1.
+// k-tile c+1's pieces were issued during k-tile c-1; each wave waits vmcnt(DPW) (only k-tile c+2's pieces may remain in flight)
+// before B(c).
+#pragma once
+#include "bd_gemm_mfma.h"
+
+namespace bd {
+
+template <int V> struct IC { static constexpr int value = V; };
+// compile-time loop: the body sees its index as a constant (register arrays must never be indexed by a runtime value)
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(IC<I>{}); static_for<I + 1, N>(f); }
+}
+
+template <int DT_, int BM_, int BN_, bool FUSED_, bool OUT_F32_, int OPT_ = 0>
+struct W4Cfg {
+    static constexpr int DT = DT_, BM = BM_, BN = BN_, NS = 3, OPT = OPT_;
+    static constexpr bool FUSED = FUSED_, OUT_F32 = OUT_F32_;
+    static constexpr int WAVES_M = 2, WAVES_N = 2, NW = 4, NT = 256;
+    static constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    static constexpr int NB = 4;                                   // B-operand fragments per k-step (delta: 4 S; fused: W0 S0 W1 S1)
+    static_assert(TM == 4 && (FUSED ? TN == 2 : TN == 4), "wave tile: 128 rows x 4 B fragments");
+    static constexpr int A_BYTES = BM * 128, W_BYTES = FUSED ? BN * 128 : 0, BW_BYTES = BN * 8;
+    static constexpr int BW_OFF = A_BYTES + W_BYTES;
+    static constexpr int STAGE = A_BYTES + W_BYTES + BW_BYTES;
+    static constexpr int A_PW = BM / 8 / NW, W_PW = FUSED ? BN / 8 / NW : 0, BW_PIECES = BN / 32, BW_PW = BW_PIECES / NW;
+    static_assert(BW_PIECES % NW == 0, "sign-word pieces vs waves");
+    static constexpr int DPW = A_PW + W_PW + BW_PW;                // LDS-DMA pieces per wave per k-tile
+    static constexpr bool USE_LUT = (OPT & 1) != 0;
+    static constexpr int LUT_OFF = NS * STAGE, LUT_BYTES = USE_LUT ? 4096 : 0;
+    static constexpr int STG_OFF = LUT_OFF + LUT_BYTES;
+    static constexpr int ESZ = OUT_F32 ? 4 : 2;
+    // epilogue staging: one 32-row block x JC 32-column blocks per wave at a time, rows padded by 16 B
+    static constexpr int stg_bytes(int jc) { return NW * 32 * (jc * 32 * ESZ + 16); }
+    static constexpr int JC = (STG_OFF + stg_bytes(TN) <= 160 * 1024) ? TN : (TN >= 2 && STG_OFF + stg_bytes(TN / 2) <= 160 * 1024) ? TN / 2 : 1;
+    static constexpr int STG_ROWB = JC * 32 * ESZ + 16, STG_PW = 32 * STG_ROWB;
+    static constexpr int LDS_BYTES = STG_OFF + NW * STG_PW;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert(DPW <= 24, "piece placement");
+};
+
+#ifdef BD_TRACE
+// s_memtime stamps of workgroup 0, wave 0 (harness builds only): [tile][0] loop entry, [1] after k-tile 7, [2] after k-tile 39,
+// [3] loop exit, [4] epilogue done; bd_trace_w4[15][0] = kernel entry, [15][1] = prologue done
+__device__ unsigned long long bd_trace_w4[16][8];
+#define BD_W4_STAMP(t, id)                                                                     \
+    do {                                                                                       \
+        if (blockIdx.x == 0 && wave == 0 && (t) < 15) {                                        \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                        \
+            if (lane == 0) bd_trace_w4[(t)][id] = t_;                                          \
+        }                                                                                      \
+    } while (0)
+#else
+#define BD_W4_STAMP(t, id) do { } while (0)
+#endif
+
+// LDS-DMA without the M0 save / restore of bd_common.h's dma16 (this kernel holds nothing in M0: gfx9+ ds_* and MFMA code
+// never needs it): 3 issue slots per piece instead of 5 -- in a one-wave-per-SIMD stream every slot beside an MFMA counts.
+template <int OFF> __device__ __forceinline__ void w4_dma16(uint32_t voff, const void* sbase, uint32_t lds_base) {
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_base), "n"(OFF) : "memory", "scc");
+}
+template <int OFF> __device__ __forceinline__ void w4_dma4(uint32_t voff, const void* sbase, uint32_t lds_base) {
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_base), "n"(OFF) : "memory", "scc");
+}
+
+// Epilogue of one output tile.  NATURAL MFMA operand order (first = X fragment, second = B fragment):
+//     acc[b][i][r] = D[m = m0 + wm*WM + 32i + (r&3) + 8(r>>2) + 4h][n = n0 + wn*WN + 32j + l31]
+// (delta: j = b; fused: accW = acc[2j], accS = acc[2j+1], out = accW + alpha[n] * accS in fp32 -- one rounding, as bd_gemm_fx.h).
+// The 8-wave kernels put the sign fragment FIRST (accumulator = D[n][m], 8-byte staging writes); measured here on sustained launches
+// (profiles/r03_w4_energy.txt) the same kernel with the +-1 fragment in the SECOND slot draws less power per MFMA and -- the chip
+// being power-limited at ~1.25 kW under either -- runs 8 % faster at a higher clock.  The price is 2-byte staging writes.
+// Each wave transposes through ITS OWN staging area (outside the DMA ring, so the next tile's k-tiles keep landing meanwhile).
+//   fast form (aligned C; plain, reference fp16 rounding, or fused + residual): one 32-row block x JC 32-column blocks at a time, values
+//   rounded to the output type before staging, whole row segments stored with 16-byte stores;
+//   general form (C += alpha * acc, unaligned / odd-sized C): 16 x 32 fp32 blocks staged, then a rolled loop of guarded scalar stores.
+// Value transforms are gemm_epilogue's (bd_gemm_mfma.h).
+template <class Cfg>
+__device__ __forceinline__ void w4_epilogue(const GemmParams& p, f32x16_t (&acc)[4][Cfg::TM], char* stg, int m0, int n0, int wm, int wn,
+                                            int b, int lane, int wave) {
+    constexpr int DT = Cfg::DT, WM = Cfg::WM, WN = Cfg::WN, TM = Cfg::TM, TN = Cfg::TN, JC = Cfg::JC, ESZ = Cfg::ESZ;
+    constexpr int ROWB = Cfg::STG_ROWB;
+    constexpr bool FUSED = Cfg::FUSED;
+    // Per-tile opaque copy of the lane id: everything lane-derived below is recomputed per tile.  Without it the compiler hoists ~40
+    // lane-constant row / column / address values out of the persistent tile loop, spills them around the k loop, and every reload's
+    // `s_waitcnt vmcnt(0)` serialises the output stores AND drains the LDS-DMA ring (cdna_hip_programming.md, 4-wave pitfalls).
+    asm volatile("" : "+v"(lane));
+    const int h = lane >> 5, l31 = lane & 31;
+    const long long c_b = (long long)b * p.sCb;
+    const bool acc_mode = !FUSED && p.accumulate;
+    const bool res_mode = FUSED && p.accumulate;
+    const bool rm16 = !FUSED && p.round_mode == 1;
+    const float* al = (FUSED || acc_mode) ? p.alpha + (long long)b * p.sAlb : nullptr;
+    float a_col[TN];                                     // this lane's column scale per column block
+#pragma unroll
+    for (int j = 0; j < TN; ++j) a_col[j] = al ? al[min(n0 + wn * WN + j * 32 + l31, p.N - 1) / p.gsz] : 0.f;
+    const bool fast = !acc_mode && (p.N % 8 == 0) && (p.sCm % 8 == 0) && (p.sCb % 8 == 0) && (((uintptr_t)p.C & 15) == 0);
+    char* buf = stg + wave * Cfg::STG_PW;
+    const bool inside = (m0 + Cfg::BM <= p.M) && (n0 + Cfg::BN <= p.N);      // wave-uniform: interior tiles store without guards
+
+    auto pack2 = [&](float lo, float hi) -> uint32_t {
+        if constexpr (DT == DT_BF16) {
+            uint32_t r;
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+            return r;
+        } else {
+            return f32_to_f16_bits(lo) | (f32_to_f16_bits(hi) << 16);
+        }
+    };
+    // Accumulator elements are fetched from the AGPR file one at a time, where they are used: left to itself the register allocator copies
+    // all 256 to VGPRs at the loop exit and spills ~50 of them (scratch traffic + vmcnt(0) stalls in front of the stores).
+    auto rd = [](float x) -> float {
+        float r;
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(x));
+        return r;
+    };
+    auto value = [&](auto ic, auto jc, auto rc) -> float {
+        constexpr int i = decltype(ic)::value, j = decltype(jc)::value, r = decltype(rc)::value;
+        if constexpr (FUSED) return __builtin_fmaf(a_col[j], rd(acc[2 * j + 1][i][r]), rd(acc[2 * j][i][r]));
+        else return rd(acc[j][i][r]);
+    };
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");    // MFMA result -> accvgpr_read distance for the last MFMAs of the k loop (asm is not padded)
+
+    if (fast) {
+        constexpr int SEG = JC * 32 * ESZ / 16;          // 16-byte pieces per staged row
+        constexpr int RPI = 64 / SEG;                    // rows per store instruction
+        static_for<0, TM*(TN / JC)>([&](auto cc) {
+            constexpr int i = decltype(cc)::value / (TN / JC), j0 = (decltype(cc)::value % (TN / JC)) * JC;
+            __builtin_amdgcn_sched_barrier(0);           // keeps the accumulator reads of later blocks from being hoisted (VGPR pressure)
+            char* wr = buf + (4 * h) * ROWB + l31 * ESZ;
+            static_for<0, JC * 8>([&](auto tc) {
+                constexpr int jj = decltype(tc)::value / 8, rp = (decltype(tc)::value % 8) * 2, j = j0 + jj;
+                if constexpr (rp == 0 || rp == 8) __builtin_amdgcn_sched_barrier(0);
+                float v0 = value(IC<i>{}, IC<j>{}, IC<rp>{}), v1 = value(IC<i>{}, IC<j>{}, IC<rp + 1>{});
+                if constexpr (!FUSED) { if (rm16) { v0 = round_through_f16(v0); v1 = round_through_f16(v1); } }
+                constexpr int row0 = (rp & 3) + 8 * (rp >> 2);                  // row of register rp within the 32-row block (h = 0); rp + 1 is the next row
+                char* d0 = wr + row0 * ROWB + jj * 32 * ESZ;
+                if constexpr (Cfg::OUT_F32) {
+                    *(float*)d0 = v0; *(float*)(d0 + ROWB) = v1;
+                } else {
+                    const uint32_t pk = pack2(v0, v1);
+                    *(unsigned short*)d0 = (unsigned short)pk;
+                    *(unsigned short*)(d0 + ROWB) = (unsigned short)(pk >> 16);
+                }
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's rows only: no block barrier needed
+            auto store_rows = [&](auto guardc) {
+                constexpr bool GUARD = decltype(guardc)::value != 0;
+#pragma unroll
+                for (int r0 = 0; r0 < 32; r0 += RPI) {
+                    const int rr = r0 + lane / SEG, sg = lane % SEG;
+                    const int mm = m0 + wm * WM + i * 32 + rr;
+                    const int n = n0 + wn * WN + j0 * 32 + sg * (16 / ESZ);
+                    u32x4_t val = *(const u32x4_t*)(buf + rr * ROWB + sg * 16);
+                    if (!GUARD || (mm < p.M && n < p.N)) {
+                        u32x4_t* dst = (u32x4_t*)(p.C + (c_b + (long long)mm * p.sCm + n) * ESZ);
+                        if (res_mode) {
+                            const u32x4_t rsd = *(const u32x4_t*)dst;
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) {
+                                if constexpr (Cfg::OUT_F32) {
+                                    val[d] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(float, val[d]) + __builtin_bit_cast(float, rsd[d]));
+                                } else {
+                                    const float lo = half_bits_to_f32<DT>(val[d] & 0xffffu) + half_bits_to_f32<DT>(rsd[d] & 0xffffu);
+                                    const float hi = half_bits_to_f32<DT>(val[d] >> 16) + half_bits_to_f32<DT>(rsd[d] >> 16);
+                                    val[d] = pack2(lo, hi);
+                                }
+                            }
+                        }
+                        __builtin_nontemporal_store(val, dst);
+                    }
+                }
+            };
+            if (inside) store_rows(IC<0>{}); else store_rows(IC<1>{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // staging rows are rewritten by the next block
+        });
+        return;
+    }
+    // ---- general form: 16 rows (register half qh = r >> 3) x 32 columns of fp32 at a time
+    constexpr int GROW = 32 * 4 + 16;
+    static_assert(16 * GROW <= Cfg::STG_PW, "general-form staging block");
+    static_for<0, TM * TN * 2>([&](auto ixc) {
+        constexpr int ix = decltype(ixc)::value, i = ix / (TN * 2), j = (ix / 2) % TN, qh = ix & 1;
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 8>([&](auto rc) {
+            constexpr int r = 8 * qh + decltype(rc)::value;
+            constexpr int row = (r & 3) + 8 * ((r >> 2) & 1);                    // within the 16-row half (h = 0)
+            *(float*)(buf + (row + 4 * h) * GROW + l31 * 4) = value(IC<i>{}, IC<j>{}, IC<r>{});
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma nounroll
+        for (int t = 0; t < 8; ++t) {
+            const int idx = t * 64 + lane, rr = idx >> 5, cc = idx & 31;
+            const int mm = m0 + wm * WM + i * 32 + 16 * qh + rr;
+            const int n = n0 + wn * WN + j * 32 + cc;
+            if (mm < p.M && n < p.N) {
+                float v = *(const float*)(buf + rr * GROW + cc * 4);
+                const long long off = c_b + (long long)mm * p.sCm + n;
+                if (acc_mode) {
+                    const float cin = Cfg::OUT_F32 ? ((const float*)p.C)[off] : half_bits_to_f32<DT>(((const unsigned short*)p.C)[off]);
+                    v = cin + al[n / p.gsz] * v;
+                } else if (rm16) {
+                    v = round_through_f16(v);
+                } else if (res_mode) {
+                    if constexpr (Cfg::OUT_F32) v = ((const float*)p.C)[off] + v;
+                    else v = half_bits_to_f32<DT>(((const unsigned short*)p.C)[off]) + half_bits_to_f32<DT>(f32_to_half_bits<DT>(v));
+                }
+                if constexpr (Cfg::OUT_F32) ((float*)p.C)[off] = v;
+                else ((unsigned short*)p.C)[off] = (unsigned short)f32_to_half_bits<DT>(v);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    });
+}
+
+template <class Cfg>
+__global__ void __launch_bounds__(256) delta_gemm_w4_kernel(const GemmParams p) {
+    constexpr int DT = Cfg::DT, BM = Cfg::BM, BN = Cfg::BN, NS = Cfg::NS;
+    constexpr int WM = Cfg::WM, WN = Cfg::WN, TM = Cfg::TM, TN = Cfg::TN;
+    constexpr int A_BYTES = Cfg::A_BYTES, STAGE = Cfg::STAGE, BW_OFF = Cfg::BW_OFF;
+    constexpr int A_PW = Cfg::A_PW, W_PW = Cfg::W_PW, BW_PW = Cfg::BW_PW, DPW = Cfg::DPW;
+    constexpr bool FUSED = Cfg::FUSED, USE_LUT = Cfg::USE_LUT;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, l31 = lane & 31;
+
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int G = (int)gridDim.x;
+    const int b = blockIdx.y;
+    const int nk = p.K >> 6;
+
+    uint32_t one2;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(one2) : "n"(One2<DT>::v));
+
+    // ---- tile walk of this persistent workgroup: round r covers tiles [r*G, r*G + Gr), XCD-remapped inside the round
+    auto tile_of = [&](int r, int& tm, int& tn) -> bool {
+        const int base = r * G;
+        const int Gr = min(G, ntiles - base);
+        if ((int)blockIdx.x >= Gr) return false;
+        tile_coords(p, base + xcd_remap(blockIdx.x, Gr), tm, tn);
+        return true;
+    };
+
+    // ---- fragment read offsets (tile independent)
+    const int swz = (l31 >> 1) & 7;
+    uint32_t a_rd[4], w_rd[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        a_rd[s] = (uint32_t)(wm * WM + l31) * 128u + (uint32_t)(((4 * h + s) ^ swz) * 16);
+        w_rd[s] = A_BYTES + (uint32_t)(wn * WN + l31) * 128u + (uint32_t)(((4 * h + s) ^ swz) * 16);
+    }
+    const uint32_t bw_rd = BW_OFF + h * BN * 4 + (wn * WN + l31) * 4;
+
+    // ---- loader state: the k-tile being fetched (two ahead of the one being multiplied), across tile boundaries.
+    //      Running wave-uniform source pointers (advanced by one k-tile per iteration), per-lane offsets fixed per tile.
+    int ld_r = 0, ld_kt = 0;
+    const char *ld_a = nullptr, *ld_w = nullptr, *ld_p = nullptr;
+    const long long p_step = (long long)p.N * 8;                          // 2 word rows per k-tile
+    uint32_t a_voff[A_PW], w_voff[W_PW > 0 ? W_PW : 1], bw_voff[BW_PW];
+    const uint32_t a_ldsw = lds0 + wave * A_PW * 1024;                    // this wave's pieces inside a ring slot
+    const uint32_t w_ldsw = lds0 + A_BYTES + wave * (W_PW > 0 ? W_PW : 1) * 1024;
+    uint32_t bw_ldsw[BW_PW];
+#pragma unroll
+    for (int i = 0; i < BW_PW; ++i) {
+        const int idx = wave * BW_PW + i;
+        bw_ldsw[i] = lds0 + BW_OFF + (idx / (BN / 64)) * BN * 4 + (idx % (BN / 64)) * 256;
+    }
+    auto loader_tile = [&](int r) {
+        int tm, tn;
+        if (!tile_of(r, tm, tn)) { if (!tile_of(r - 1 >= 0 ? r - 1 : 0, tm, tn)) { tm = 0; tn = 0; } }   // past the end: re-fetch (never read)
+        const int m0 = tm * BM, n0 = tn * BN;
+        ld_a = p.A + ((long long)b * p.sAb + (long long)m0 * p.sAm) * 2;
+        ld_p = (const char*)p.P + ((long long)b * p.sPb + n0) * 4;
+        if constexpr (FUSED) ld_w = p.W + (long long)n0 * p.ldw * 2;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                                        // recomputed per tile, not hoisted + spilled
+#pragma unroll
+        for (int i = 0; i < A_PW; ++i) {
+            const int rg = wave * A_PW + i;
+            const int r8 = rg * 8 + (ln >> 3);
+            const int c = (ln & 7) ^ ((r8 >> 1) & 7);
+            const int rr = min(m0 + r8, p.M - 1) - m0;
+            a_voff[i] = (uint32_t)rr * (uint32_t)p.sAm * 2u + (uint32_t)c * 16u;
+        }
+        if constexpr (FUSED) {
+#pragma unroll
+            for (int i = 0; i < W_PW; ++i) {
+                const int rg = wave * W_PW + i;
+                const int r8 = rg * 8 + (ln >> 3);
+                const int c = (ln & 7) ^ ((r8 >> 1) & 7);
+                const int rr = min(n0 + r8, p.N - 1) - n0;
+                w_voff[i] = (uint32_t)rr * (uint32_t)p.ldw * 2u + (uint32_t)c * 16u;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BW_PW; ++i) {
+            const int idx = wave * BW_PW + i;
+            const int hh = idx / (BN / 64), seg = idx % (BN / 64);
+            const int nn = min(n0 + seg * 64 + ln, p.N - 1) - n0;
+            bw_voff[i] = (uint32_t)hh * (uint32_t)p.N * 4u + (uint32_t)nn * 4u;
+        }
+    };
+    // piece pc of the loader's current k-tile into the ring slot at byte offset slot_off
+    auto dma_piece = [&](auto pcc, uint32_t slot_off) {
+        constexpr int pc = decltype(pcc)::value;
+        if constexpr (pc < A_PW) {
+            w4_dma16<pc * 1024>(a_voff[pc], ld_a, a_ldsw + slot_off);
+        } else if constexpr (pc < A_PW + W_PW) {
+            constexpr int i = pc - A_PW;
+            w4_dma16<i * 1024>(w_voff[i], ld_w, w_ldsw + slot_off);
+        } else {
+            constexpr int i = pc - A_PW - W_PW;
+            w4_dma4<0>(bw_voff[i], ld_p, bw_ldsw[i] + slot_off);
+        }
+    };
+    auto loader_advance = [&]() {
+        ld_a += 128; ld_p += p_step;
+        if constexpr (FUSED) ld_w += 128;
+        if (++ld_kt == nk) { ld_kt = 0; ++ld_r; loader_tile(ld_r); }
+    };
+
+    if constexpr (USE_LUT) {
+        constexpr uint32_t POS = One2<DT>::v & 0xffffu, NEG = POS | 0x8000u;
+        const int e = threadIdx.x;
+        u32x4_t v;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            v[d] = (((e >> (2 * d)) & 1) ? POS : NEG) | ((((e >> (2 * d + 1)) & 1) ? POS : NEG) << 16);
+        *(u32x4_t*)(smem + Cfg::LUT_OFF + e * 16) = v;
+    }
+
+    // ---- register state of the multiply stream
+    f32x16_t acc[4][TM];                       // [B fragment b][row block i]; fused: b = 2j (W) / 2j+1 (S)
+    u32x4_t xf[2][TM];                         // X fragments of k-step s (parity s & 1)
+    u32x4_t bf[4];                             // B fragments, produced 3 regions ahead
+    uint32_t sw_lo[TN], sw_hi[TN];             // prepared sign words of the k-tile whose fragments are being produced
+    uint32_t sw_raw[TN];
+
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[bb][i][r] = 0.f;
+    };
+
+    // produce B fragment (k-step sp, fragment bp) from ring slot `st` (byte pointer) -- sign expansion or W read
+    auto produce = [&](auto spc, auto bpc, const char* st) {
+        constexpr int sp = decltype(spc)::value, bp = decltype(bpc)::value;
+        if constexpr (FUSED && !(bp & 1)) {      // fused fragment order W0 S0 W1 S1: the step's LAST fragment is VALU-made (see ring note)
+            bf[bp] = *(const u32x4_t*)(st + w_rd[sp] + (bp >> 1) * 4096);
+        } else {
+            constexpr int j = FUSED ? (bp >> 1) : bp;
+            if constexpr (USE_LUT) {
+                const uint32_t byte = (sw_raw[j] >> (8 * sp)) & 0xffu;
+                bf[bp] = *(const u32x4_t*)(smem + Cfg::LUT_OFF + byte * 16);
+            } else {
+                const uint32_t src = sp < 2 ? sw_lo[j] : sw_hi[j];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int q = (sp & 1) * 4 + d;
+                    bf[bp][d] = ((src << (15 - 2 * q)) & 0x80008000u) | one2;
+                }
+                asm volatile("" : "+v"(bf[bp]));      // pin: the IR optimiser otherwise sinks the expansion towards its use (3 regions later)
+            }
+        }
+    };
+    uint32_t sw_new[TN];                       // raw words of the NEXT k-tile (read at region 12, committed at region 13)
+    auto read_words = [&](const char* st) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) sw_new[j] = *(const uint32_t*)(st + bw_rd + j * 128);
+    };
+    // prepared forms of word j: lo = {w[15:0], w[16:1]}, hi = {w[31:16], w[31:17]} of the inverted word, so that one shift puts bit 2q on
+    // bit 15 and bit 2q+1 on bit 31 (4 VALU per word: v_not, v_lshrrev, 2 x v_perm)
+    auto commit_word = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (USE_LUT) {
+            sw_raw[j] = sw_new[j];
+        } else {
+            const uint32_t w = ~sw_new[j], w1 = w >> 1;
+            sw_lo[j] = __builtin_amdgcn_perm(w1, w, 0x05040100u);     // bytes {w.0, w.1, w1.0, w1.1}
+            sw_hi[j] = __builtin_amdgcn_perm(w1, w, 0x07060302u);     // bytes {w.2, w.3, w1.2, w1.3}
+            asm volatile("" : "+v"(sw_lo[j]), "+v"(sw_hi[j]));
+        }
+    };
+
+    // One region (4 MFMAs).  g = 4 s + b.  MF = 0: prologue form (no MFMAs, no DMA).
+    auto region = [&](auto gc, auto mfc, const char* st_cur, const char* st_nxt, uint32_t slot_ld) {
+        constexpr int g = decltype(gc)::value, s = g >> 2, bb = g & 3;
+        constexpr bool MF = decltype(mfc)::value != 0;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (g == 12) {
+            wait_vmcnt<DPW>();                          // own pieces of k-tile c+1 have landed
+            __builtin_amdgcn_s_waitcnt(0xc07f);         // lgkmcnt(0): own reads of k-tile c are done (slot c is refilled after B(c))
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            read_words(st_nxt);
+        }
+        // X fragments of the next k-step: regions b = 0, 1 read two each
+        if constexpr (bb < 2) {
+            const char* st = (s == 3) ? st_nxt : st_cur;
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = 2 * bb + ii;
+                xf[(s + 1) & 1][i] = *(const u32x4_t*)(st + a_rd[(s + 1) & 3] + i * 4096);
+            }
+        }
+        // commit the next k-tile's words one per region: word j is first needed by fragment 16 + j (region 13 + j); the current
+        // k-tile's word j was last used by fragment 12 + j, produced at region 9 + j
+        if constexpr (g >= 13) { if constexpr (g - 13 < TN) commit_word(IC<(g - 13 < TN ? g - 13 : 0)>{}); }
+        if constexpr (g == 0 && TN == 4) commit_word(IC<TN - 1>{});
+        // B fragment f + 3 (f + 3 >= 16: first fragments of the next k-tile)
+        {
+            constexpr int f = g + 3;
+            if constexpr (f < 16) produce(IC<(f >> 2) & 3>{}, IC<f & 3>{}, st_cur);
+            else produce(IC<((f - 16) >> 2) & 3>{}, IC<(f - 16) & 3>{}, st_nxt);
+        }
+        if constexpr (MF) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                // OPT & 4 (energy A/B only, results transposed inside each 32 x 32 block): the 8-wave kernels' order, sign fragment first
+                if constexpr (Cfg::OPT & 4) acc[bb][i] = mfma32<DT>(bf[bb], xf[s & 1][i], acc[bb][i]);
+                else acc[bb][i] = mfma32<DT>(xf[s & 1][i], bf[bb], acc[bb][i]);
+            }
+            // interleave: 1 MFMA, then its share of the region's reads and VALU
+            // VALU per region: 8 (expansion) or 2 (LUT address) + 4 in the regions that commit a word; the MFMA in front of an LDS-DMA
+            // piece gets none (the piece is 3 issue slots)
+            constexpr int p0 = g < 12 ? g * DPW / 12 : 0, p1 = g < 12 ? (g + 1) * DPW / 12 : 0;
+            static_assert(p1 - p0 <= 2, "at most two pieces per region");
+            constexpr bool commits = !USE_LUT && (g >= 13 || (g == 0 && TN == 4));
+            constexpr bool s_type = !(FUSED && !(((g + 3) & 3) & 1));
+            constexpr int nvalu = (s_type ? (USE_LUT ? 2 : 8) : 0) + (commits ? 4 : 0) + 2;
+            constexpr int slots = p1 > p0 ? 3 : 4;
+            constexpr int vq = (nvalu + slots - 1) / slots;
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, vq, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, vq, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, vq, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if constexpr (slots == 4) __builtin_amdgcn_sched_group_barrier(0x002, vq, 0);
+            if constexpr (p1 > p0) {
+                __builtin_amdgcn_sched_barrier(0);
+                dma_piece(IC<p0>{}, slot_ld);
+                if constexpr (p1 - p0 > 1) dma_piece(IC<(p0 + 1 < DPW ? p0 + 1 : p0)>{}, slot_ld);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#define BD_W4_ALL_PIECES(slot)                                                                                            \
+    do {                                                                                                                  \
+        dma_piece(IC<0>{}, slot); dma_piece(IC<(1 < DPW ? 1 : 0)>{}, slot);                                               \
+        if constexpr (DPW > 2) dma_piece(IC<(2 < DPW ? 2 : 0)>{}, slot);                                                  \
+        if constexpr (DPW > 3) dma_piece(IC<(3 < DPW ? 3 : 0)>{}, slot);                                                  \
+        if constexpr (DPW > 4) dma_piece(IC<(4 < DPW ? 4 : 0)>{}, slot);                                                  \
+        if constexpr (DPW > 5) dma_piece(IC<(5 < DPW ? 5 : 0)>{}, slot);                                                  \
+        if constexpr (DPW > 6) dma_piece(IC<(6 < DPW ? 6 : 0)>{}, slot);                                                  \
+        if constexpr (DPW > 7) dma_piece(IC<(7 < DPW ? 7 : 0)>{}, slot);                                                  \
+        if constexpr (DPW > 8) dma_piece(IC<(8 < DPW ? 8 : 0)>{}, slot);                                                  \
+        if constexpr (DPW > 9) dma_piece(IC<(9 < DPW ? 9 : 0)>{}, slot);                                                  \
+        if constexpr (DPW > 10) dma_piece(IC<(10 < DPW ? 10 : 0)>{}, slot);                                               \
+        if constexpr (DPW > 11) dma_piece(IC<(11 < DPW ? 11 : 0)>{}, slot);                                               \
+        if constexpr (DPW > 12) dma_piece(IC<(12 < DPW ? 12 : 0)>{}, slot);                                               \
+        if constexpr (DPW > 13) dma_piece(IC<(13 < DPW ? 13 : 0)>{}, slot);                                               \
+        static_assert(DPW >= 2 && DPW <= 14, "piece count");                                                              \
+    } while (0)
+#define BD_W4_R(G, MFV) region(IC<G>{}, IC<MFV>{}, st_cur, st_nxt, l_slot)
+
+    // ================================================================ prologue
+    int tm_c = 0, tn_c = 0;
+    if (!tile_of(0, tm_c, tn_c)) return;
+    BD_W4_STAMP(15 - 1 + 0 * 1, 5);
+    loader_tile(0);
+    BD_W4_ALL_PIECES(0u); loader_advance();
+    BD_W4_ALL_PIECES((uint32_t)STAGE); loader_advance();
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        // regions 12..15 without MFMAs: barrier (k-tile 0 landed, LUT visible), sign words, first X fragments, B fragments 0..2
+        const char *st_cur = smem, *st_nxt = smem;
+        const uint32_t l_slot = 0;
+        BD_W4_R(12, 0); BD_W4_R(13, 0); BD_W4_R(14, 0); BD_W4_R(15, 0);
+    }
+
+    // ================================================================ tile loop
+    int c_slot = 0;                                   // ring slot of the k-tile being multiplied
+    for (int r = 0;; ++r) {
+        const int m0 = tm_c * BM, n0 = tn_c * BN;
+        zero_acc();
+        BD_W4_STAMP(r, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int n_slot = c_slot + 1 == NS ? 0 : c_slot + 1;
+            const uint32_t l_slot = (n_slot + 1 == NS ? 0 : n_slot + 1) * STAGE;      // k-tile c+2 goes where k-tile c-1 was
+            const char* st_cur = smem + c_slot * STAGE;
+            const char* st_nxt = smem + n_slot * STAGE;
+            BD_W4_R(0, 1); BD_W4_R(1, 1); BD_W4_R(2, 1); BD_W4_R(3, 1);
+            BD_W4_R(4, 1); BD_W4_R(5, 1); BD_W4_R(6, 1); BD_W4_R(7, 1);
+            BD_W4_R(8, 1); BD_W4_R(9, 1); BD_W4_R(10, 1); BD_W4_R(11, 1);
+            BD_W4_R(12, 1); BD_W4_R(13, 1); BD_W4_R(14, 1); BD_W4_R(15, 1);
+            loader_advance();
+            c_slot = n_slot;
+#ifdef BD_TRACE
+            if (kt == 7) BD_W4_STAMP(r, 1);
+            if (kt == 39) BD_W4_STAMP(r, 2);
+#endif
+        }
+        BD_W4_STAMP(r, 3);
+        // ---- epilogue of tile r (the DMA of the next tile's first two k-tiles is already in flight / landed)
+        int tm_n = 0, tn_n = 0;
+        const bool more = tile_of(r + 1, tm_n, tn_n);
+        w4_epilogue<Cfg>(p, acc, smem + Cfg::STG_OFF, m0, n0, wm, wn, b, lane, wave);
+        BD_W4_STAMP(r, 4);
+        if (!more) break;
+        tm_c = tm_n; tn_c = tn_n;
+    }
+    wait_vmcnt<0>();
+}
+
+#undef BD_W4_R
+#undef BD_W4_ALL_PIECES
+
+}  // namespace bd
