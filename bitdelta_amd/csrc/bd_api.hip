@@ -11,6 +11,7 @@
 #endif
 #include "bd_gemm_pf.h"
 #include "bd_gemm_fx.h"
+#include "bd_gemm_w4.h"
 #include "bd_gemv.h"
 #include "bd_gemv_stream.h"
 #include "bd_gemv_chain.h"
@@ -517,6 +518,7 @@ inline GemmParams make_params(const Problem& q, int BM, int BN) {
     p.sAm = (int)q.sAm; p.sCm = (int)q.sCm; p.ldw = (int)q.ldw;
     p.sAlb = (int)q.sAlb; p.gsz = q.N / q.G;
     p.round_mode = q.round_mode; p.accumulate = q.accumulate;
+    p.nbatch = q.B;
     // Tile walk order (profiles/r01_tile_order.txt): delta-only = n fastest (the XCD's run shares X row panels; the mask is tiny).
     // Fused = groups of 4 tile rows: each XCD's run covers a ~4 x 8 block of tiles, which minimises X + W bytes per XCD
     // (+3..5 % on the MLP shapes over n-fastest, equal to m-fastest on the single-round ones).
@@ -569,6 +571,25 @@ int launch_tile(const Problem& q) {
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)q.B);
     hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, q.st, p);
     return launch_status();
+}
+
+// Four-wave persistent kernels (bd_gemm_w4.h): grid = min(batch x tiles, CUs) workgroups of 256 threads, each walking its share of the
+// (batch entry, tile) stream.
+template <class Cfg>
+int launch_w4(const Problem& q) {
+    const GemmParams p = make_params(q, Cfg::BM, Cfg::BN);
+    auto kern = delta_gemm_w4_kernel<Cfg>;
+    static std::atomic<uint64_t> lds_done{0};
+    if (!ensure_dyn_lds((const void*)kern, Cfg::LDS_BYTES, lds_done)) return BD_E_LAUNCH;
+    const long long total = (long long)p.tiles_m * p.tiles_n * q.B, cus = num_cus();
+    dim3 grid((unsigned)(total < cus ? total : cus));
+    hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, q.st, p);
+    return launch_status();
+}
+// share of the CU-rounds a tile count keeps busy (1.0 = every round full)
+inline double round_fill(long long tiles) {
+    const long long cus = num_cus();
+    return (double)tiles / (double)(((tiles + cus - 1) / cus) * cus);
 }
 
 template <int DT, bool FUSED, bool OUT_F32>
@@ -661,18 +682,27 @@ int dispatch3(const Problem& q) {
             // 64x256 tiles (twice the MFMAs per X fragment read) once they fill at least half the CUs, else 64x128 for the parallelism:
             // 6 tenants x 64 rows: q+k+v 56 vs 76 us, gate+up 207 vs 253 us, but o 54 vs 38 us (tools/bench_mt_prefill.py)
             v = ((long long)((q.N + 255) / 256) * q.B * 2 >= num_cus()) ? 12 : 11;
-        else if (FUSED && q.M > 16) v = choose_fused_tile(q);     // fused: one-pass kernel (profiles/r01_fx_vs_two_loop.txt, r01_small_m.txt,
-                                                                  // r01_mid_m.txt: also for 16 < M <= 64, rows padded to the 128-row tile)
-        else if (q.M > 128) v = choose_big_tile(q);
+        else if (FUSED && q.M > 16) {
+            v = choose_fused_tile(q);     // fused: one-pass kernel (profiles/r01_fx_vs_two_loop.txt, r01_small_m.txt,
+                                          // r01_mid_m.txt: also for 16 < M <= 64, rows padded to the 128-row tile)
+            // same 256x128 tile on the four-wave persistent schedule: +4..7 % on every shape measured (profiles/r03_w4_*.txt)
+            if (v == 8 && !OUT_F32) v = 14;
+        } else if (q.M > 128) {
+            v = choose_big_tile(q);
+            // four-wave persistent 256x256 kernel once its tiles keep >= 80 % of the CU-rounds busy (it has no 256x128 form)
+            if (round_fill((long long)((q.M + 255) / 256) * ((q.N + 255) / 256) * q.B) >= 0.8) v = 13;
+        }
         else if (q.M > 64) v = 1;
         else if (q.M > 32) v = 2;
         else v = 3;
     } else {
         if ((v == 200 || v == 300 || v == 400 || v == 500 || v == 600) && !gemv_ok(q)) return BD_E_BAD_SHAPE;
-        if (v >= 0 && v <= 12 && !fast_ok(q)) return BD_E_BAD_SHAPE;
+        if (v >= 0 && v <= 14 && !fast_ok(q)) return BD_E_BAD_SHAPE;
+        if (v == 13 && FUSED) return BD_E_BAD_SHAPE;
+        if (v == 14 && !FUSED) return BD_E_BAD_SHAPE;
         if ((v == 8 || v == 9 || v == 10 || v == 11 || v == 12) && !FUSED) return BD_E_BAD_SHAPE;
         if (v == 10 && (q.N % 8 || q.sCm % 4 || q.sCb % 4 || q.accumulate)) return BD_E_BAD_SHAPE;
-        if (FUSED && q.accumulate && !(v == 8 || v == 9 || v == 11 || v == 12 || v == 200 || v == 300 || v == 400 || v == 500 || v == 600))
+        if (FUSED && q.accumulate && !(v == 8 || v == 9 || v == 11 || v == 12 || v == 14 || v == 200 || v == 300 || v == 400 || v == 500 || v == 600))
             return BD_E_BAD_SHAPE;            // residual epilogue: one-pass fused tiles and the decode kernels only
     }
     t_last_variant = v;
@@ -720,6 +750,12 @@ int dispatch3(const Problem& q) {
             else return BD_E_BAD_SHAPE;
         case 9:      // one-pass fused, 128x128 tile, 4-slot ring: twice the tiles when 256x128 cannot fill the CUs (128 < M <~ 768)
             if constexpr (FUSED) return launch_tile<FxCfg<DT, 128, 128, 4, OUT_F32, 1>, 3>(q);
+            else return BD_E_BAD_SHAPE;
+        case 13:     // four-wave persistent delta-only kernel, 256x256 tile, LUT sign expansion (bd_gemm_w4.h)
+            if constexpr (!FUSED) return launch_w4<W4Cfg<DT, 256, 256, false, OUT_F32, 1>>(q);
+            else return BD_E_BAD_SHAPE;
+        case 14:     // four-wave persistent one-pass fused kernel, 256x128 tile, VALU sign expansion
+            if constexpr (FUSED) return launch_w4<W4Cfg<DT, 256, 128, true, OUT_F32, 0>>(q);      // (fp32 output: general-form epilogue only)
             else return BD_E_BAD_SHAPE;
         case 1: return launch_tile<GemmCfg<DT, 128, 256, 1, 4, 4, FUSED, OUT_F32>>(q);
         case 2: return launch_tile<GemmCfg<DT, 64, 256, 1, 4, 4, FUSED, OUT_F32>>(q);

@@ -57,10 +57,15 @@ struct W4Cfg {
     static constexpr int LUT_OFF = NS * STAGE, LUT_BYTES = USE_LUT ? 4096 : 0;
     static constexpr int STG_OFF = LUT_OFF + LUT_BYTES;
     static constexpr int ESZ = OUT_F32 ? 4 : 2;
-    // epilogue staging: one 32-row block x JC 32-column blocks per wave at a time, rows padded by 16 B
-    static constexpr int stg_bytes(int jc) { return NW * 32 * (jc * 32 * ESZ + 16); }
-    static constexpr int JC = (STG_OFF + stg_bytes(TN) <= 160 * 1024) ? TN : (TN >= 2 && STG_OFF + stg_bytes(TN / 2) <= 160 * 1024) ? TN / 2 : 1;
-    static constexpr int STG_ROWB = JC * 32 * ESZ + 16, STG_PW = 32 * STG_ROWB;
+    // epilogue staging, per wave, one 32-row block x JC 32-column blocks at a time:
+    //   16-bit outputs: TRANSPOSED image [n][32 m] (64 B per column n, 8-byte quads XOR-swizzled), written with ds_write_b64 (4 consecutive
+    //   m of one column = one accumulator register quad), read back with ds_read_b64_tr_b16 (4 consecutive n of one row per lane);
+    //   fp32 outputs: [m][n] rows padded by 16 B, 4-byte writes.
+    static constexpr int stg_pw(int jc) { return OUT_F32 ? 32 * (jc * 32 * 4 + 16) : jc * 32 * 64; }
+    static constexpr bool fits(int jc) { return STG_OFF + NW * stg_pw(jc) <= 160 * 1024; }
+    static constexpr int JC = fits(TN) ? TN : (TN >= 2 && fits(TN / 2)) ? TN / 2 : 1;
+    static constexpr bool FAST_EPI = fits(JC);          // fused + fp32 output: only the general form's 2-KiB block fits behind the ring
+    static constexpr int STG_ROWB = JC * 32 * ESZ + 16, STG_PW = FAST_EPI ? stg_pw(JC) : 2048;
     static constexpr int LDS_BYTES = STG_OFF + NW * STG_PW;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     static_assert(DPW <= 24, "piece placement");
@@ -90,6 +95,18 @@ template <int OFF> __device__ __forceinline__ void w4_dma4(uint32_t voff, const 
     asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_base), "n"(OFF) : "memory", "scc");
 }
 
+// Split form: the M0 write and the load go into two different MFMA gaps (no s_nop: at least one MFMA separates them).  Valid only
+// because nothing else in this kernel touches M0 between the two statements (audited in the ISA: the only M0 writers are these).
+template <int OFF> __device__ __forceinline__ void w4_set_m0(uint32_t lds_base) {
+    asm volatile("s_add_u32 m0, %0, %1" ::"s"(lds_base), "n"(OFF) : "memory", "scc");
+}
+__device__ __forceinline__ void w4_dma16_m0(uint32_t voff, const void* sbase) {
+    asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void w4_dma4_m0(uint32_t voff, const void* sbase) {
+    asm volatile("global_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase) : "memory");
+}
+
 // Epilogue of one output tile.  NATURAL MFMA operand order (first = X fragment, second = B fragment):
 //     acc[b][i][r] = D[m = m0 + wm*WM + 32i + (r&3) + 8(r>>2) + 4h][n = n0 + wn*WN + 32j + l31]
 // (delta: j = b; fused: accW = acc[2j], accS = acc[2j+1], out = accW + alpha[n] * accS in fp32 -- one rounding, as bd_gemm_fx.h).
@@ -117,10 +134,21 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, f32x16_t (&acc)
     const bool res_mode = FUSED && p.accumulate;
     const bool rm16 = !FUSED && p.round_mode == 1;
     const float* al = (FUSED || acc_mode) ? p.alpha + (long long)b * p.sAlb : nullptr;
-    float a_col[TN];                                     // this lane's column scale per column block
+    // this lane's column scale per column block.  One scale group (the reference's scalar coeff): a scalar load.  Grouped scales: per-lane
+    // loads, retired at once with a wait the compiler's waitcnt pass can see -- a VMEM load it believes pending at the k-loop entry makes
+    // it put `s_waitcnt vmcnt(0)` in front of the first reuse of that register INSIDE the k loop, which drains the LDS-DMA ring every
+    // k-tile (measured: 2970 instead of 2355 cycles per k-tile on the fused kernel).
+    float a_col[TN];
+    if (p.gsz >= p.N) {
+        const float a0 = al ? al[0] : 0.f;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) a_col[j] = al ? al[min(n0 + wn * WN + j * 32 + l31, p.N - 1) / p.gsz] : 0.f;
-    const bool fast = !acc_mode && (p.N % 8 == 0) && (p.sCm % 8 == 0) && (p.sCb % 8 == 0) && (((uintptr_t)p.C & 15) == 0);
+        for (int j = 0; j < TN; ++j) a_col[j] = a0;
+    } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) a_col[j] = al ? al[min(n0 + wn * WN + j * 32 + l31, p.N - 1) / p.gsz] : 0.f;
+        __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0)
+    }
+    const bool fast = Cfg::FAST_EPI && !acc_mode && (p.N % 8 == 0) && (p.sCm % 8 == 0) && (p.sCb % 8 == 0) && (((uintptr_t)p.C & 15) == 0);
     char* buf = stg + wave * Cfg::STG_PW;
     const bool inside = (m0 + Cfg::BM <= p.M) && (n0 + Cfg::BN <= p.N);      // wave-uniform: interior tiles store without guards
 
@@ -147,7 +175,73 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, f32x16_t (&acc)
     };
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");    // MFMA result -> accvgpr_read distance for the last MFMAs of the k loop (asm is not padded)
 
-    if (fast) {
+    if constexpr (!Cfg::OUT_F32) if (fast) {
+        // ---- 16-bit fast form: transposed staging + hardware transpose read (mapping of ds_read_b64_tr_b16 probed on the device,
+        //      tests/native/probes/tr_probe.hip: inside a 16-lane group, output lane t gets element (t & 3) of the quads addressed by source
+        //      lanes (t >> 2), 4 + (t >> 2), 8 + (t >> 2), 12 + (t >> 2)).
+        //      image: byte(n, mq) = n * 64 + ((mq ^ ((n >> 1) & 7)) * 8), n = column inside the chunk, mq = 4-row quad 0..7
+        //      -> the ds_write_b64 groups (16 consecutive n, one mq) and the tr-read groups (4 n x 4 mq) both touch 16 distinct 8-byte slots.
+        typedef short v4s_t __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) v4s_t* lds_v4s_p;
+        const int swz = (l31 >> 1) & 7;
+        uint32_t wr_off[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wr_off[q] = l31 * 64 + (((2 * q + h) ^ swz) * 8);
+        const int G = lane >> 4, t = lane & 15, js = t >> 2, cs = t & 3;
+        uint32_t rd_off[2][2];
+#pragma unroll
+        for (int B = 0; B < 2; ++B)
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh)
+                rd_off[B][mh] = (8 * G + 4 * B + js) * 64 + (((4 * mh + cs) ^ ((4 * G + 2 * B + (js >> 1)) & 7)) * 8);
+        static_for<0, TM*(TN / JC)>([&](auto cc) {
+            constexpr int i = decltype(cc)::value / (TN / JC), j0 = (decltype(cc)::value % (TN / JC)) * JC;
+            static_for<0, JC * 4>([&](auto tc) {
+                constexpr int jj = decltype(tc)::value / 4, q = decltype(tc)::value % 4, j = j0 + jj;
+                __builtin_amdgcn_sched_barrier(0);           // keeps the accumulator reads of later quads from being hoisted (VGPR pressure)
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = 0.f;
+                v[0] = value(IC<i>{}, IC<j>{}, IC<4 * q + 0>{}); v[1] = value(IC<i>{}, IC<j>{}, IC<4 * q + 1>{});
+                v[2] = value(IC<i>{}, IC<j>{}, IC<4 * q + 2>{}); v[3] = value(IC<i>{}, IC<j>{}, IC<4 * q + 3>{});
+                if constexpr (!FUSED) { if (rm16) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = round_through_f16(v[e]);
+                } }
+                *(u32x2_t*)(buf + wr_off[q] + jj * 2048) = u32x2_t{pack2(v[0], v[1]), pack2(v[2], v[3])};
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's image only: no block barrier needed
+            auto store_rows = [&](auto guardc) {
+                constexpr bool GUARD = decltype(guardc)::value != 0;
+                static_for<0, JC * 2>([&](auto uc) {
+                    constexpr int u = decltype(uc)::value / 2, mh = decltype(uc)::value % 2;
+                    const v4s_t ra = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(buf + rd_off[0][mh] + u * 2048));
+                    const v4s_t rb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(buf + rd_off[1][mh] + u * 2048));
+                    const u32x2_t a2 = __builtin_bit_cast(u32x2_t, ra), b2 = __builtin_bit_cast(u32x2_t, rb);
+                    u32x4_t val = u32x4_t{a2.x, a2.y, b2.x, b2.y};
+                    const int mm = m0 + wm * WM + i * 32 + 16 * mh + t;
+                    const int n = n0 + wn * WN + (j0 + u) * 32 + 8 * G;
+                    if (!GUARD || (mm < p.M && n < p.N)) {
+                        u32x4_t* dst = (u32x4_t*)(p.C + (c_b + (long long)mm * p.sCm + n) * ESZ);
+                        if (res_mode) {
+                            const u32x4_t rsd = *(const u32x4_t*)dst;
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) {
+                                const float lo = half_bits_to_f32<DT>(val[d] & 0xffffu) + half_bits_to_f32<DT>(rsd[d] & 0xffffu);
+                                const float hi = half_bits_to_f32<DT>(val[d] >> 16) + half_bits_to_f32<DT>(rsd[d] >> 16);
+                                val[d] = pack2(lo, hi);
+                            }
+                        }
+                        __builtin_nontemporal_store(val, dst);
+                    }
+                });
+            };
+            if (inside) store_rows(IC<0>{}); else store_rows(IC<1>{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the image is rewritten by the next chunk
+        });
+        return;
+    }
+    if constexpr (Cfg::OUT_F32 && Cfg::FAST_EPI) if (fast) {
         constexpr int SEG = JC * 32 * ESZ / 16;          // 16-byte pieces per staged row
         constexpr int RPI = 64 / SEG;                    // rows per store instruction
         static_for<0, TM*(TN / JC)>([&](auto cc) {
@@ -203,7 +297,7 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, f32x16_t (&acc)
         return;
     }
     // ---- general form: 16 rows (register half qh = r >> 3) x 32 columns of fp32 at a time
-    constexpr int GROW = 32 * 4 + 16;
+    constexpr int GROW = 32 * 4;                        // (4-byte accesses along n: conflict-free without padding)
     static_assert(16 * GROW <= Cfg::STG_PW, "general-form staging block");
     static_for<0, TM * TN * 2>([&](auto ixc) {
         constexpr int ix = decltype(ixc)::value, i = ix / (TN * 2), j = (ix / 2) % TN, qh = ix & 1;
@@ -255,19 +349,21 @@ __global__ void __launch_bounds__(256) delta_gemm_w4_kernel(const GemmParams p) 
     const int h = lane >> 5, l31 = lane & 31;
 
     const int ntiles = p.tiles_m * p.tiles_n;
+    const int ntotal = ntiles * max(p.nbatch, 1);          // the persistent stream runs over (batch entry, tile) pairs
     const int G = (int)gridDim.x;
-    const int b = blockIdx.y;
     const int nk = p.K >> 6;
 
     uint32_t one2;
     asm volatile("v_mov_b32 %0, %1" : "=v"(one2) : "n"(One2<DT>::v));
 
     // ---- tile walk of this persistent workgroup: round r covers tiles [r*G, r*G + Gr), XCD-remapped inside the round
-    auto tile_of = [&](int r, int& tm, int& tn) -> bool {
+    auto tile_of = [&](int r, int& tm, int& tn, int& tb) -> bool {
         const int base = r * G;
-        const int Gr = min(G, ntiles - base);
+        const int Gr = min(G, ntotal - base);
         if ((int)blockIdx.x >= Gr) return false;
-        tile_coords(p, base + xcd_remap(blockIdx.x, Gr), tm, tn);
+        const int lin = base + xcd_remap(blockIdx.x, Gr);
+        tb = __builtin_amdgcn_readfirstlane(lin / ntiles);
+        tile_coords(p, lin - tb * ntiles, tm, tn);
         return true;
     };
 
@@ -296,8 +392,8 @@ __global__ void __launch_bounds__(256) delta_gemm_w4_kernel(const GemmParams p) 
         bw_ldsw[i] = lds0 + BW_OFF + (idx / (BN / 64)) * BN * 4 + (idx % (BN / 64)) * 256;
     }
     auto loader_tile = [&](int r) {
-        int tm, tn;
-        if (!tile_of(r, tm, tn)) { if (!tile_of(r - 1 >= 0 ? r - 1 : 0, tm, tn)) { tm = 0; tn = 0; } }   // past the end: re-fetch (never read)
+        int tm, tn, b;
+        if (!tile_of(r, tm, tn, b)) { if (!tile_of(r - 1 >= 0 ? r - 1 : 0, tm, tn, b)) { tm = 0; tn = 0; b = 0; } }   // past the end: re-fetch (never read)
         const int m0 = tm * BM, n0 = tn * BN;
         ld_a = p.A + ((long long)b * p.sAb + (long long)m0 * p.sAm) * 2;
         ld_p = (const char*)p.P + ((long long)b * p.sPb + n0) * 4;
@@ -342,6 +438,18 @@ __global__ void __launch_bounds__(256) delta_gemm_w4_kernel(const GemmParams p) 
             constexpr int i = pc - A_PW - W_PW;
             w4_dma4<0>(bw_voff[i], ld_p, bw_ldsw[i] + slot_off);
         }
+    };
+    auto dma_m0 = [&](auto pcc, uint32_t slot_off) {
+        constexpr int pc = decltype(pcc)::value;
+        if constexpr (pc < A_PW) w4_set_m0<pc * 1024>(a_ldsw + slot_off);
+        else if constexpr (pc < A_PW + W_PW) w4_set_m0<(pc - A_PW) * 1024>(w_ldsw + slot_off);
+        else w4_set_m0<0>(bw_ldsw[pc - A_PW - W_PW] + slot_off);
+    };
+    auto dma_go = [&](auto pcc) {
+        constexpr int pc = decltype(pcc)::value;
+        if constexpr (pc < A_PW) w4_dma16_m0(a_voff[pc], ld_a);
+        else if constexpr (pc < A_PW + W_PW) w4_dma16_m0(w_voff[pc - A_PW], ld_w);
+        else w4_dma4_m0(bw_voff[pc - A_PW - W_PW], ld_p);
     };
     auto loader_advance = [&]() {
         ld_a += 128; ld_p += p_step;
@@ -421,6 +529,7 @@ __global__ void __launch_bounds__(256) delta_gemm_w4_kernel(const GemmParams p) 
         constexpr bool MF = decltype(mfc)::value != 0;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (g == 12) {
+            if constexpr (Cfg::OPT & 8) wait_vmcnt<0>(); else
             wait_vmcnt<DPW>();                          // own pieces of k-tile c+1 have landed
             __builtin_amdgcn_s_waitcnt(0xc07f);         // lgkmcnt(0): own reads of k-tile c are done (slot c is refilled after B(c))
             __builtin_amdgcn_s_barrier();
@@ -428,7 +537,7 @@ __global__ void __launch_bounds__(256) delta_gemm_w4_kernel(const GemmParams p) 
             read_words(st_nxt);
         }
         // X fragments of the next k-step: regions b = 0, 1 read two each
-        if constexpr (bb < 2) {
+        if constexpr (bb < 2 && !((Cfg::OPT & 32) && MF)) {
             const char* st = (s == 3) ? st_nxt : st_cur;
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii) {
@@ -451,6 +560,8 @@ __global__ void __launch_bounds__(256) delta_gemm_w4_kernel(const GemmParams p) 
             for (int i = 0; i < TM; ++i) {
                 // OPT & 4 (energy A/B only, results transposed inside each 32 x 32 block): the 8-wave kernels' order, sign fragment first
                 if constexpr (Cfg::OPT & 4) acc[bb][i] = mfma32<DT>(bf[bb], xf[s & 1][i], acc[bb][i]);
+                else if constexpr (Cfg::OPT & 2) acc[bb][i & 2] = mfma32<DT>(xf[s & 1][i], bf[bb], acc[bb][i & 2]);   // energy A/B: dependent pairs
+                else if constexpr (Cfg::OPT & 16) acc[bb][0] = mfma32<DT>(xf[s & 1][i], bf[bb], acc[bb][0]);          // energy A/B: chains of 4
                 else acc[bb][i] = mfma32<DT>(xf[s & 1][i], bf[bb], acc[bb][i]);
             }
             // interleave: 1 MFMA, then its share of the region's reads and VALU
@@ -461,6 +572,27 @@ __global__ void __launch_bounds__(256) delta_gemm_w4_kernel(const GemmParams p) 
             constexpr bool commits = !USE_LUT && (g >= 13 || (g == 0 && TN == 4));
             constexpr bool s_type = !(FUSED && !(((g + 3) & 3) & 1));
             constexpr int nvalu = (s_type ? (USE_LUT ? 2 : 8) : 0) + (commits ? 4 : 0) + 2;
+            if constexpr ((Cfg::OPT & 64) && p1 - p0 == 1) {
+                // split form: [MFMA MFMA] m0 write [MFMA MFMA] load -- each statement alone in its gap
+                constexpr int vq = (nvalu + 3) / 4;
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, vq, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, vq, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                dma_m0(IC<p0>{}, slot_ld);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, vq, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, vq, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                dma_go(IC<p0>{});
+            } else {
             constexpr int slots = p1 > p0 ? 3 : 4;
             constexpr int vq = (nvalu + slots - 1) / slots;
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -475,10 +607,11 @@ __global__ void __launch_bounds__(256) delta_gemm_w4_kernel(const GemmParams p) 
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             if constexpr (slots == 4) __builtin_amdgcn_sched_group_barrier(0x002, vq, 0);
-            if constexpr (p1 > p0) {
+            if constexpr (p1 > p0 && !(Cfg::OPT & 8)) {
                 __builtin_amdgcn_sched_barrier(0);
                 dma_piece(IC<p0>{}, slot_ld);
                 if constexpr (p1 - p0 > 1) dma_piece(IC<(p0 + 1 < DPW ? p0 + 1 : p0)>{}, slot_ld);
+            }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -503,8 +636,8 @@ __global__ void __launch_bounds__(256) delta_gemm_w4_kernel(const GemmParams p) 
 #define BD_W4_R(G, MFV) region(IC<G>{}, IC<MFV>{}, st_cur, st_nxt, l_slot)
 
     // ================================================================ prologue
-    int tm_c = 0, tn_c = 0;
-    if (!tile_of(0, tm_c, tn_c)) return;
+    int tm_c = 0, tn_c = 0, b_c = 0;
+    if (!tile_of(0, tm_c, tn_c, b_c)) return;
     BD_W4_STAMP(15 - 1 + 0 * 1, 5);
     loader_tile(0);
     BD_W4_ALL_PIECES(0u); loader_advance();
@@ -541,12 +674,12 @@ __global__ void __launch_bounds__(256) delta_gemm_w4_kernel(const GemmParams p) 
         }
         BD_W4_STAMP(r, 3);
         // ---- epilogue of tile r (the DMA of the next tile's first two k-tiles is already in flight / landed)
-        int tm_n = 0, tn_n = 0;
-        const bool more = tile_of(r + 1, tm_n, tn_n);
-        w4_epilogue<Cfg>(p, acc, smem + Cfg::STG_OFF, m0, n0, wm, wn, b, lane, wave);
+        int tm_n = 0, tn_n = 0, b_n = 0;
+        const bool more = tile_of(r + 1, tm_n, tn_n, b_n);
+        w4_epilogue<Cfg>(p, acc, smem + Cfg::STG_OFF, m0, n0, wm, wn, b_c, lane, wave);
         BD_W4_STAMP(r, 4);
         if (!more) break;
-        tm_c = tm_n; tn_c = tn_n;
+        tm_c = tm_n; tn_c = tn_n; b_c = b_n;
     }
     wait_vmcnt<0>();
 }

@@ -77,7 +77,9 @@ static void launch_w4(const GemmParams& p0, int B, hipStream_t st, int grid_cap 
     p.tiles_m = (p.M + Cfg::BM - 1) / Cfg::BM; p.tiles_n = (p.N + Cfg::BN - 1) / Cfg::BN;
     const int nt = p.tiles_m * p.tiles_n;
     int G = std::min(nt, grid_cap > 0 ? grid_cap : g_cus);
-    hipLaunchKernelGGL(kern, dim3(G, B), dim3(256), Cfg::LDS_BYTES, st, p);
+    p.nbatch = B;
+    G = std::min(nt * B, grid_cap > 0 ? grid_cap : g_cus);
+    hipLaunchKernelGGL(kern, dim3(G), dim3(256), Cfg::LDS_BYTES, st, p);
 }
 template <class Cfg, class K>
 static void launch_old(K kern, const GemmParams& p0, int B, hipStream_t st) {
@@ -182,13 +184,20 @@ int main(int argc, char** argv) {
     if (what.rfind("soak", 0) == 0) {      // soak<variant>: run one kernel back to back for `reps` x 0.1 s (power / clock sampling from outside)
         const int M = Ms[0];
         const int v = atoi(what.c_str() + 4);
-        GemmParams p0 = params(M, N, v >= 10, C0);
+        GemmParams p0 = params(M, N, v >= 10, C0);   // (fused variants: 10, 11, 12)
         using OldD = GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 1>;
         using OldF = FxCfg<DT_BF16, 256, 128, 3, false, 1>;
         auto one = [&] {
             if (v == 0) launch_old<OldD>(delta_gemm_pf_kernel<OldD>, p0, 1, 0);
             else if (v == 1) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 0>>(p0, 1, 0);
             else if (v == 2) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1>>(p0, 1, 0);
+            else if (v == 5) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 2>>(p0, 1, 0);     // energy A/B: dependent MFMA pairs (results wrong)
+            else if (v == 6) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 16>>(p0, 1, 0);    // energy A/B: dependent chains of 4
+            else if (v == 7) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 8>>(p0, 1, 0);     // ablation: no LDS-DMA in the loop
+            else if (v == 8) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 32>>(p0, 1, 0);    // ablation: no X-fragment reads in the loop
+            else if (v == 9) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 8 | 32>>(p0, 1, 0);  // ablation: neither
+            else if (v == 3) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 64>>(p0, 1, 0);    // split-form DMA
+            else if (v == 12) launch_w4<W4Cfg<DT_BF16, 256, 128, true, false, 64>>(p0, 1, 0);        // fused, split-form DMA
             else if (v == 4) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 4>>(p0, 1, 0);     // energy A/B: sign fragment in the first MFMA slot (results wrong)
             else if (v == 10) launch_old<OldF>(delta_gemm_fx_kernel<OldF>, p0, 1, 0);
             else launch_w4<W4Cfg<DT_BF16, 256, 128, true, false, 0>>(p0, 1, 0);
@@ -210,7 +219,12 @@ int main(int argc, char** argv) {
         printf("== trace M=%d\n", M);
         trace_one<W4Cfg<DT_BF16, 256, 256, false, false, 0>>("w4 VALU", params(M, N, false, C1), 2.0 * M * N * K);
         trace_one<W4Cfg<DT_BF16, 256, 256, false, false, 1>>("w4 LUT", params(M, N, false, C1), 2.0 * M * N * K);
+        trace_one<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 64>>("w4 LUT split-dma", params(M, N, false, C1), 2.0 * M * N * K);
+        trace_one<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 8>>("w4 LUT no-dma", params(M, N, false, C1), 2.0 * M * N * K);
+        trace_one<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 32>>("w4 LUT no-xread", params(M, N, false, C1), 2.0 * M * N * K);
+        trace_one<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 8 | 32>>("w4 LUT neither", params(M, N, false, C1), 2.0 * M * N * K);
         trace_one<W4Cfg<DT_BF16, 256, 128, true, false, 0>>("w4 fused", params(M, N, true, C1), 4.0 * M * N * K);
+        trace_one<W4Cfg<DT_BF16, 256, 128, true, false, 64>>("w4 fused split-dma", params(M, N, true, C1), 4.0 * M * N * K);
     }
     return 0;
 #endif

@@ -186,11 +186,17 @@ SHAPES = [
     (6, 1, 1024, 1000, 6, 600), (3, 2, 512, 512, 1, 600), (4, 4, 160, 520, 4, 600), (5, 1, 1536, 700, 5, 601),
     (8, 1, 2048, 1024, 8, 600), (1, 16, 512, 600, 1, 600), (6, 1, 1184, 1000, 6, 640), (2, 1, 4096, 1040, 2, 610),
     (1, 1, 4096, 4096, 1, 600), (3, 1, 8192, 520, 3, 603), (6, 2, 2176, 777, 6, 605),
+    # forced: four-wave persistent kernels (bd_gemm_w4.h; 13 = delta-only 256x256, 14 = fused 256x128 -- 13 is refused for fused launches
+    # and 14 for delta-only ones, so each list below keeps only its own).  Ragged M / N, a single k-tile (k shorter than the ring and than
+    # the DMA look-ahead), several batch entries in one persistent stream, a broadcast mask, odd N (general-form epilogue)
+    (2, 200, 256, 520, 2, 13), (3, 130, 64, 300, 1, 13), (1, 700, 512, 1032, 1, 13), (1, 257, 128, 77, 1, 13),
+    (2, 200, 256, 520, 2, 14), (3, 130, 64, 300, 1, 14), (1, 700, 512, 1032, 1, 14), (1, 257, 128, 77, 1, 14), (6, 64, 512, 640, 6, 14),
 ]
+DELTA_SHAPES = [sh for sh in SHAPES if sh[5] != 14]
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("shape", DELTA_SHAPES)
 def test_delta_bmm_vs_oracle(bd, oracle, dtype, shape):
     from bitdelta_amd import _lib
     B, M, K, N, T, variant = shape
@@ -216,7 +222,7 @@ def test_delta_bmm_vs_oracle(bd, oracle, dtype, shape):
 
 # the one-pass fused kernel (variant 8, bd_binary_linear only): multi-tenant, ragged M/N, k shorter than its 3-slot ring
 # fused launches: forced 0 / 5 are the two-loop A/B references (harness-only build) -> the shipped library refuses them (tested below)
-LINEAR_SHAPES = [sh for sh in SHAPES if not (sh[5] in (0, 5))] + [(3, 130, 128, 300, 1, None),
+LINEAR_SHAPES = [sh for sh in SHAPES if not (sh[5] in (0, 5, 13))] + [(3, 130, 128, 300, 1, None),
                           (2, 200, 256, 520, 2, 8), (1, 257, 64, 136, 1, 8), (3, 300, 128, 264, 1, 8), (1, 512, 1024, 384, 1, 8),
                           (2, 200, 256, 520, 2, 9), (1, 257, 64, 136, 1, 9), (3, 300, 128, 264, 1, 9), (1, 512, 1024, 384, 1, 9),   # 9 = 128x128 tile
                           (2, 200, 256, 520, 2, 10), (1, 128, 512, 384, 1, 10), (1, 40, 1024, 264, 1, None), (3, 33, 2048, 1024, 3, None),  # split-k (mid M)
@@ -289,6 +295,83 @@ def test_decode_in_launch_reduction_matches_two_launch_form(bd):
     finally:
         L.bd_set_decode_two_launch(1)          # library default
         L.bd_set_gemm_variant(-1)
+
+
+def test_four_wave_persistent_kernels(bd, oracle):
+    """bd_gemm_w4.h beyond the per-shape oracle checks above: (i) a persistent workgroup walking SEVERAL tiles and batch entries (more
+    tiles than CUs), (ii) bit-identity with the 8-wave kernels it replaces (same per-element MFMA sequence), (iii) every epilogue
+    form: reference fp16 rounding, C += alpha * acc with scale groups, fused + residual, grouped alpha, strided C rows."""
+    from bitdelta_amd import _lib
+    L = _lib.lib()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+
+    def forced(v, fn):
+        L.bd_set_gemm_variant(v)
+        try:
+            out = fn()
+            assert L.bd_last_gemm_variant() == v
+            return out
+        finally:
+            L.bd_set_gemm_variant(-1)
+
+    # (i) + (ii): 3 x (5 x 64) = 960 fused tiles / 3 x (5 x 32) = 480 delta tiles on <= 256 CUs, ragged edges
+    B, M, K, N = 3, 1100, 320, 8100 + 8
+    a, p, w, alpha = rand_problem(B, M, K, N, torch.bfloat16, B, seed=21)
+    assert B * ((M + 255) // 256) * ((N + 255) // 256) > cus
+    d13 = forced(13, lambda: bd.delta_bmm(dev(a), dev(p), round_mode=1))
+    d0 = forced(0, lambda: bd.delta_bmm(dev(a), dev(p), round_mode=1))
+    assert torch.equal(d13, d0)
+    y14 = forced(14, lambda: bd.binary_linear(dev(a), dev(w), dev(p), dev(alpha)))
+    y8 = forced(8, lambda: bd.binary_linear(dev(a), dev(w), dev(p), dev(alpha)))
+    assert torch.equal(y14, y8)
+    rows = torch.tensor([0, 255, 256, 511, 777, 1099])
+    ref = oracle.binary_linear(a[:, rows].contiguous(), w, p, alpha, out_dtype=torch.float32)
+    ok, same = within_one_ulp(y14[:, rows].cpu(), ref.bfloat16(), K)
+    assert ok and same >= 0.99
+    # the automatic choice at these sizes IS the four-wave kernel
+    bd.delta_bmm(dev(a), dev(p))
+    assert L.bd_last_gemm_variant() == 13
+    bd.binary_linear(dev(a), dev(w), dev(p), dev(alpha))
+    assert L.bd_last_gemm_variant() == 14
+
+    # (iii) epilogue forms
+    a, p, w, _ = rand_problem(2, 300, 256, 512, torch.bfloat16, 2, seed=22)
+    alpha = torch.tensor([[3e-4, 4e-4, 5e-4, 6e-4], [1e-3, 2e-3, 3e-3, 4e-3]])
+    scale = alpha.repeat_interleave(128, dim=1)[:, None, :]
+    ref = oracle.delta_bmm(a, p, out_dtype=torch.float32, round_mode=0)
+    base = (a.float() @ w.float().T).bfloat16()
+    out = dev(base.clone())
+    forced(13, lambda: bd.delta_bmm(dev(a), dev(p), out=out, alpha=dev(alpha), accumulate=True, groups=4))
+    assert ulp_diff(out.cpu(), (base.float() + scale * ref).bfloat16()).max().item() <= 1
+    z = forced(13, lambda: bd.delta_bmm(dev(a), dev(p), alpha=dev(alpha), groups=4, out_dtype=torch.float32))
+    assert relerr(z.cpu(), scale * ref)[0] <= 1e-5
+    y = forced(14, lambda: bd.binary_linear(dev(a), dev(w), dev(p), dev(alpha), groups=4))
+    yo = oracle.binary_linear(a, w, p, alpha, G=4, out_dtype=torch.float32)
+    ok, same = within_one_ulp(y.cpu(), yo.bfloat16(), 256)
+    assert ok and same >= 0.99
+    y32 = forced(14, lambda: bd.binary_linear(dev(a), dev(w), dev(p), dev(alpha), groups=4, out_dtype=torch.float32))
+    assert relerr(y32.cpu(), yo)[0] <= 1e-5
+    for dt in (torch.bfloat16, torch.float16):          # fused + residual: two roundings, like the separate add
+        a, p, w, al1 = rand_problem(2, 300, 256, 512, dt, 2, seed=23)
+        r = torch.randn(2, 300, 512).to(dt)
+        got = forced(14, lambda: bd.binary_linear(dev(a), dev(w), dev(p), dev(al1), residual=dev(r).clone()))
+        y32 = oracle.binary_linear(a, w, p, al1, out_dtype=torch.float32)
+        want = (r.float() + y32.to(dt).float()).to(dt)
+        # one ulp at the magnitude of the larger addend (the sum may cancel to something much smaller than its terms) ...
+        d = (got.cpu().float() - want.float()).abs()
+        assert (d <= (r.float().abs() + y32.abs()) * (2 ** -10 if dt == torch.float16 else 2 ** -7) + 1e-4).all()
+        assert (got.cpu() == want).float().mean().item() >= 0.99
+        # ... and exactly the separate ops wherever the Linear output itself is bit-equal
+        y16 = forced(14, lambda: bd.binary_linear(dev(a), dev(w), dev(p), dev(al1)))
+        assert torch.equal(got, dev(r) + y16)
+    # strided output rows (a column slice of a wider buffer): the aligned fast form with sCm != N, and an unaligned slice (general form)
+    a, p, w, al1 = rand_problem(1, 300, 128, 256, torch.bfloat16, 1, seed=24)
+    ref = oracle.delta_bmm(a, p, round_mode=1)
+    for off in (8, 3):
+        wide = torch.zeros(1, 300, 256 + 16, dtype=torch.bfloat16, device="cuda")
+        forced(13, lambda: bd.delta_bmm(dev(a), dev(p), out=wide[:, :, off:off + 256]))
+        ok, same = within_one_ulp(wide[:, :, off:off + 256].cpu().contiguous(), ref, 128)
+        assert ok and same >= 0.99 and (wide[:, :, :off] == 0).all() and (wide[:, :, off + 256:] == 0).all()
 
 
 def test_delta_bmm_alpha_accumulate_and_groups(bd, oracle):
