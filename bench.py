@@ -65,6 +65,21 @@ class LaunchTimer:
             timer.records.append((e0, e1, 4.0 * B * M * K * N, nbytes))
             return y
         k.binary_linear = d.binary_linear = s.binary_linear = sl.binary_linear = timed
+        orig_sw = k.binary_linear_swiglu
+
+        def timed_swiglu(x, weight, mask, alpha):
+            if not timer.enabled:
+                return orig_sw(x, weight, mask, alpha)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = orig_sw(x, weight, mask, alpha)
+            e1.record()
+            B, M, K = x.shape
+            N = weight.shape[0]
+            nbytes = 2.0 * B * M * K + 2.0 * N * K + mask.shape[0] * K * N / 8.0 + 4.0 * mask.shape[0] + 2.0 * B * M * (N // 2)
+            timer.records.append((e0, e1, 4.0 * B * M * K * N, nbytes))
+            return y
+        k.binary_linear_swiglu = sl.binary_linear_swiglu = timed_swiglu
         orig_dec = k.binary_linear_decode
 
         def timed_dec(x, weight, mask, alpha, **kw):
@@ -148,28 +163,111 @@ def cpu_baseline(seq=128):
                       f"layers; host: {cpu}, os.cpu_count()={ncpu}, torch threads={torch.get_num_threads()}, torch {torch.__version__}"}
 
 
-def delta_gemm_microbench(dev, M=4096, N=4096, K=4096, iters=30):
+def parity_block(dev):
+    """Part of the CPU-baseline leg (the only place bench.py touches oracle/): the timed GPU kernels re-run on the TIMED shapes and
+    compared with the C oracle (oracle/bd_oracle.c, pinned to the reference's golden vectors by tests/test_oracle_golden.py) on a
+    sample of output columns -- the oracle takes the sliced W rows / packed-word columns, so every sampled column is exact over all
+    rows and all of k (tests/test_gpu_baseline_shapes.py runs the same check with asserts).  SURVEY.md 8(d): the parity gate is
+    reported with every perf number."""
     import bitdelta_amd as bd
-    g = torch.Generator(device=dev).manual_seed(1)
-    x = torch.randn(1, M, K, device=dev, generator=g).bfloat16()
-    p = torch.randint(-2 ** 31, 2 ** 31 - 1, (1, K // 32, N), device=dev, generator=g, dtype=torch.int64).to(torch.int32)
-    out = torch.empty(1, M, N, device=dev, dtype=torch.bfloat16)
-    for _ in range(5):
-        bd.delta_bmm(x, p, out=out, round_mode=0)
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-    for a, b in ev:
-        a.record()
-        bd.delta_bmm(x, p, out=out, round_mode=0)
-        b.record()
-    torch.cuda.synchronize()
-    ts = sorted(a.elapsed_time(b) for a, b in ev)
-    avg = sum(ts) / len(ts)
-    fl = 2.0 * M * N * K
-    return {"shape": [M, N, K], "flops_per_launch": fl, "avg_ms": avg, "median_ms": ts[len(ts) // 2],
-            "tflops": fl / avg * 1e-9, "tflops_median": fl / ts[len(ts) // 2] * 1e-9,
-            "frac_of_peak": fl / avg * 1e-9 / PEAK_BF16_TFLOPS, "peak_tflops": PEAK_BF16_TFLOPS,
-            "bytes_per_launch": 2.0 * M * K + K * N / 8 + 2.0 * M * N}
+    from bitdelta_amd import _lib
+    from oracle import bd_oracle as o
+
+    def ulp(a, b):
+        def key(t):
+            i = t.view(torch.int16).int()
+            return torch.where(i < 0, -(i & 0x7fff), i)
+        return (key(a) - key(b)).abs()
+
+    def cols_of(N, n=48, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        fixed = [0, 1, 127, 128, 255, 256, N // 2, N - 257, N - 129, N - 2, N - 1]
+        return torch.tensor(sorted(set([c for c in fixed if 0 <= c < N] + torch.randint(0, N, (n,), generator=g).tolist())))
+
+    out = {"oracle": "oracle/bd_oracle.c on sampled output columns, all rows, all of k", "gates": "16-bit outputs: <= 1 ulp of the rounded "
+           "fp32 oracle (or inside the cancellation floor 2^-22 sqrt(K) max|ref|), >= 99 % bit-equal; fp32 outputs: rel-Frobenius <= 1e-5"}
+    g = torch.Generator().manual_seed(5)
+    # (1) the delta GEMM row at M = 4096 (bf16, round_mode 0 as timed; fp32-output mode as the exactness check)
+    M, N, K = 4096, 4096, 4096
+    x = torch.randn(1, M, K, generator=g).bfloat16()
+    p = torch.randint(-2 ** 31, 2 ** 31 - 1, (1, K // 32, N), generator=g, dtype=torch.int64).to(torch.int32)
+    cols = cols_of(N)
+    c16 = bd.delta_bmm(x.to(dev), p.to(dev), round_mode=0)
+    v = _lib.lib().bd_last_gemm_variant()
+    c32 = bd.delta_bmm(x.to(dev), p.to(dev), out_dtype=torch.float32, round_mode=0)
+    ref32 = o.delta_bmm(x, p[:, :, cols].contiguous(), out_dtype=torch.float32, round_mode=0)
+    d = ulp(c16[:, :, cols.to(dev)].cpu().contiguous(), ref32.bfloat16())
+    out["delta_gemm_4096"] = {"kernel_variant": v, "sampled_columns": len(cols), "max_ulp": int(d.max()), "bit_equal": float((d == 0).float().mean()),
+                              "fp32_mode_rel_frobenius": float(((c32[:, :, cols.to(dev)].cpu().double() - ref32.double()).norm() / ref32.double().norm()))}
+    # (2) the fused Linear of the timed prefill at its largest shape (2048 x 4096 -> 11008)
+    M, N = 2048, 11008
+    x = torch.randn(1, M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.02).bfloat16()
+    p = torch.randint(-2 ** 31, 2 ** 31 - 1, (1, K // 32, N), generator=g, dtype=torch.int64).to(torch.int32)
+    al = torch.tensor([[4e-4]])
+    cols = cols_of(N, seed=1)
+    y16 = bd.binary_linear(x.to(dev), w.to(dev), p.to(dev), al.to(dev))
+    v = _lib.lib().bd_last_gemm_variant()
+    y32 = bd.binary_linear(x.to(dev), w.to(dev), p.to(dev), al.to(dev), out_dtype=torch.float32)
+    ref32 = o.binary_linear(x, w[cols].contiguous(), p[:, :, cols].contiguous(), al, out_dtype=torch.float32, round_mode=0)
+    got = y16[:, :, cols.to(dev)].cpu().contiguous()
+    d = ulp(got, ref32.bfloat16())
+    floor = 2.0 ** -22 * (K ** 0.5) * float(ref32.abs().max())
+    ok = (d <= 1) | ((got.float() - ref32.bfloat16().float()).abs() <= floor)
+    out["fused_linear_2048x4096_to_11008"] = {
+        "kernel_variant": v, "sampled_columns": len(cols), "max_ulp": int(d.max()), "all_within_gate": bool(ok.all()),
+        "bit_equal": float((d == 0).float().mean()),
+        "fp32_mode_rel_frobenius": float(((y32[:, :, cols.to(dev)].cpu().double() - ref32.double()).norm() / ref32.double().norm())),
+        "rel_frobenius_16bit_vs_fp32_oracle": float(((got.double() - ref32.double()).norm() / ref32.double().norm()))}
+    return out
+
+
+def committed_traffic():
+    """HBM/fabric-side bytes per launch of the dominant kernels, from the committed rocprofv3 PMC passes over THIS command
+    (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE x 2 per MI355X_MICROARCH.md; tools/prof_bench.sh).  A bench run cannot
+    read PMC counters in-process, so the line carries the committed figure and names its source."""
+    path = os.path.join(ROOT, "profiles", "r03_traffic.json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        d["_source"] = "profiles/r03_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `python bench.py`, tools/prof_bench.sh)"
+        return d
+    except Exception:
+        return None
+
+
+def delta_gemm_microbench(dev, Ms=(4096, 8192, 16384), N=4096, K=4096, iters=100, warmup=100):
+    """The W1A16 delta-GEMM alone (SURVEY.md 8d row C1': K = N = 4096, M in {4096, 8192, 16384}, one mask, random operands, round_mode 0).
+    `warmup` untimed launches first: the chip's power management needs tens of milliseconds of this kernel before its clock
+    settles (the first ~20 ms after a different workload run 10 % slow), and a serving / training process lives in the steady
+    state.  Then `iters` launches, each between two HIP events recorded on the launch stream (no host sync in between)."""
+    import bitdelta_amd as bd
+    from bitdelta_amd import _lib
+    rows = []
+    for M in Ms:
+        g = torch.Generator(device=dev).manual_seed(1)
+        x = torch.randn(1, M, K, device=dev, generator=g).bfloat16()
+        p = torch.randint(-2 ** 31, 2 ** 31 - 1, (1, K // 32, N), device=dev, generator=g, dtype=torch.int64).to(torch.int32)
+        out = torch.empty(1, M, N, device=dev, dtype=torch.bfloat16)
+        for _ in range(warmup):
+            bd.delta_bmm(x, p, out=out, round_mode=0)
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for a, b in ev:
+            a.record()
+            bd.delta_bmm(x, p, out=out, round_mode=0)
+            b.record()
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) for a, b in ev)
+        avg = sum(ts) / len(ts)
+        fl = 2.0 * M * N * K
+        rows.append({"shape": [M, N, K], "flops_per_launch": fl, "avg_ms": avg, "median_ms": ts[len(ts) // 2], "min_ms": ts[0],
+                     "tflops": fl / avg * 1e-9, "tflops_median": fl / ts[len(ts) // 2] * 1e-9,
+                     "frac_of_peak": fl / avg * 1e-9 / PEAK_BF16_TFLOPS, "peak_tflops": PEAK_BF16_TFLOPS,
+                     "bytes_per_launch": 2.0 * M * K + K * N / 8 + 2.0 * M * N, "launches": iters, "warmup_launches": warmup,
+                     "kernel_variant": _lib.lib().bd_last_gemm_variant()})
+        del x, p, out
+    return rows
 
 
 def run_mt_decode(dev, timer, model_name, tenants, kv_len, steps, warmup, layers=None, seed=4321, ab_glue=False):
@@ -373,6 +471,7 @@ def main():
     if rank != 0:
         return
     mb = delta_gemm_microbench(dev)
+    traffic = committed_traffic()
     achieved = k_flops / k_ms * 1e-9 if k_ms > 0 else 0.0
     out = {
         "metric": "W1A16 binary-delta GEMM TFLOP/s + tokens/s, Llama-2-7B+Vicuna delta, 1/2/4/8 MI355X "
@@ -385,11 +484,16 @@ def main():
                    "seq_len": args.seq, "global_batch": world, "parallelism": f"dp{world} independent replicas, no collective",
                    "valid": args.layers is None},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
-                     "traffic_note": "not measured by this run (PMC counters need a rocprofv3 pass): see profiles/ for the per-launch "
-                                     "FETCH_SIZE / WRITE_SIZE tables; algorithmic bytes per launch = algorithmic_bytes_total / launches",
-                     "algorithmic_bytes_total": k_bytes,
-                     "kernel": "bd::delta_gemm_fx_kernel<bf16, 256x128 tile> (one-pass fused, two accumulator sets, full-tile ping-pong; x.W^T + alpha*(x.S), 4*M*N*K flop/launch)",
+                     "frac": achieved / PEAK_BF16_TFLOPS,
+                     "traffic": traffic.get("fused_gemm", {}).get("traffic_bytes_per_launch") if traffic else None,
+                     "traffic_source": traffic.get("_source") if traffic else
+                                       "not available: PMC counters need rocprofv3 passes (tools/prof_bench.sh writes profiles/r03_traffic.json)",
+                     "traffic_over_algorithmic": (traffic["fused_gemm"]["traffic_bytes_per_launch"] / (k_bytes / n_launch))
+                                                 if traffic and n_launch and traffic.get("fused_gemm") else None,
+                     "algorithmic_bytes_total": k_bytes, "algorithmic_bytes_per_launch": k_bytes / n_launch if n_launch else None,
+                     "kernel": "bd::delta_gemm_w4_kernel<bf16, 256x128 tile, fused> (four-wave persistent one-pass fused kernel: "
+                               "x.W^T + alpha*(x.S), 4*M*N*K flop/launch; a tail split hands the last partial round's columns to "
+                               "bd::delta_gemm_fx_kernel<128x128>)",
                      "launches": n_launch, "kernel_ms_total": k_ms, "algorithmic_flops_total": k_flops,
                      "share_of_step_time": (k_ms / 1e3) / dt if dt > 0 else None},
         "delta_gemm": mb,
@@ -402,6 +506,10 @@ def main():
             out["mt_decode"] = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
+        try:
+            out["parity"] = parity_block(dev)
+        except Exception as e:
+            out["parity"] = {"error": f"{type(e).__name__}: {e}"}
     print(json.dumps(out), flush=True)
 
 

@@ -76,6 +76,25 @@ class SingleTenantLinear(nn.Module):
         return self.lin(x, residual=residual)
 
 
+class FusedSingleTenantLinear(nn.Module):
+    """Several single-tenant BinaryDiff projections that read the same input, stored and launched as ONE (q|k|v; gate|up with the
+    rows interleaved in blocks of 8 so that SwiGLU runs in the GEMM's epilogue): serving_loop.FusedDeltaLinear with one tenant."""
+
+    def __init__(self, shapes, device, dtype, gen, interleave8=False):
+        super().__init__()
+        from bitdelta_amd.serving_loop import FusedDeltaLinear
+        ws, ms, cs = [], [], []
+        for n_out, n_in in shapes:
+            w, fine = synth_pair(n_out, n_in, device, dtype, gen)
+            m, c = binarize(w, fine)
+            ws.append(w); ms.append(m[None]); cs.append(c.reshape(1))
+        self.lin = FusedDeltaLinear(ws, ms, cs, interleave8=interleave8, decode_copies=False)
+        self.flops_per_row = sum(4 * o * i for o, i in shapes)
+
+    def forward(self, x):
+        return self.lin(x)
+
+
 class MultiTenantLinear(nn.Module):
     """One base nn.Linear + T deltas, row i -> tenant i: serving form, reference demo/demo_backend.py:82-98."""
 
@@ -101,18 +120,26 @@ class MultiTenantLinear(nn.Module):
 
 
 class DecoderLayer(nn.Module):
-    def __init__(self, cfg, device, dtype, gen, tenants=0):
+    def __init__(self, cfg, device, dtype, gen, tenants=0, fuse=True):
         super().__init__()
         hid, inter, _, heads, kvh, _ = cfg
         self.heads, self.kvh, self.hd = heads, kvh, hid // heads
         mk = (lambda o, i: MultiTenantLinear(o, i, device, dtype, gen, tenants)) if tenants else \
              (lambda o, i: SingleTenantLinear(o, i, device, dtype, gen))
-        self.q_proj = mk(hid, hid)
-        self.k_proj = mk(kvh * self.hd, hid)
-        self.v_proj = mk(kvh * self.hd, hid)
+        # single tenant: q|k|v and gate|up as ONE launch each (4 GEMM launches per layer: q|k|v, o + residual, gate|up -> SwiGLU,
+        # down + residual); `fuse=False` keeps the reference's seven separate BinaryDiff modules
+        self.fused = (not tenants) and fuse and inter % 8 == 0
+        self.swiglu_epilogue = False
+        if self.fused:
+            self.qkv_proj = FusedSingleTenantLinear([(hid, hid), (kvh * self.hd, hid), (kvh * self.hd, hid)], device, dtype, gen)
+            self.gate_up_proj = FusedSingleTenantLinear([(inter, hid), (inter, hid)], device, dtype, gen, interleave8=True)
+        else:
+            self.q_proj = mk(hid, hid)
+            self.k_proj = mk(kvh * self.hd, hid)
+            self.v_proj = mk(kvh * self.hd, hid)
+            self.gate_proj = mk(inter, hid)
+            self.up_proj = mk(inter, hid)
         self.o_proj = mk(hid, hid)
-        self.gate_proj = mk(inter, hid)
-        self.up_proj = mk(inter, hid)
         self.down_proj = mk(hid, inter)
         self.input_layernorm = RMSNorm(hid, dtype, device)
         self.post_attention_layernorm = RMSNorm(hid, dtype, device)
@@ -120,7 +147,20 @@ class DecoderLayer(nn.Module):
     def forward(self, x, cos, sin, kv=None, rope=None):
         B, S, _ = x.shape
         h = self.input_layernorm(x)
-        if self.hd == 128 and rope is not None:
+        if self.fused:
+            qkv = self.qkv_proj(h)                                               # [B, S, (heads + 2 kvh) * hd]: one launch
+            nq, nk = self.heads * self.hd, self.kvh * self.hd
+            qf, kf, vf = qkv[..., :nq], qkv[..., nq:nq + nk], qkv[..., nq + nk:]
+            if self.hd == 128 and rope is not None:
+                ops.rope_(qf, rope[0], rope[1], self.heads, S, rope[2])
+                ops.rope_(kf, rope[0], rope[1], self.kvh, S, rope[2])
+                q = qf.view(B, S, self.heads, self.hd).transpose(1, 2)
+                k = kf.view(B, S, self.kvh, self.hd).transpose(1, 2)
+            else:
+                q = apply_rope(qf.reshape(B, S, self.heads, self.hd).transpose(1, 2), cos, sin)
+                k = apply_rope(kf.reshape(B, S, self.kvh, self.hd).transpose(1, 2), cos, sin)
+            v = vf.view(B, S, self.kvh, self.hd).transpose(1, 2)
+        elif self.hd == 128 and rope is not None:
             # fused in-place RoPE on the projection outputs (one pass instead of cat + mul + addcmul and their temporaries)
             q = ops.rope_(self.q_proj(h), rope[0], rope[1], self.heads, S, rope[2]).view(B, S, self.heads, self.hd).transpose(1, 2)
             k = ops.rope_(self.k_proj(h), rope[0], rope[1], self.kvh, S, rope[2]).view(B, S, self.kvh, self.hd).transpose(1, 2)
@@ -144,8 +184,13 @@ class DecoderLayer(nn.Module):
         a = a.transpose(1, 2).reshape(B, S, self.heads * self.hd)
         x = self.o_proj(a, residual=x) if self._res_epilogue(x, self.o_proj) else x + self.o_proj(a)
         h = self.post_attention_layernorm(x)
-        g, u = self.gate_proj(h), self.up_proj(h)
-        act = ops.swiglu2(g, u) if g.shape[-1] % 8 == 0 else F.silu(g) * u       # one pass: round(silu(g)) * u
+        if self.fused and self.swiglu_epilogue and self.gate_up_proj.lin.swiglu_ok(h):
+            act = self.gate_up_proj.lin.forward_swiglu(h)                        # gate|up -> SwiGLU in the GEMM's epilogue (A/B: slower)
+        elif self.fused:
+            act = ops.swiglu_interleaved8(self.gate_up_proj(h))                  # one GEMM launch + one elementwise pass
+        else:
+            g, u = self.gate_proj(h), self.up_proj(h)
+            act = ops.swiglu2(g, u) if g.shape[-1] % 8 == 0 else F.silu(g) * u   # one pass: round(silu(g)) * u
         x = self.down_proj(act, residual=x) if self._res_epilogue(x, self.down_proj) else x + self.down_proj(act)
         return x
 
@@ -156,7 +201,7 @@ class DecoderLayer(nn.Module):
 
 
 class Decoder(nn.Module):
-    def __init__(self, name, device, dtype=torch.bfloat16, tenants=0, layers=None, seed=0):
+    def __init__(self, name, device, dtype=torch.bfloat16, tenants=0, layers=None, seed=0, fuse=True):
         super().__init__()
         cfg = CONFIGS[name]
         hid, inter, nl, heads, kvh, vocab = cfg
@@ -165,7 +210,7 @@ class Decoder(nn.Module):
         gen.manual_seed(seed)
         self.cfg, self.dtype, self.device_, self.tenants = cfg, dtype, device, tenants
         self.embed = nn.Embedding(vocab, hid, device=device, dtype=dtype)
-        self.layers = nn.ModuleList([DecoderLayer(cfg, device, dtype, gen, tenants) for _ in range(nl)])
+        self.layers = nn.ModuleList([DecoderLayer(cfg, device, dtype, gen, tenants, fuse) for _ in range(nl)])
         self.norm = RMSNorm(hid, dtype, device)
         self.lm_head = nn.Linear(hid, vocab, bias=False, device=device, dtype=dtype)
         for p in self.parameters():

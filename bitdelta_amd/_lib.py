@@ -27,6 +27,7 @@ SIGNATURES = {
                            _vp, _i64, _ci, _ci, _vp, _i64, _vp]),
     "bd_binary_linear": (_ci, [_vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _ci,
                                _i64, _i64, _ci, _ci, _vp, _i64, _vp]),
+    "bd_binary_linear_swiglu": (_ci, [_vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _ci, _vp]),
     "bd_binary_linear_decode": (_ci, [_vp, _vp, _vp, _ci, _ci, _vp, _vp, _ci, _ci, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _ci,
                                       _i64, _i64, _ci, _ci, _ci, _vp]),
     "bd_binary_linear_residual": (_ci, [_vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _ci,
@@ -49,6 +50,7 @@ SIGNATURES = {
     "bd_last_gemm_variant": (_ci, []),
     "bd_set_tile_group_m": (_ci, [_ci]),
     "bd_set_launch_chunking": (_ci, [_ci]),
+    "bd_set_tail_split": (_ci, [_ci]),
     "bd_set_decode_two_launch": (_ci, [_ci]),
     "bd_set_decode_wave_spec": (_ci, [_ci]),
     "bd_set_decode_small_lut": (_ci, [_ci]),

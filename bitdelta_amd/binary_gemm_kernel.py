@@ -158,6 +158,33 @@ def binary_linear(x, weight, mask, alpha, *, out_dtype=None, groups=1, residual=
     return y
 
 
+def binary_linear_swiglu(x, weight, mask, alpha):
+    """Prefill-size fused gate|up projection with SwiGLU in its epilogue (bd_binary_linear_swiglu): weight / mask describe the two
+    BinaryDiff projections `gate_proj` and `up_proj` stored as ONE projection with the output rows interleaved in blocks of 8
+    (serving_loop.FusedDeltaLinear(interleave8=True)), alpha (B or 1, 2) = (gate, up) scales.  Returns (B, M, N/2):
+    round(silu(round(gate))) * round(up) -- bit-identical to binary_linear followed by serving_ops.swiglu, one launch and no
+    [M, N] intermediate.  Raises BitDeltaHipError(BD_E_BAD_SHAPE) outside its envelope (M > 16, N % 16 == 0, K % 64 == 0, aligned rows)."""
+    require_gpu(x, weight, mask, alpha)
+    assert x.dim() == 3 and mask.dim() == 3 and weight.dim() == 2
+    B, M, K = x.shape
+    N = weight.shape[0]
+    assert weight.shape[1] == K and weight.stride(1) == 1 and weight.dtype == x.dtype
+    assert mask.dtype == torch.int32 and mask.is_contiguous() and mask.shape[1] * 32 == K and mask.shape[2] == N
+    assert mask.shape[0] in (1, B) and x.stride(2) == 1 and N % 16 == 0
+    alpha = alpha.detach()
+    if alpha.dtype != torch.float32 or not alpha.is_contiguous():
+        alpha = alpha.float().contiguous()
+    alpha = alpha.reshape(-1, 2)
+    assert alpha.shape[0] in (1, B)
+    sPb = 0 if (mask.shape[0] == 1 and B > 1) else mask.stride(0)
+    y = torch.empty((B, M, N // 2), device=x.device, dtype=x.dtype)
+    with torch.cuda.device(x.device):
+        check(lib().bd_binary_linear_swiglu(ptr(x), ptr(weight), ptr(mask), ptr(alpha), ptr(y), B, M, N, K, x.stride(0), x.stride(1),
+                                            weight.stride(0), sPb, 0 if alpha.shape[0] == 1 else 2, y.stride(0), y.stride(1),
+                                            DTYPE_CODE[x.dtype], stream_ptr()), "binary_linear_swiglu")
+    return y
+
+
 def tile_masks(mask):
     """Repack packed sign words [T, K/32, N] (the reference / diff.pt layout) into the tile-major order of the streaming decode
     kernel, [T, ceil(N/16), K/32, 16]: every 16-column tile's words become one contiguous run over k.  Done once per registered

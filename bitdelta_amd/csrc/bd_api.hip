@@ -22,6 +22,7 @@
 using namespace bd;
 
 static thread_local int g_forced_variant = -1;
+static thread_local int g_tail_split = 1;          // A/B hook (bd_set_tail_split)
 static thread_local int g_forced_group_m = 0;        // 0 = automatic tile order
 static thread_local int g_col16_small_lut = -1;      // sign LUT of the 16-column decode kernel: -1 auto, 1 = single 4-KiB table, 0 = 16-copy conflict-free
                                         // table whenever it fits.  Auto = 16 copies for delta-only launches (-16..18 % at 6-8 masks;
@@ -38,6 +39,7 @@ static thread_local int t_last_variant = -1;
 extern "C" int bd_version(void) { return 1; }
 extern "C" int bd_set_gemm_variant(int v) { g_forced_variant = v; return BD_OK; }
 extern "C" int bd_last_gemm_variant(void) { return t_last_variant; }
+extern "C" int bd_set_tail_split(int v) { g_tail_split = v ? 1 : 0; return BD_OK; }
 extern "C" int bd_set_tile_group_m(int g) { g_forced_group_m = g; return BD_OK; }
 extern "C" int bd_set_decode_two_launch(int on) { g_gemv_two_launch = on ? 1 : 0; return BD_OK; }
 extern "C" int bd_set_decode_wave_spec(int on) { g_gemv_wave_spec = on ? 1 : 0; return BD_OK; }
@@ -537,8 +539,9 @@ template <class Cfg> struct TileKernel<Cfg, 3> { static auto get() { return delt
 // SCHED 0 = single barrier per k-tile (bd_gemm_mfma.h; the small-M tiles), 1 = half-tile ping-pong (bd_gemm_pp.h),
 // 2 = full-tile ping-pong (bd_gemm_pf.h; the shipped delta-only schedule), 3 = one-pass fused, two accumulator sets (bd_gemm_fx.h).
 template <class Cfg, int SCHED = 0>
-int launch_tile(const Problem& q) {
-    const GemmParams p = make_params(q, Cfg::BM, Cfg::BN);
+int launch_tile(const Problem& q, int col0 = 0) {          // col0 > 0: only tile columns [col0, tiles_n) (launch_fused_tail_split)
+    GemmParams p = make_params(q, Cfg::BM, Cfg::BN);
+    if (col0 > 0) { p.tile_n0 = col0; p.tiles_n -= col0; if (p.tiles_n <= 0) return BD_OK; }
     auto kern = TileKernel<Cfg, SCHED>::get();
     static std::atomic<uint64_t> lds_done{0};
     if (!ensure_dyn_lds((const void*)kern, Cfg::LDS_BYTES, lds_done)) return BD_E_LAUNCH;
@@ -575,13 +578,16 @@ int launch_tile(const Problem& q) {
 
 // Four-wave persistent kernels (bd_gemm_w4.h): grid = min(batch x tiles, CUs) workgroups of 256 threads, each walking its share of the
 // (batch entry, tile) stream.
+// cols >= 0: only tile columns [0, cols) of the problem (the rest goes to another launch: launch_fused_tail_split)
 template <class Cfg>
-int launch_w4(const Problem& q) {
-    const GemmParams p = make_params(q, Cfg::BM, Cfg::BN);
+int launch_w4(const Problem& q, int cols = -1) {
+    GemmParams p = make_params(q, Cfg::BM, Cfg::BN);
+    if (cols >= 0) p.tiles_n = cols;
     auto kern = delta_gemm_w4_kernel<Cfg>;
     static std::atomic<uint64_t> lds_done{0};
     if (!ensure_dyn_lds((const void*)kern, Cfg::LDS_BYTES, lds_done)) return BD_E_LAUNCH;
     const long long total = (long long)p.tiles_m * p.tiles_n * q.B, cus = num_cus();
+    if (total <= 0) return BD_OK;
     dim3 grid((unsigned)(total < cus ? total : cus));
     hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, q.st, p);
     return launch_status();
@@ -619,6 +625,25 @@ inline int choose_fused_tile(const Problem& q) {
     const long long t8 = (q.M + 255) / 256 * tn * q.B, t9 = (q.M + 127) / 128 * tn * q.B;
     const double c8 = (double)((t8 + cus - 1) / cus), c9 = (double)((t9 + cus - 1) / cus) * 0.70;
     return c9 < c8 ? 9 : 8;
+}
+
+// Tail split of a multi-round fused launch (one mask, 16-bit output).  The persistent 256x128 kernel needs ceil(tiles / CUs) rounds; when
+// the last round is mostly empty (Llama-2-7B gate|up at 2048 rows: 1376 tiles = 5.4 rounds -> 6), the tile columns of the FULL rounds go
+// to it and the remaining columns to the 8-wave kernel on 128x128 tiles (twice as many, ~0.70 of a round each), launched behind it on
+// the same stream: 5 + 0.53 instead of 6 rounds.  Returns the number of 128-wide tile columns for the main launch, or -1 = no split.
+inline int fused_tail_split_cols(const Problem& q) {
+    if (q.B != 1) return -1;
+    const long long cus = num_cus();
+    const long long tm = (q.M + 255) / 256, tn = (q.N + 127) / 128, T = tm * tn;
+    if (T <= cus || T % cus == 0) return -1;
+    const long long full = T / cus;                       // full rounds
+    const long long n_main = full * cus / tm;             // whole tile columns inside them
+    const long long rem = tn - n_main;
+    if (n_main <= 0 || rem <= 0) return -1;
+    const double now = (double)((T + cus - 1) / cus);
+    const long long t_rem = ((q.M + 127) / 128) * rem;
+    const double split = (double)((n_main * tm + cus - 1) / cus) + (double)((t_rem + cus - 1) / cus) * 0.70;
+    return split < now - 0.2 ? (int)n_main : -1;
 }
 
 // Split-k for the one-pass fused kernel at mid-size M (16 < M <= 512: decode batches, speculative decoding, short prefills), where
@@ -673,6 +698,10 @@ int dispatch3(const Problem& q) {
     if (v > 400 && v <= 464) v = 400;        // 400 (+ KS): force the MFMA + LUT decode kernel
     if (v > 500 && v <= 564) v = 500;        // 500 (+ KS): force the no-split-k 16-column decode kernel
     if (v > 600 && v <= 664) v = 600;        // 600 (+ columns per block / 4): force the streaming decode kernel
+    if (q.epilogue == 1 && q.M > GEMV_MAX_M) {        // prefill-size SwiGLU launch (bd_binary_linear_swiglu): one kernel can do it
+        if (v >= 0 && v != 15) return BD_E_BAD_SHAPE;
+        v = 15;
+    }
     if (v < 0) {
         if (gemv_ok(q)) v = 200;
         else if (!fast_ok(q)) v = 100;
@@ -697,7 +726,8 @@ int dispatch3(const Problem& q) {
         else v = 3;
     } else {
         if ((v == 200 || v == 300 || v == 400 || v == 500 || v == 600) && !gemv_ok(q)) return BD_E_BAD_SHAPE;
-        if (v >= 0 && v <= 14 && !fast_ok(q)) return BD_E_BAD_SHAPE;
+        if (v >= 0 && v <= 15 && !fast_ok(q)) return BD_E_BAD_SHAPE;
+        if (v == 15 && (!FUSED || OUT_F32 || q.epilogue != 1)) return BD_E_BAD_SHAPE;
         if (v == 13 && FUSED) return BD_E_BAD_SHAPE;
         if (v == 14 && !FUSED) return BD_E_BAD_SHAPE;
         if ((v == 8 || v == 9 || v == 10 || v == 11 || v == 12) && !FUSED) return BD_E_BAD_SHAPE;
@@ -755,7 +785,19 @@ int dispatch3(const Problem& q) {
             if constexpr (!FUSED) return launch_w4<W4Cfg<DT, 256, 256, false, OUT_F32, 1>>(q);
             else return BD_E_BAD_SHAPE;
         case 14:     // four-wave persistent one-pass fused kernel, 256x128 tile, VALU sign expansion
-            if constexpr (FUSED) return launch_w4<W4Cfg<DT, 256, 128, true, OUT_F32, 0>>(q);      // (fp32 output: general-form epilogue only)
+            if constexpr (FUSED) {
+                if constexpr (!OUT_F32) {
+                    const int cols = (g_forced_variant < 0 && g_tail_split) ? fused_tail_split_cols(q) : -1;
+                    if (cols > 0) {
+                        const int rc = launch_w4<W4Cfg<DT, 256, 128, true, false, 0>>(q, cols);
+                        if (rc != BD_OK) return rc;
+                        return launch_tile<FxCfg<DT, 128, 128, 4, false, 1>, 3>(q, cols);      // same 128-wide tile columns
+                    }
+                }
+                return launch_w4<W4Cfg<DT, 256, 128, true, OUT_F32, 0>>(q);      // (fp32 output: general-form epilogue only)
+            } else return BD_E_BAD_SHAPE;
+        case 15:     // 14 with the SwiGLU epilogue (bd_binary_linear_swiglu: 8-interleaved gate|up pair, C has N/2 columns)
+            if constexpr (FUSED && !OUT_F32) return launch_w4<W4Cfg<DT, 256, 128, true, false, 0, 1>>(q);
             else return BD_E_BAD_SHAPE;
         case 1: return launch_tile<GemmCfg<DT, 128, 256, 1, 4, 4, FUSED, OUT_F32>>(q);
         case 2: return launch_tile<GemmCfg<DT, 64, 256, 1, 4, 4, FUSED, OUT_F32>>(q);
@@ -927,6 +969,23 @@ extern "C" int bd_binary_linear(const void* X, const void* W, const int32_t* P, 
                                 void* stream) {
     return binary_linear_impl(X, W, P, alpha, Y, B, M, N, K, sXb, sXm, ldw, sPb, sAlb, G, sYb, sYm, dtype, out_dtype, 0, 0, 0, ws,
                               ws_bytes, stream);
+}
+
+extern "C" int bd_binary_linear_swiglu(const void* X, const void* W, const int32_t* P, const float* alpha, void* Y, int B, int M, int N,
+                                       int K, int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb, int64_t sAlb, int64_t sYb, int64_t sYm,
+                                       int dtype, void* stream) {
+    if (B > 0 && M > 0 && N > 0 && !W) return BD_E_NULL;
+    if (M <= GEMV_MAX_M) return BD_E_BAD_SHAPE;                    // decode shapes: bd_binary_linear_decode_fused (packed sign layout)
+    if (N % 16 || K % 64 || sYm % 8 || sYb % 8 || !aligned16(Y)) return BD_E_BAD_SHAPE;
+    Problem q{};
+    q.A = X; q.P = P; q.C = Y; q.W = W; q.alpha = alpha;
+    q.B = B; q.M = M; q.N = N; q.K = K;
+    q.sAb = sXb; q.sAm = sXm; q.sPb = sPb; q.sCb = sYb; q.sCm = sYm; q.ldw = ldw; q.sAlb = sAlb;
+    q.G = 2; q.dtype = dtype; q.out_dtype = dtype; q.round_mode = 0; q.accumulate = 0;
+    q.epilogue = 1;
+    q.st = (hipStream_t)stream;
+    if (!fast_ok(q)) return BD_E_BAD_SHAPE;
+    return dispatch(q);
 }
 
 extern "C" int bd_binary_linear_decode(const void* X, const void* W, const int32_t* P, int mask_layout, int t_pad, const float* alpha,

@@ -30,6 +30,7 @@
 // before B(c).
 #pragma once
 #include "bd_gemm_mfma.h"
+#include "bd_serving.h"      // swiglu1 (the SwiGLU epilogue shares bd_srv_swiglu's arithmetic)
 
 namespace bd {
 
@@ -39,9 +40,11 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
     if constexpr (I < N) { f(IC<I>{}); static_for<I + 1, N>(f); }
 }
 
-template <int DT_, int BM_, int BN_, bool FUSED_, bool OUT_F32_, int OPT_ = 0>
+// EPI_ = 1 (fused, 16-bit output only): SwiGLU epilogue over an 8-interleaved gate|up projection -- C has N/2 columns
+template <int DT_, int BM_, int BN_, bool FUSED_, bool OUT_F32_, int OPT_ = 0, int EPI_ = 0>
 struct W4Cfg {
-    static constexpr int DT = DT_, BM = BM_, BN = BN_, NS = 3, OPT = OPT_;
+    static constexpr int DT = DT_, BM = BM_, BN = BN_, NS = 3, OPT = OPT_, EPI = EPI_;
+    static_assert(EPI_ == 0 || (FUSED_ && !OUT_F32_), "SwiGLU epilogue: fused kernel, 16-bit output");
     static constexpr bool FUSED = FUSED_, OUT_F32 = OUT_F32_;
     static constexpr int WAVES_M = 2, WAVES_N = 2, NW = 4, NT = 256;
     static constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -139,7 +142,10 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, f32x16_t (&acc)
     // it put `s_waitcnt vmcnt(0)` in front of the first reuse of that register INSIDE the k loop, which drains the LDS-DMA ring every
     // k-tile (measured: 2970 instead of 2355 cycles per k-tile on the fused kernel).
     float a_col[TN];
-    if (p.gsz >= p.N) {
+    if constexpr (Cfg::EPI == 1) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) a_col[j] = 0.f;
+    } else if (p.gsz >= p.N) {
         const float a0 = al ? al[0] : 0.f;
 #pragma unroll
         for (int j = 0; j < TN; ++j) a_col[j] = a0;
@@ -175,6 +181,64 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, f32x16_t (&acc)
     };
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");    // MFMA result -> accvgpr_read distance for the last MFMAs of the k loop (asm is not padded)
 
+    if constexpr (Cfg::EPI == 1) {
+        // ---- SwiGLU epilogue (fast form only; the host checks alignment).  Output rows of W are interleaved in blocks of 8
+        //      ([g0..7 | u0..7 | g8..15 | ...], G = 2 scales: alpha[0] gate, alpha[1] up), so in this accumulator layout (lane <-> column)
+        //      lanes 0-7 / 16-23 of a 32-column block hold gate columns and lanes 8-15 / 24-31 the matching up columns: both are rounded
+        //      to the output type as the separate Linear would have stored them, the up value crosses 8 lanes by DPP (row_ror:8), and the
+        //      gate lanes stage round(silu(g)) * u (swiglu1: bd_srv_swiglu's arithmetic) -- 16 output columns per 32-column block.
+        typedef short v4s_t __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) v4s_t* lds_v4s_p;
+        static_assert(TN == 2 && Cfg::STG_PW >= 2048, "one chunk = both column blocks = 32 output columns");
+        const float a_g = al[0], a_u = al[1];                        // (two scalar loads + a select: no VMEM load, see a_col above)
+        const float a_gu = (l31 & 8) ? a_u : a_g;
+        const bool is_gate = !(l31 & 8);
+        const int no = (l31 & 7) + ((l31 >> 4) << 3);                   // output column inside the block's 16
+        uint32_t wr_off[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wr_off[q] = no * 64 + (((2 * q + h) ^ ((no >> 1) & 7)) * 8);
+        const int G = lane >> 4, t = lane & 15, js = t >> 2, cs = t & 3;
+        uint32_t rd_off[2][2];
+#pragma unroll
+        for (int B = 0; B < 2; ++B)
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh)
+                rd_off[B][mh] = (8 * G + 4 * B + js) * 64 + (((4 * mh + cs) ^ ((4 * G + 2 * B + (js >> 1)) & 7)) * 8);
+        const int NO = p.N >> 1;
+        static_for<0, TM>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            static_for<0, 8>([&](auto tc) {
+                constexpr int jj = decltype(tc)::value / 4, q = decltype(tc)::value % 4;
+                __builtin_amdgcn_sched_barrier(0);
+                uint32_t o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = 0.f;
+                    if (e == 0) v = __builtin_fmaf(a_gu, rd(acc[2 * jj + 1][i][4 * q + 0]), rd(acc[2 * jj][i][4 * q + 0]));
+                    if (e == 1) v = __builtin_fmaf(a_gu, rd(acc[2 * jj + 1][i][4 * q + 1]), rd(acc[2 * jj][i][4 * q + 1]));
+                    if (e == 2) v = __builtin_fmaf(a_gu, rd(acc[2 * jj + 1][i][4 * q + 2]), rd(acc[2 * jj][i][4 * q + 2]));
+                    if (e == 3) v = __builtin_fmaf(a_gu, rd(acc[2 * jj + 1][i][4 * q + 3]), rd(acc[2 * jj][i][4 * q + 3]));
+                    const float r16 = round16<DT>(v);
+                    const float other = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r16), 0x128, 0xf, 0xf, true));
+                    o[e] = swiglu1<DT>(r16, other);
+                }
+                if (is_gate) *(u32x2_t*)(buf + wr_off[q] + jj * 1024) = u32x2_t{o[0] | (o[1] << 16), o[2] | (o[3] << 16)};
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            static_for<0, 2>([&](auto mc) {
+                constexpr int mh = decltype(mc)::value;
+                const v4s_t ra = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(buf + rd_off[0][mh]));
+                const v4s_t rb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(buf + rd_off[1][mh]));
+                const u32x2_t a2 = __builtin_bit_cast(u32x2_t, ra), b2 = __builtin_bit_cast(u32x2_t, rb);
+                const u32x4_t val = u32x4_t{a2.x, a2.y, b2.x, b2.y};
+                const int mm = m0 + wm * WM + i * 32 + 16 * mh + t;
+                const int n = ((n0 + wn * WN) >> 1) + 8 * G;
+                if (inside || (mm < p.M && n < NO)) *(u32x4_t*)(p.C + (c_b + (long long)mm * p.sCm + n) * 2) = val;
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        });
+        return;
+    }
     if constexpr (!Cfg::OUT_F32) if (fast) {
         // ---- 16-bit fast form: transposed staging + hardware transpose read (mapping of ds_read_b64_tr_b16 probed on the device,
         //      tests/native/probes/tr_probe.hip: inside a 16-lane group, output lane t gets element (t & 3) of the quads addressed by source
@@ -214,7 +278,8 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, f32x16_t (&acc)
             auto store_rows = [&](auto guardc) {
                 constexpr bool GUARD = decltype(guardc)::value != 0;
                 static_for<0, JC * 2>([&](auto uc) {
-                    constexpr int u = decltype(uc)::value / 2, mh = decltype(uc)::value % 2;
+                    // u fastest: the 64-byte halves of a 128-byte line leave back to back
+                    constexpr int u = decltype(uc)::value % JC, mh = decltype(uc)::value / JC;
                     const v4s_t ra = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(buf + rd_off[0][mh] + u * 2048));
                     const v4s_t rb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(buf + rd_off[1][mh] + u * 2048));
                     const u32x2_t a2 = __builtin_bit_cast(u32x2_t, ra), b2 = __builtin_bit_cast(u32x2_t, rb);
@@ -232,7 +297,9 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, f32x16_t (&acc)
                                 val[d] = pack2(lo, hi);
                             }
                         }
-                        __builtin_nontemporal_store(val, dst);
+                        // plain stores: a wave-instruction covers 16 rows x 64 bytes, and the nt policy made the L2 forward those half lines
+                        // un-merged (WRITE_SIZE 45.8 MB instead of 32.0 MB per 4096^2 output, +1 % time; profiles/r03_w4_store_policy.txt)
+                        *dst = val;
                     }
                 });
             };

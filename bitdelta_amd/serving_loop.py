@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .binary_gemm_kernel import (binary_linear, binary_linear_decode, decode_chain, decode_shape_ok, fused_norm_ok,
+from .binary_gemm_kernel import (binary_linear, binary_linear_swiglu, binary_linear_decode, decode_chain, decode_shape_ok, fused_norm_ok,
                                  pack_decode_masks, tenant_linear, tile_weight)
 from .diff import binarize
 from . import serving_ops as ops
@@ -58,7 +58,8 @@ class FusedDeltaLinear(nn.Module):
 
     tile_decode_weight = True     # keep a tile-major decode copy of the base weight (class switch)
 
-    def __init__(self, weights, masks, coeffs, interleave8=False):
+    def __init__(self, weights, masks, coeffs, interleave8=False, decode_copies=True):
+        """decode_copies=False skips the decode-only copies (packed sign words, tile-major base weight): a prefill-only user"""
         super().__init__()
         widths = [w.shape[0] for w in weights]
         self.widths = widths
@@ -85,7 +86,7 @@ class FusedDeltaLinear(nn.Module):
         self.groups = alpha.shape[1]
         # decode copy of the sign words in the streaming kernel's packed order (tenants interleaved, natural k order); prefill keeps
         # the reference layout
-        self.register_buffer("mask_packed", pack_decode_masks(self.mask) if self.mask.shape[0] <= 8 else None)
+        self.register_buffer("mask_packed", pack_decode_masks(self.mask) if (decode_copies and self.mask.shape[0] <= 8) else None)
         # ... and of the base weight in the kernel's tile-major order (one contiguous 4-KiB block per stage; +2 bytes per weight of HBM)
         N, K = self.weight.shape
         tiled = self.mask_packed is not None and self.tile_decode_weight and N % 16 == 0 and K % 128 == 0
@@ -126,6 +127,16 @@ class FusedDeltaLinear(nn.Module):
                                         norm_weight=norm_weight, eps=eps, swiglu=True, weight_tiled=wt)
         return binary_linear_decode(x, self.weight, self.mask_packed, self.alpha, layout="packed", groups=self.groups,
                                     norm_weight=norm_weight, eps=eps)
+
+    def swiglu_ok(self, x):
+        """True when forward_swiglu can take this input: an interleaved gate|up pair at prefill size on the fused GEMM's fast path"""
+        B, M, K = x.shape
+        return self.interleave8 and M > 16 and K % 64 == 0 and x.data_ptr() % 16 == 0 and x.stride(2) == 1 and \
+            x.stride(0) % 8 == 0 and x.stride(1) % 8 == 0 and (self.mask.shape[0] in (1, B))
+
+    def forward_swiglu(self, x):
+        """act_fn(gate_proj(x)) * up_proj(x) of the MLP in ONE launch at prefill size (bd_binary_linear_swiglu): [B, M, inter]"""
+        return binary_linear_swiglu(x, self.weight, self.mask, self.alpha_pair)
 
     def split(self, y):
         """per-projection outputs of y = forward(x)  (undoes the interleaved row order)"""
@@ -290,6 +301,8 @@ class TenantDecoder(nn.Module):
             act = layer.gate_up.forward_fused(x, layer.norm2, self.eps, swiglu=True)   # RMSNorm -> gate|up -> SwiGLU: one launch
         elif fuse and layer.gate_up.interleave8 and layer.gate_up._decode_ok(x):
             act = layer.gate_up.forward_fused(self._norm(x, layer.norm2), None, self.eps, swiglu=True)   # gate|up -> SwiGLU: one launch
+        elif self.fast_glue and layer.gate_up.swiglu_ok(x):
+            act = layer.gate_up.forward_swiglu(self._norm(x, layer.norm2))       # prefill: gate|up -> SwiGLU in the GEMM's epilogue
         else:
             gu = layer.gate_up(self._norm(x, layer.norm2))
             if S <= 16 and self.fast_glue and inter % 8 == 0:

@@ -99,6 +99,18 @@ int bd_binary_linear_decode(const void* X, const void* W, const int32_t* P, int 
                             int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb, int64_t sAlb, int G,
                             int64_t sYb, int64_t sYm, int dtype, int out_dtype, int accumulate, void* stream);
 
+/* PREFILL-size fused gate|up projection with the MLP's activation in its epilogue (M > 16; the decode-size form is
+ * bd_binary_linear_decode_fused with epilogue = 1).  W [N, K] / P [B or 1, K/32, N] (reference sign layout) / alpha [B or 1, 2] describe
+ * the gate_proj and up_proj BinaryDiff modules of one MLP (the two Linears bitdelta/diff.py:60-64 selects by name `mlp.*proj`) stored
+ * as ONE projection whose output rows are interleaved in blocks of 8 ([g0..7 | u0..7 | g8..15 | ...]); Y [B, M, N/2] receives
+ *     round(silu(round(gate))) * round(up),   gate / up = X . W^T + alpha * (X . S)  (fp32, one rounding each)
+ * i.e. exactly bd_binary_linear followed by bd_srv_swiglu (bit-identical), without the [M, N] round trip through HBM and the second
+ * launch.  N % 16 == 0, K % 64 == 0, 16-byte aligned rows; anything else returns BD_E_BAD_SHAPE and the caller runs the two launches. */
+int bd_binary_linear_swiglu(const void* X, const void* W, const int32_t* P, const float* alpha, void* Y,
+                            int B, int M, int N, int K,
+                            int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb, int64_t sAlb,
+                            int64_t sYb, int64_t sYm, int dtype, void* stream);
+
 /* packed-layout decode Linear with the neighbouring glue of a decoder layer FUSED into the launch (bit-identical to the separate
  * launches; what disappears is a ~4 us kernel + a launch gap per fused op, on a step of a few hundred 15-65 us Linears):
  *   norm_w != NULL (optional when epilogue = 1): X is the UN-NORMALISED residual stream; every block computes HF RMSNorm
@@ -215,7 +227,12 @@ int bd_merge_delta(void* W, int64_t ldw, const int32_t* P, const float* coeff, i
  * 300 (+ KS) = the VALU sign-flip kernel, 400 (+ KS) = the MFMA + sign-LUT kernel and 500 (+ KS) = the no-split-k kernel
  * (16 columns x all of k per block).  Variants 4 / 6 / 7 and fused 0 / 5 (rejected schedules kept as A/B references) exist
  * only in builds with -DBD_AB_VARIANTS (tests/native/bd_harness); the shipped library answers BD_E_BAD_SHAPE for them.
- * A forced variant whose preconditions fail returns BD_E_BAD_SHAPE instead of silently falling back. */
+ * 13 / 14 = the FOUR-WAVE PERSISTENT kernels (bd_gemm_w4.h: one wave per SIMD, 16 AGPR accumulators, grid = min(tiles, CUs)):
+ * 13 delta-only on 256x256 tiles (automatic once those tiles fill >= 80 % of the CU-rounds), 14 fused on 256x128 tiles (automatic
+ * wherever 8 was; with fp32 output only its general-form epilogue); 15 = 14 with the SwiGLU epilogue (bd_binary_linear_swiglu only).
+ * A forced variant whose preconditions fail returns BD_E_BAD_SHAPE instead of silently falling back.
+ * The bd_set_* entry points below are TUNING / TEST HOOKS: thread-local, not part of the stable interface a reference-side binding
+ * needs (INTEGRATION.md binds none of them), and free to change between versions. */
 int bd_set_gemm_variant(int variant);
 /* which family the LAST call on this thread dispatched to (same codes as above) */
 int bd_last_gemm_variant(void);
@@ -224,6 +241,9 @@ int bd_last_gemm_variant(void);
 int bd_set_tile_group_m(int group_m);
 /* A/B hook: 1 = problems of more than one tile per CU are issued as consecutive single-round launches; 0 (default) = one launch */
 int bd_set_launch_chunking(int on);
+/* A/B hook: 1 (default) = a fused launch whose last round of 256x128 tiles would be mostly empty hands the tile columns of that round to
+ * the 8-wave kernel on 128x128 tiles (a second launch on the same stream; same results); 0 = always one launch */
+int bd_set_tail_split(int on);
 /* 1 (default) = the decode path sums its split-k partials with a second launch (gemv_reduce_kernel); 0 = in-launch ticket
  * reduction (single launch; measured equal within noise, and it needs the zeroed ticket area described at bd_delta_bmm) */
 int bd_set_decode_two_launch(int on);

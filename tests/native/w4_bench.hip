@@ -183,8 +183,8 @@ int main(int argc, char** argv) {
 
     if (what.rfind("soak", 0) == 0) {      // soak<variant>: run one kernel back to back for `reps` x 0.1 s (power / clock sampling from outside)
         const int M = Ms[0];
-        const int v = atoi(what.c_str() + 4);
-        GemmParams p0 = params(M, N, v >= 10, C0);   // (fused variants: 10, 11, 12)
+        const int v = atoi(what.c_str() + (what.rfind("soakn", 0) == 0 ? 5 : 4));
+        GemmParams p0 = params(M, N, v >= 10 && v < 20, C0);   // (fused variants: 10, 11, 12)
         using OldD = GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 1>;
         using OldF = FxCfg<DT_BF16, 256, 128, 3, false, 1>;
         auto one = [&] {
@@ -202,6 +202,12 @@ int main(int argc, char** argv) {
             else if (v == 10) launch_old<OldF>(delta_gemm_fx_kernel<OldF>, p0, 1, 0);
             else launch_w4<W4Cfg<DT_BF16, 256, 128, true, false, 0>>(p0, 1, 0);
         };
+        if (what.rfind("soakn", 0) == 0) {        // soakn<variant>: exactly `reps` launches (for rocprofv3 passes)
+            for (int i = 0; i < reps; ++i) one();
+            CK(hipDeviceSynchronize());
+            printf("ran %d launches of variant %d at M=%d\n", reps, v, M);
+            return 0;
+        }
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         long long n = 0; float total = 0;
         CK(hipEventRecord(e0, 0));

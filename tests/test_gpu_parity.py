@@ -374,6 +374,42 @@ def test_four_wave_persistent_kernels(bd, oracle):
         assert ok and same >= 0.99 and (wide[:, :, :off] == 0).all() and (wide[:, :, off + 256:] == 0).all()
 
 
+def test_prefill_swiglu_epilogue_is_the_two_launches(bd, oracle):
+    """bd_binary_linear_swiglu (fused gate|up GEMM + SwiGLU epilogue, bd_gemm_w4.h EPI = 1) == bd_binary_linear followed by
+    bd_srv_swiglu, bit for bit, and both agree with the oracle's Linear pushed through the same activation arithmetic."""
+    from bitdelta_amd.binary_gemm_kernel import binary_linear_swiglu
+    from bitdelta_amd import serving_ops as ops
+    from bitdelta_amd import _lib
+    from bitdelta_amd.serving_loop import FusedDeltaLinear
+    L = _lib.lib()
+    for dt in (torch.bfloat16, torch.float16):
+        for B, M, K, inter, T in ((1, 300, 256, 264, 1), (2, 130, 64, 1032, 2), (3, 17, 128, 136, 1), (1, 700, 512, 2752, 1)):
+            g = torch.Generator().manual_seed(B * 7 + M)
+            x = torch.randn(B, M, K, generator=g).to(dt)
+            ws, ms, cs = [], [], []
+            for _ in range(2):
+                w = (torch.randn(inter, K, generator=g) * 0.02).to(dt)
+                ws.append(w.cuda())
+                ms.append(torch.randint(-2 ** 31, 2 ** 31 - 1, (T, K // 32, inter), generator=g, dtype=torch.int64).to(torch.int32).cuda())
+                cs.append((torch.rand(T, generator=g) * 2e-4 + 3e-4).cuda())
+            f = FusedDeltaLinear(ws, ms, cs, interleave8=True, decode_copies=False)
+            assert f.swiglu_ok(x.cuda())
+            got = f.forward_swiglu(x.cuda())
+            assert L.bd_last_gemm_variant() == 15 and got.shape == (B, M, inter)
+            two = ops.swiglu_interleaved8(f(x.cuda()))
+            assert torch.equal(got, two)
+            # oracle: the two projections separately, then round(silu(round(g))) * round(u)
+            go = oracle.binary_linear(x, ws[0].cpu(), ms[0].cpu(), cs[0].cpu().reshape(T, 1), out_dtype=torch.float32).to(dt).float()
+            uo = oracle.binary_linear(x, ws[1].cpu(), ms[1].cpu(), cs[1].cpu().reshape(T, 1), out_dtype=torch.float32).to(dt).float()
+            want = ((go / (1 + torch.exp(-go))).to(dt).float() * uo).to(dt)
+            d = (got.cpu().float() - want.float()).abs()
+            tol = (go.abs() * uo.abs() + uo.abs() + go.abs()) * (2 ** -9 if dt == torch.float16 else 2 ** -6) + 1e-4
+            assert (d <= tol).all() and (got.cpu() == want).float().mean().item() >= 0.97
+    with pytest.raises(Exception):          # decode-size launches are refused (their fused form is bd_binary_linear_decode_fused)
+        binary_linear_swiglu(torch.zeros(1, 8, 64, device="cuda", dtype=torch.bfloat16), torch.zeros(32, 64, device="cuda", dtype=torch.bfloat16),
+                             torch.zeros(1, 2, 32, device="cuda", dtype=torch.int32), torch.ones(1, 2, device="cuda"))
+
+
 def test_delta_bmm_alpha_accumulate_and_groups(bd, oracle):
     a, p, w, _ = rand_problem(2, 150, 256, 512, torch.bfloat16, 2, seed=11)
     alpha = torch.tensor([[3e-4, 4e-4, 5e-4, 6e-4], [1e-3, 2e-3, 3e-3, 4e-3]])
