@@ -327,14 +327,12 @@ def run_mt_decode(dev, timer, model_name, tenants, kv_len, steps, warmup, layers
     ab = None
     if ab_glue and graph_ms is not None:
         # same process, same box, alternating: the step with RMSNorm / SwiGLU folded into the Linear launches vs separate glue launches
-        ab = {"persistent_chain_ms": [], "fused_glue_ms": [], "fused_gateup_only_ms": [], "swiglu_epilogue_only_ms": [], "separate_glue_ms": []}
+        ab = {"fused_glue_ms": [], "fused_gateup_only_ms": [], "swiglu_epilogue_only_ms": [], "separate_glue_ms": []}
         runners = {}
-        keep = (dec.persistent, dec.fuse_glue, dec.fuse_qkv_norm, dec.fuse_gateup_norm)
-        for name, pers, flag, qn, gn in (("persistent_chain_ms", True, True, True, True), ("fused_glue_ms", False, True, True, True),
-                                         ("fused_gateup_only_ms", False, True, False, True),
-                                         ("swiglu_epilogue_only_ms", False, True, False, False),
-                                         ("separate_glue_ms", False, False, True, True)):
-            dec.persistent, dec.fuse_glue, dec.fuse_qkv_norm, dec.fuse_gateup_norm = pers, flag, qn, gn
+        keep = (dec.fuse_glue, dec.fuse_qkv_norm, dec.fuse_gateup_norm)
+        for name, flag, qn, gn in (("fused_glue_ms", True, True, True), ("fused_gateup_only_ms", True, False, True),
+                                   ("swiglu_epilogue_only_ms", True, False, False), ("separate_glue_ms", False, True, True)):
+            dec.fuse_glue, dec.fuse_qkv_norm, dec.fuse_gateup_norm = flag, qn, gn
             restore()
             runners[name] = dec._graph_runner(st)
         for _ in range(3):
@@ -342,7 +340,7 @@ def run_mt_decode(dev, timer, model_name, tenants, kv_len, steps, warmup, layers
                 restore()
                 run()
                 ab[name].append(bdd.timed_region(run, steps, device_sync=torch.cuda.synchronize) / steps * 1e3)
-        dec.persistent, dec.fuse_glue, dec.fuse_qkv_norm, dec.fuse_gateup_norm = keep
+        dec.fuse_glue, dec.fuse_qkv_norm, dec.fuse_gateup_norm = keep
         # shipped defaults with the row-major base weight instead of its tile-major decode copy
         from bitdelta_amd.serving_loop import FusedDeltaLinear
         FusedDeltaLinear.use_tiled = False

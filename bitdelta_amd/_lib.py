@@ -34,8 +34,6 @@ SIGNATURES = {
                                         _i64, _i64, _ci, _ci, _vp, _i64, _vp]),
     "bd_tenant_linear": (_ci, [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _i64, _ci, _ci, _vp]),
     "bd_srv_rmsnorm": (_ci, [_vp, _vp, _vp, _ci, _ci, _i64, _i64, _i64, _ci, ctypes.c_float, _ci, _vp]),
-    "bd_decode_chain": (_ci, [_vp, _ci, _ci, _ci, _ci, _vp, _vp]),
-    "bd_decode_chain_sync_bytes": (_i64, []),
     "bd_srv_swiglu": (_ci, [_vp, _vp, _vp, _ci, _ci, _i64, _i64, _i64, _ci, _ci, _vp]),
     "bd_binary_linear_decode_fused": (_ci, [_vp, _vp, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _ci,
                                             _i64, _i64, _ci, _ci, _ci, _vp, _i64, ctypes.c_float, _ci, _vp]),
@@ -105,15 +103,6 @@ def stream_ptr():
 
 def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
-
-
-class ChainPhase(ctypes.Structure):
-    """bd_chain_phase_t of include/bitdelta_hip.h"""
-    _fields_ = [("X", ctypes.c_void_p), ("W", ctypes.c_void_p), ("P", ctypes.c_void_p), ("alpha", ctypes.c_void_p),
-                ("Y", ctypes.c_void_p), ("residual", ctypes.c_void_p), ("norm_w", ctypes.c_void_p),
-                ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("G", ctypes.c_int32), ("kind", ctypes.c_int32),
-                ("ldw", ctypes.c_int64), ("sX", ctypes.c_int64), ("sY", ctypes.c_int64), ("sR", ctypes.c_int64),
-                ("s_alpha", ctypes.c_int64), ("s_norm", ctypes.c_int64), ("eps", ctypes.c_float), ("reserved", ctypes.c_int32)]
 
 
 _WORKSPACES = {}          # (device index, stream handle) -> [scratch tensors, newest (largest) last]

@@ -391,70 +391,3 @@ def binary_bmm(a, b, n_bits=32, activation="", *, round_mode=1, out_dtype=None):
     assert a.device == b.device, "A and B must be on the same device"
     # output: non-differentiable tensor of a.dtype, fp32 accumulate -> fp16 -> a.dtype (reference :287, :314)
     return delta_bmm(a, _words32(b, n_bits), round_mode=round_mode, out_dtype=out_dtype)
-
-
-_CHAIN_SYNC_OFF = 8192
-
-
-def decode_chain(phases, *, tenants):
-    """One persistent launch for a chain of decode Linears (include/bitdelta_hip.h: bd_decode_chain).
-
-    phases: 3 or 4 dicts in the order [o, gate|up, down(, q|k|v of the next layer)] with keys
-        x (T,1,K), weight (N,K), mask_packed (pack_decode_masks), alpha fp32 (T,G), out (T,1,N or N/2) -- preallocated --, and
-        optionally residual (T,1,N) [plain phases], norm_weight (T or 1,K) + eps [norm phases]; kind is implied by the position.
-    Bit-identical to the corresponding binary_linear_decode calls.  Raises on shapes outside the envelope."""
-    from ._lib import ChainPhase, workspace
-    import ctypes
-    assert len(phases) in (3, 4)
-    kinds = (0, 2, 0, 1)
-    arr = (ChainPhase * len(phases))()
-    keep = []
-    t_pad = phases[0]["mask_packed"].shape[4]
-    dtype = phases[0]["x"].dtype
-    dev = phases[0]["x"].device
-    for i, ph in enumerate(phases):
-        x, w, pk, al, out = ph["x"], ph["weight"], ph["mask_packed"], ph["alpha"], ph["out"]
-        require_gpu(x, w, pk, al, out, ph.get("residual"), ph.get("norm_weight"))
-        T, M, K = x.shape
-        N = w.shape[0]
-        assert M == 1 and T == tenants and x.stride(2) == 1 and w.stride(1) == 1 and w.shape[1] == K and x.dtype == dtype == w.dtype
-        assert pk.dtype == torch.int32 and pk.is_contiguous() and pk.shape == (N // 16, K // 128, 4, 16, t_pad)
-        al = al.detach()
-        if al.dtype != torch.float32 or not al.is_contiguous():
-            al = al.float().contiguous()
-        al = al.reshape(-1, al.shape[-1]) if al.dim() > 1 else al.reshape(-1, 1)
-        keep.append(al)
-        G = al.shape[1]
-        n_out = N // 2 if kinds[i] == 2 else N
-        assert out.shape == (T, 1, n_out) and out.dtype == dtype and out.stride(2) == 1
-        c = arr[i]
-        c.X, c.W, c.P, c.alpha, c.Y = ptr(x), ptr(w), ptr(pk), ptr(al), ptr(out)
-        res, nw = ph.get("residual"), ph.get("norm_weight")
-        c.residual = ptr(res) if res is not None else None
-        c.norm_w = ptr(nw) if nw is not None else None
-        assert (nw is not None) == (kinds[i] != 0) and (res is None or kinds[i] == 0)
-        if res is not None:
-            assert res.shape == (T, 1, N) and res.dtype == dtype and res.stride(2) == 1
-        if nw is not None:
-            assert nw.dim() == 2 and nw.shape[1] == K and nw.shape[0] in (1, T) and nw.dtype == dtype and nw.stride(1) == 1
-        c.N, c.K, c.G, c.kind = N, K, G, kinds[i]
-        c.ldw, c.sX, c.sY = w.stride(0), x.stride(0), out.stride(0)
-        c.sR = res.stride(0) if res is not None else 0
-        c.s_alpha = 0 if (al.shape[0] == 1 and T > 1) else G
-        c.s_norm = 0 if (nw is None or (nw.shape[0] == 1 and T > 1)) else nw.stride(0)
-        c.eps = float(ph.get("eps", 1e-5))
-    # epoch word + arrival flags: zero-filled once, then owned by the chain kernel.  They live in the head of the stream's persistent
-    # scratch (bytes 8192 .. 12351: past the decode-attention tickets, before anything that holds partial sums)
-    ws, _ = workspace(16384, dev, zeroed=True)
-    with torch.cuda.device(dev):
-        check(lib().bd_decode_chain(ctypes.cast(arr, ctypes.c_void_p), len(phases), tenants, t_pad, DTYPE_CODE[dtype],
-                                    ctypes.c_void_p(ws.data_ptr() + _CHAIN_SYNC_OFF), stream_ptr()), "decode_chain")
-    return [ph["out"] for ph in phases]
-
-
-def decode_chain_error(device):
-    """non-zero if a persistent chain launch on this (device, current stream) gave up at a grid barrier (diagnostic; synchronises)"""
-    from ._lib import workspace
-    ws, _ = workspace(16384, device, zeroed=True)
-    return int(ws[_CHAIN_SYNC_OFF:_CHAIN_SYNC_OFF + 32].view(torch.int32)[1].item())
-

@@ -14,7 +14,6 @@
 #include "bd_gemm_w4.h"
 #include "bd_gemv.h"
 #include "bd_gemv_stream.h"
-#include "bd_gemv_chain.h"
 #include "bd_serving.h"
 #include <algorithm>
 #include <atomic>
@@ -1006,100 +1005,6 @@ extern "C" int bd_binary_linear_decode_fused(const void* X, const void* W, const
     if (B < 1 || M < 1 || N < 1 || K < 1) return BD_E_BAD_SHAPE;
     return binary_linear_impl(X, W, P, alpha, Y, B, M, N, K, sXb, sXm, ldw, sPb, sAlb, G, sYb, sYm, dtype, out_dtype, accumulate, 2,
                               t_pad, nullptr, 0, stream, norm_w, s_norm, eps, epilogue);
-}
-
-// ------------------------------------------------------------------ persistent chain of decode Linears (bd_gemv_chain.h)
-// stages in flight per wave.  What crosses a phase boundary should cover the barrier + reload latency behind it (~8 us ~ 8 stages
-// chip-wide), and 6 is the most the 6-bit vmcnt allows a plain phase (5 x 10 loads outstanding) -- but 6 makes every phase's loop
-// ~10 % slower (as the stream kernel's own A/B found) and the step went 5.91 -> 6.63 ms: 4 it is.
-constexpr int CHAIN_NS = 4;
-template <int DT, int NM, int NS>
-static int launch_chain_inst(const ChainParams& cp, int grid, int lds, hipStream_t st) {
-    auto kern = decode_chain_kernel<DT, NM, NS>;
-    static std::atomic<uint64_t> lds_done{0};
-    if (!ensure_dyn_lds((const void*)kern, STREAM_LDS_MAX, lds_done)) return BD_E_LAUNCH;
-    // every block must be resident at once (grid barriers): one block per CU by LDS size, grid <= CUs, and the occupancy query
-    // must confirm that the kernel fits at all
-    static std::atomic<uint64_t> occ_ok{0};
-    const int dev = current_device();
-    const uint64_t bit = dev < MAX_DEVICES ? (1ull << dev) : 0;
-    if (!(bit && (occ_ok.load(std::memory_order_acquire) & bit))) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, (size_t)lds) != hipSuccess || nb < 1) return BD_E_LAUNCH;
-        if (bit) occ_ok.fetch_or(bit, std::memory_order_release);
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), (size_t)lds, st, cp);
-    return launch_status();
-}
-
-extern "C" int64_t bd_decode_chain_sync_bytes(void) { return CHAIN_SYNC_BYTES; }
-
-extern "C" int bd_decode_chain(const bd_chain_phase_t* phases, int n_phases, int tenants, int t_pad, int dtype, void* sync,
-                               void* stream) {
-    if (!phases || !sync) return BD_E_NULL;
-    if (n_phases != 3 && n_phases != 4) return BD_E_BAD_SHAPE;
-    if (dtype != BD_F16 && dtype != BD_BF16) return BD_E_BAD_DTYPE;
-    // (instantiated for the multi-tenant packs only -- 4, 6 or 8 dwords per column; one or two tenants run the separate launches)
-    const bool tp_ok = t_pad == 4 || t_pad == 6 || t_pad == 8;
-    if (!tp_ok || tenants < 1 || tenants > t_pad || !aligned16(sync) || num_cus() > 1024) return BD_E_BAD_SHAPE;
-    static const int kinds[4] = {0, 2, 0, 1};
-    const int ns = CHAIN_NS;
-    const int cus = num_cus();
-    const int grid = cus;
-    ChainParams cp{};
-    cp.nph = n_phases; cp.R = tenants; cp.tp = (uint32_t)t_pad; cp.sync = (unsigned*)sync;
-#ifdef BD_CHAIN_TRACE
-    cp.trace = (unsigned long long*)((char*)sync + CHAIN_SYNC_BYTES);      // the probe's buffer follows the sync area (caller: + 64 KiB)
-#else
-    cp.trace = nullptr;
-#endif
-    cp.xs_off = (uint32_t)STREAM_XS_OFF; cp.xrow = 0;
-    const int64_t lim = (1ll << 31) - 64;
-    for (int i = 0; i < n_phases; ++i) {
-        const bd_chain_phase_t& h = phases[i];
-        ChainPhase& q = cp.ph[i];
-        if (h.kind != kinds[i]) return BD_E_BAD_SHAPE;
-        if (!h.X || !h.W || !h.P || !h.alpha || !h.Y) return BD_E_NULL;
-        if (h.N < 16 || h.N % 16 || h.K % 128 || h.K < 512 * ns || h.G < 1 || h.N % h.G) return BD_E_BAD_SHAPE;
-        if (h.kind == 2 && h.G != 2) return BD_E_BAD_GROUPS;
-        if (!aligned16(h.X) || !aligned16(h.W) || !aligned16(h.P) || !aligned16(h.Y) || h.ldw % 8 || h.sX % 8 || h.sY % 4) return BD_E_BAD_SHAPE;
-        if (h.residual && (h.kind != 0 || !aligned16(h.residual) || h.sR % 4 || h.residual == h.Y)) return BD_E_BAD_SHAPE;
-        if (h.Y == h.X) return BD_E_BAD_SHAPE;
-        const int64_t xb = ((int64_t)(tenants - 1) * h.sX + h.K) * 2, wb = ((int64_t)(h.N - 1) * h.ldw + h.K) * 2;
-        const int64_t pb = (int64_t)(h.N / 16) * (h.K / 128) * 4 * 16 * t_pad * 4;
-        if (xb >= lim || wb >= lim || pb >= lim || h.sX < 0 || h.ldw < h.K) return BD_E_BAD_SHAPE;
-        q.X = (const unsigned short*)h.X; q.W = (const unsigned short*)h.W; q.P = (const uint32_t*)h.P; q.alpha = h.alpha;
-        q.C = (unsigned short*)h.Y; q.Rsd = (const unsigned short*)h.residual; q.nw = (const unsigned short*)h.norm_w;
-        q.N = h.N; q.K = h.K; q.ldw = (int)h.ldw; q.gsz = h.kind == 2 ? h.N / 2 : h.N / h.G;
-        q.sX = (int)h.sX; q.sC = (int)h.sY; q.sR = (int)h.sR; q.sAl = (int)h.s_alpha; q.sNw = (int)h.s_norm;
-        q.x_bytes = (uint32_t)xb; q.w_bytes = (uint32_t)wb; q.p_bytes = (uint32_t)pb;
-        q.eps = h.eps; q.jsh = 0;
-        int cpb = (h.N + grid - 1) / grid;
-        cpb = h.kind == 2 ? (cpb + 15) & ~15 : (cpb + 3) & ~3;
-        if (cpb < 4) cpb = 4;
-        q.cpb = cpb;
-        // the SwiGLU phase's output is re-read by the next (plain) phase through L2: the column ranges of the grid/8 consecutive blocks
-        // of an XCD must end on a 128-byte line, so that no line is written from two XCDs (see bd_gemv_chain.h)
-        if (h.kind == 2 && (grid % 8 || ((int64_t)(grid / 8) * (cpb / 2) * 2) % 128)) return BD_E_BAD_SHAPE;
-        if (h.kind != 0) {
-            if (!h.norm_w || !aligned16(h.norm_w) || h.s_norm % 8 || h.s_norm < 0) return BD_E_BAD_SHAPE;
-            if (h.K < 2048 || (h.K & (h.K - 1)) || (int64_t)tenants * h.K > 16 * 2048) return BD_E_BAD_SHAPE;
-            while ((2048 << q.jsh) < h.K) ++q.jsh;
-            q.n_bytes = (uint32_t)(((int64_t)(tenants - 1) * h.s_norm + h.K) * 2);
-            const uint32_t xrow = (uint32_t)h.K * 2u + 16u;
-            if (cp.xrow < xrow) cp.xrow = xrow;
-        }
-    }
-    const int64_t lds = std::max<int64_t>((int64_t)cp.xs_off + (int64_t)tenants * cp.xrow, STREAM_LDS_BYTES);
-    if (lds > STREAM_LDS_MAX) return BD_E_BAD_SHAPE;
-    hipStream_t st = (hipStream_t)stream;
-#define BD_CH(NM, NS) (dtype == BD_BF16 ? launch_chain_inst<DT_BF16, NM, NS>(cp, grid, (int)lds, st) : launch_chain_inst<DT_F16, NM, NS>(cp, grid, (int)lds, st))
-    switch (t_pad) {
-        case 4: return BD_CH(4, CHAIN_NS);
-        case 6: return BD_CH(6, CHAIN_NS);
-        default: return BD_CH(8, CHAIN_NS);
-    }
-#undef BD_CH
 }
 
 extern "C" int bd_binary_linear_residual(const void* X, const void* W, const int32_t* P, const float* alpha, void* Y, int B,

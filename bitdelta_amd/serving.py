@@ -63,8 +63,14 @@ class DataParallelModule(nn.Module):
             return "embedding"
         if isinstance(module, nn.Linear):
             return "linear"
+        # 'scale' = evaluate the module once with weight := 1 and multiply by every tenant's weight afterwards.  That equals per-tenant
+        # evaluation only when the module's LAST step is literally `weight * normed` (Llama / Mistral RMSNorm, torch.nn.RMSNorm).  A
+        # whitelist by class, not "any 1-D weight": GemmaRMSNorm computes normed * (1 + weight), nn.PReLU uses its weight as a slope --
+        # both would silently give wrong activations.  forward() additionally verifies the first call against the reference loop.
         w = getattr(module, "weight", None)
-        if w is not None and w.dim() == 1 and getattr(module, "bias", None) is None and not isinstance(module, nn.LayerNorm):
+        name = type(module).__name__
+        rms_like = isinstance(module, getattr(nn, "RMSNorm", ())) or (name.endswith("RMSNorm") and "Gemma" not in name)
+        if rms_like and w is not None and w.dim() == 1 and getattr(module, "bias", None) is None:
             return "scale"
         return "loop"
 
@@ -103,7 +109,15 @@ class DataParallelModule(nn.Module):
                 normed = self.module(hidden_states)
             finally:
                 self.module.weight.data = self.original_weight
-            return self.stack.view(T, *([1] * (normed.dim() - 2)), -1) * normed
+            out = self.stack.view(T, *([1] * (normed.dim() - 2)), -1) * normed
+            if not getattr(self, "_scale_verified", False):
+                # one-time probe on real data: the batched form must reproduce the reference's weight-swapping loop exactly
+                if out.shape == (ref := self._loop(hidden_states)).shape and torch.equal(out, ref):
+                    self._scale_verified = True
+                else:
+                    self.kind = "loop"
+                    return ref
+            return out
         return self._loop(hidden_states)
 
 

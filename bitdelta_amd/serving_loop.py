@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .binary_gemm_kernel import (binary_linear, binary_linear_swiglu, binary_linear_decode, decode_chain, decode_shape_ok, fused_norm_ok,
+from .binary_gemm_kernel import (binary_linear, binary_linear_swiglu, binary_linear_decode, decode_shape_ok, fused_norm_ok,
                                  pack_decode_masks, tenant_linear, tile_weight)
 from .diff import binarize
 from . import serving_ops as ops
@@ -35,7 +35,7 @@ MODEL_CONFIGS = {
     "llama-2-70b": (8192, 28672, 80, 64, 8, 32000),
     "tiny": (256, 512, 2, 4, 2, 512),
     "tiny128": (512, 1024, 2, 4, 1, 512),        # head_dim 128, 4 query heads per kv head: exercises the decode glue kernels
-    "tiny4096": (4096, 4096, 2, 32, 8, 512),     # two Llama-width layers: exercises the persistent chain launch (K >= 3072)
+    "tiny4096": (4096, 4096, 2, 32, 8, 512),     # two Llama-width layers (the fused-norm launches need K >= 2048)
     "tiny2048": (2048, 2048, 2, 16, 4, 512),     # hidden % 2048 == 0: exercises the fused RMSNorm / SwiGLU launches
 }
 
@@ -195,12 +195,12 @@ class TenantDecoder(nn.Module):
         # tile-major weights): separate launches 5.35 | SwiGLU in gate|up's epilogue 5.11 | + RMSNorm in gate|up's prologue 5.17 |
         # + RMSNorm in q|k|v's prologue 5.28.  The epilogue is free; a norm prologue makes 256 blocks each re-read and re-normalise
         # all rows (~6 us in front of the launch) to save a 4.4 us kernel -- at best a wash on the long launch, a loss on the short one.
+        self._static = {}               # (max_new_tokens, stop width) -> static request state + captured decode-step graph
+        self._capture_stream = None
         self.fuse_qkv_norm = False      # RMSNorm folded into the q|k|v launch
         self.fuse_gateup_norm = False   # RMSNorm folded into the gate|up launch (SwiGLU stays in its epilogue either way)
-        # ... or run [o, gate|up, down, next layer's q|k|v] as ONE persistent launch per layer (bit-identical).  OFF by default: measured
-        # 5.91 vs 5.33 ms per step -- a grid barrier plus the dependent reload behind it is a chain of 5-6 memory round trips (~8 us)
-        # and the 4 stages of weights prefetched across it cover 4.4 us
-        self.persistent = False
+        # (round 2 also shipped a persistent per-layer chain launch, bd_decode_chain: bit-identical but 5.91 vs 5.33 ms per step in every
+        # same-process A/B, so it was removed from the library in round 3 -- profiles/r02_decode_chain_*.txt keep the measurements)
 
     # ---------------------------------------------------------------- construction
     @classmethod
@@ -313,48 +313,6 @@ class TenantDecoder(nn.Module):
         x = layer.down(act, residual=x)
         return x
 
-    def _chain_ok(self, x):
-        """the persistent chain takes this decode step: fused envelope for every phase of every layer (bd_decode_chain)"""
-        T, S, hid = x.shape
-        _, inter, _, heads, kvh, _ = self.cfg
-        if not (self.persistent and self.fast_glue and self.fuse_glue and S == 1 and x.is_contiguous()):
-            return False
-        if not ops.decode_attention_supported(heads, kvh, self.hd) or hid % 16 or inter % 16:
-            return False
-        l0 = self.layers[0]
-        if l0.qkv.mask_packed is None or l0.qkv.mask_packed.shape[4] < 4:
-            return False
-        ns = 4
-        return all(l.qkv.fusable(x) and l.gate_up.fusable(x, swiglu=True) and l.o.mask_packed is not None and
-                   l.down.mask_packed is not None for l in self.layers) and hid >= 512 * ns and inter >= 512 * ns and inter % 128 == 0
-
-    def _decode_layers_chain(self, x, cache, pos_idx):
-        """decode step over all layers with one persistent launch per layer for [o, gate|up, down, q|k|v of the next layer]"""
-        T, _, hid = x.shape
-        _, inter, _, heads, kvh, _ = self.cfg
-        first = self.layers[0]
-        qkv = first.qkv.forward_fused(x, first.norm1, self.eps)
-        h = x
-        for li, layer in enumerate(self.layers):
-            a = ops.decode_attention(qkv, self.cos, self.sin, cache["k"][li], cache["v"][li], cache["valid"], pos_idx, heads, kvh)
-            nxt = self.layers[li + 1] if li + 1 < len(self.layers) else None
-            h_mid, h_out = torch.empty_like(h), torch.empty_like(h)
-            act = torch.empty((T, 1, inter), device=x.device, dtype=x.dtype)
-            phases = [
-                dict(x=a, weight=layer.o.weight, mask_packed=layer.o.mask_packed, alpha=layer.o.alpha, out=h_mid, residual=h),
-                dict(x=h_mid, weight=layer.gate_up.weight, mask_packed=layer.gate_up.mask_packed, alpha=layer.gate_up.alpha_pair,
-                     out=act, norm_weight=layer.norm2, eps=self.eps),
-                dict(x=act, weight=layer.down.weight, mask_packed=layer.down.mask_packed, alpha=layer.down.alpha, out=h_out,
-                     residual=h_mid),
-            ]
-            if nxt is not None:
-                qkv = torch.empty((T, 1, nxt.qkv.weight.shape[0]), device=x.device, dtype=x.dtype)
-                phases.append(dict(x=h_out, weight=nxt.qkv.weight, mask_packed=nxt.qkv.mask_packed, alpha=nxt.qkv.alpha, out=qkv,
-                                   norm_weight=nxt.norm1, eps=self.eps))
-            decode_chain(phases, tenants=T)
-            h = h_out
-        return h
-
     @torch.no_grad()
     def forward(self, ids, pos_idx, cache, attn_mask):
         """ids [T, S]; pos_idx [S] (device, positions of these tokens in the cache); attn_mask [T, 1, S, L] bool.
@@ -363,11 +321,8 @@ class TenantDecoder(nn.Module):
         cos, sin = self.cos[pos_idx], self.sin[pos_idx]
         t_idx = torch.arange(T, device=ids.device).view(T, 1)
         x = self.embed[t_idx, ids]                                            # per-tenant embedding: one gather
-        if self._chain_ok(x):
-            x = self._decode_layers_chain(x, cache, pos_idx)
-        else:
-            for li, layer in enumerate(self.layers):
-                x = self._layer(layer, x, cos, sin, cache, li, pos_idx, attn_mask)
+        for li, layer in enumerate(self.layers):
+            x = self._layer(layer, x, cos, sin, cache, li, pos_idx, attn_mask)
         last = self._norm(x[:, -1:, :], self.final_norm)
         return tenant_linear(last, self.lm_head)[:, 0, :]                     # per-tenant lm_head: one launch
 
@@ -421,22 +376,41 @@ class TenantDecoder(nn.Module):
         ids, am = self.prepare(prompts)
         T, L = ids.shape
         assert L + max_new_tokens <= self.max_len
-        cache = self.new_cache()
-        logits = self.prefill(ids, am, cache)
         nstop = max((len(s) for s in stop_token_ids), default=0) if stop_token_ids else 0
-        stop = torch.full((T, max(nstop, 1)), -1, dtype=torch.long, device=self.dev)
+        # Static request state, reused by every generate() call of the same shape: the KV cache, the feedback buffers and -- with them --
+        # the captured hipGraph of the decode step (capturing per call re-allocated scratch for a fresh side stream every time and
+        # replayed a full-buffer memset node: ADVICE r02).  Stale keys of an earlier request are masked by cache["valid"].
+        key = (max_new_tokens, max(nstop, 1), self.fast_glue, self.fuse_glue, self.fuse_qkv_norm, self.fuse_gateup_norm, FusedDeltaLinear.use_tiled)
+        slot = self._static.get(key)
+        if slot is None:
+            slot = self._static[key] = {"st": {
+                "cache": self.new_cache(), "tok": torch.zeros(T, 1, dtype=torch.long, device=self.dev),
+                "pos": torch.zeros(1, dtype=torch.long, device=self.dev), "step": torch.zeros(1, dtype=torch.long, device=self.dev),
+                "stop_ids": torch.full((T, max(nstop, 1)), -1, dtype=torch.long, device=self.dev),
+                "out": torch.zeros(T, max_new_tokens + 1, dtype=torch.long, device=self.dev),
+                "stopped": torch.zeros(T, dtype=torch.bool, device=self.dev)}, "graph": None}
+        st = slot["st"]
+        cache = st["cache"]
+        logits = self.prefill(ids, am, cache)
+        st["stop_ids"].fill_(-1)
         if stop_token_ids:
-            for t, s in enumerate(stop_token_ids):
-                if len(s):
-                    stop[t, :len(s)] = torch.tensor(sorted(s), dtype=torch.long, device=self.dev)
+            for t, s_ in enumerate(stop_token_ids):
+                if len(s_):
+                    st["stop_ids"][t, :len(s_)] = torch.tensor(sorted(s_), dtype=torch.long, device=self.dev)
         first = torch.argmax(logits, dim=-1)
-        st = {"cache": cache, "tok": first[:, None].clone(), "pos": torch.tensor([L], device=self.dev),
-              "step": torch.tensor([1], device=self.dev), "stop_ids": stop,
-              "out": torch.zeros(T, max_new_tokens + 1, dtype=torch.long, device=self.dev),
-              "stopped": (first[:, None] == stop).any(dim=1)}
+        st["tok"].copy_(first[:, None])
+        st["pos"].fill_(L)
+        st["step"].fill_(1)
+        st["out"].zero_()
         st["out"][:, 0] = first
+        st["stopped"].copy_((first[:, None] == st["stop_ids"]).any(dim=1))
         n = 1
-        runner = self._graph_runner(st) if use_graph and max_new_tokens > 1 else (lambda: self._decode_step(st))
+        if use_graph and max_new_tokens > 1:
+            if slot["graph"] is None:
+                slot["graph"] = self._graph_runner(st)
+            runner = slot["graph"]
+        else:
+            runner = lambda: self._decode_step(st)
         while n < max_new_tokens:
             if (n - 1) % check_every == 0 and bool(st["stopped"].all()):
                 break
@@ -447,7 +421,11 @@ class TenantDecoder(nn.Module):
     def _graph_runner(self, st):
         """Capture one decode step as a hipGraph on the request's static buffers and return a replay callable.  The launch-bound
         step (4 Linear launches + ~20 small torch ops per layer) replays without per-op host overhead."""
-        side = torch.cuda.Stream(device=self.dev)
+        # ONE capture stream per decoder: the library's scratch is keyed by (device, stream), so the warm-up step below allocates it on
+        # the very stream the capture then runs on (nothing is allocated or memset inside the graph), and later captures reuse it
+        if self._capture_stream is None:
+            self._capture_stream = torch.cuda.Stream(device=self.dev)
+        side = self._capture_stream
         snap = {k: v.clone() for k, v in st.items() if torch.is_tensor(v)}
         snap_valid = st["cache"]["valid"].clone()
         side.wait_stream(torch.cuda.current_stream(self.dev))
@@ -455,7 +433,7 @@ class TenantDecoder(nn.Module):
             self._decode_step(st)
         torch.cuda.current_stream(self.dev).wait_stream(side)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, stream=side):
             self._decode_step(st)
         torch.cuda.synchronize(self.dev)
         for k, v in snap.items():                         # undo the two trial steps: replay starts from the request's real state

@@ -129,31 +129,6 @@ int bd_binary_linear_decode_fused(const void* X, const void* W, const int32_t* P
                                   int64_t sYb, int64_t sYm, int dtype, int out_dtype, int accumulate,
                                   const void* norm_w, int64_t s_norm, float eps, int epilogue, void* stream);
 
-/* PERSISTENT form of the decode step's Linear chain: the Linears of a decoder layer that follow each other without an attention in
- * between -- [o + residual] -> [RMSNorm -> gate|up -> SwiGLU] -> [down + residual] -> [RMSNorm -> q|k|v of the NEXT layer] (3 phases
- * for the last layer) -- as ONE launch of one block per CU with grid barriers between the phases; the first weight stages of a
- * phase are fetched while the block waits at the barrier in front of it (bd_gemv_chain.h).  Bit-identical to the separate
- * bd_binary_linear_decode / _fused launches.  Phase kinds must be {0, 2, 0[, 1]} in this order:
- *   kind 0: Y = residual + X . W^T + alpha * (X . S)            (residual may be NULL; Y must not alias residual or X)
- *   kind 1: Y = RMSNorm(X; norm_w, eps) . W^T + alpha * (...)    (X = the un-normalised residual stream)
- *   kind 2: kind 1 on an 8-interleaved gate|up pair followed by SwiGLU: Y [tenants, N/2], alpha [tenants, 2]
- * All phases: one row per tenant (M = 1), tenants <= t_pad in {4, 6, 8}, packed sign layout (mask_layout 2 of
- * bd_binary_linear_decode), N % 16 == 0, K % 128 == 0 and K >= 2048; kinds 1, 2: K a power of two with
- * tenants * K <= 32768.  Every buffer a later phase reads (Y of an earlier phase) must be written by this launch only; a phase's X
- * may be the Y of the phase before it.  `sync`: bd_decode_chain_sync_bytes() of device memory, zero-filled ONCE by the caller and
- * then owned by this entry point (an epoch word + one arrival flag per block; never reset, one launch at a time per buffer).  If a
- * grid barrier is not passed within ~1 s the kernel gives up (results are then invalid) and leaves a non-zero word at sync[1]
- * instead of hanging the device. */
-typedef struct bd_chain_phase {
-    const void* X; const void* W; const int32_t* P; const float* alpha; void* Y; const void* residual; const void* norm_w;
-    int32_t N, K, G, kind;
-    int64_t ldw, sX, sY, sR, s_alpha, s_norm;       /* element strides: W rows; X / Y / residual / alpha / norm_w rows (0 = broadcast) */
-    float eps;
-    int32_t reserved;
-} bd_chain_phase_t;
-int bd_decode_chain(const bd_chain_phase_t* phases, int n_phases, int tenants, int t_pad, int dtype, void* sync, void* stream);
-int64_t bd_decode_chain_sync_bytes(void);
-
 /* the same Linear with the residual connection folded into its epilogue:  Y[b] = Y_in[b] + X[b] . W^T + alpha * (X[b] . S[b])
  * -- the `hidden = residual + o_proj(...)` / `+ down_proj(...)` of the decoder layers that call the reference's modules.
  * Decode shapes (M <= 16, B*M <= 64): fp32 sum, one rounding.  M > 16 on the fused GEMM's fast path (K % 64 == 0, 16-byte aligned
