@@ -66,27 +66,27 @@ class _DeltaLinearFn(torch.autograd.Function):
     """y = x . W^T + coeff * (x . S) with the FULL gradient (opt-in, BinaryDiff.delta_input_grad = True).
 
     forward : one fused HIP launch (bd_binary_linear), fp32 accumulate, one rounding.
-    backward: dx = g . W + coeff * (g . S^T)   -- torch GEMM + the delta GEMM kernel on the transposed pack (alpha epilogue)
-              dcoeff = sum(g * (x . S))         -- the delta GEMM once more (fp32 output), reduced in fp32
+    backward: dx = g . W + coeff * (g . S^T)   -- ONE launch of the same fused kernel on (W^T stored [in, out], S^T packed over n):
+                                                  the backward of a fused Linear is a fused Linear with the roles of in / out swapped
+              dcoeff = sum(g * (x . S))         -- the delta GEMM (fp32 output), reduced in fp32
     The reference has no backward for its kernel: see BinaryDiff.forward for the default, reference-identical behaviour."""
 
     @staticmethod
-    def forward(ctx, x3, weight_nk, mask, mask_t, coeff):
-        ctx.save_for_backward(x3, weight_nk, mask, mask_t, coeff)
+    def forward(ctx, x3, weight_nk, mask, mask_t, weight_kn, coeff):
+        ctx.save_for_backward(x3, mask, mask_t, weight_kn, coeff)
         return binary_linear(x3, weight_nk, mask.unsqueeze(0), coeff.detach().reshape(1, 1))
 
     @staticmethod
     def backward(ctx, g):
-        x3, weight_nk, mask, mask_t, coeff = ctx.saved_tensors
+        x3, mask, mask_t, weight_kn, coeff = ctx.saved_tensors
         g = g.contiguous()
         gx = gc_ = None
         if ctx.needs_input_grad[0]:
-            gx = torch.matmul(g, weight_nk)                                      # [1, M, N] @ [N, K]
-            delta_bmm(g, mask_t.unsqueeze(0), out=gx, alpha=coeff.detach().reshape(1, 1), accumulate=True, round_mode=0)
-        if ctx.needs_input_grad[4]:
+            gx = binary_linear(g, weight_kn, mask_t.unsqueeze(0), coeff.detach().reshape(1, 1))      # [1, M, N] -> [1, M, K]
+        if ctx.needs_input_grad[5]:
             c = delta_bmm(x3, mask.unsqueeze(0), out_dtype=torch.float32, round_mode=0)
             gc_ = (g.float() * c).sum().reshape(coeff.shape)
-        return gx, None, None, None, gc_
+        return gx, None, None, None, None, gc_
 
 
 # ------------------------------------------------------------------------------------------------ the module
@@ -105,10 +105,19 @@ class BinaryDiff(nn.Module):
         self.register_buffer("base", base.T)
         self.register_parameter("coeff", nn.Parameter(mean_abs.detach().clone().to(torch.float32).requires_grad_(True)))
         self._mask_t = None          # lazily packed S^T for the opt-in backward (not a buffer: the state_dict stays the reference's)
+        self._weight_kn = None       # ... and the base weight stored [in, out] (the backward launch's "W")
 
     def _weight_nk(self):
         w = self.base.T                      # [out, in]; contiguous while `base` is still the .T view it was built as
         return w if w.stride(1) == 1 else w.contiguous()      # e.g. after a state_dict round trip densified the buffer
+
+    def _transposed_weight(self):
+        """base weight as a contiguous [in, out] matrix: what the fused kernel needs as its row-major `W` when it computes
+        dx = g . W + coeff * (g . S^T).  `self.base` IS that matrix logically ([in, out] view of the [out, in] storage); this is its
+        contiguous copy, made once (training only, opt-in: +2 bytes per parameter)."""
+        if self._weight_kn is None or self._weight_kn.device != self.base.device:
+            self._weight_kn = self.base.contiguous()
+        return self._weight_kn
 
     def _transposed_mask(self):
         if self._mask_t is None or self._mask_t.device != self.mask.device:
@@ -132,7 +141,7 @@ class BinaryDiff(nn.Module):
         if not needs_grad:
             y = binary_linear(x3, self._weight_nk(), self.mask.unsqueeze(0), self.coeff.reshape(1, 1))
         elif self.delta_input_grad:
-            y = _DeltaLinearFn.apply(x3, self._weight_nk(), self.mask, self._transposed_mask(), self.coeff)
+            y = _DeltaLinearFn.apply(x3, self._weight_nk(), self.mask, self._transposed_mask(), self._transposed_weight(), self.coeff)
         else:
             # training form, reference composition (diff.py:39): d/dcoeff flows through `coeff * c`, d/dx only through
             # `x @ base` -- the kernel output carries no grad_fn, exactly like the reference's Triton launch.
