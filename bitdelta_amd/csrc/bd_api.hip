@@ -1123,7 +1123,7 @@ extern "C" int bd_srv_decode_attention(const void* QKV, const void* cos_t, const
     if (T == 0) return BD_OK;
     if (!QKV || !cos_t || !sin_t || !kcache || !vcache || !valid || !pos || !out) return BD_E_NULL;
     const int G = H / KVH;
-    if (head_dim != 128 || (G != 1 && G != 4) || s_qkv % 8 || !aligned16(QKV) || !aligned16(kcache) || !aligned16(vcache))
+    if (head_dim != 128 || (G != 1 && G != 4 && G != 8) || s_qkv % 8 || !aligned16(QKV) || !aligned16(kcache) || !aligned16(vcache))
         return BD_E_BAD_SHAPE;                         // other head geometries: the caller keeps its torch attention
     AttnParams p;
     p.qkv = (const unsigned short*)QKV; p.cos = (const unsigned short*)cos_t; p.sin = (const unsigned short*)sin_t;
@@ -1142,8 +1142,9 @@ extern "C" int bd_srv_decode_attention(const void* QKV, const void* cos_t, const
     do {                                                                                                    \
         hipLaunchKernelGGL((decode_attn_kernel<DT, GG>), grid, dim3(512), 0, st, p);                        \
     } while (0)
-    if (dtype == BD_BF16) { if (G == 1) BD_ATT(DT_BF16, 1); else BD_ATT(DT_BF16, 4); }
-    else { if (G == 1) BD_ATT(DT_F16, 1); else BD_ATT(DT_F16, 4); }
+    // G = query heads per kv head: 1 (Llama-2-7B), 4 (Mistral-7B), 8 (Llama-2-70B -- also per rank under tensor parallelism)
+    if (dtype == BD_BF16) { if (G == 1) BD_ATT(DT_BF16, 1); else if (G == 4) BD_ATT(DT_BF16, 4); else BD_ATT(DT_BF16, 8); }
+    else { if (G == 1) BD_ATT(DT_F16, 1); else if (G == 4) BD_ATT(DT_F16, 4); else BD_ATT(DT_F16, 8); }
 #undef BD_ATT
     return launch_status();
 }

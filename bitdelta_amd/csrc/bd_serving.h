@@ -168,7 +168,7 @@ struct AttnParams {
 // reads 16 bytes (dims 8*d8 .. +7) of key / value row l0 + kq, so a wave instruction covers 4 whole 256-byte rows and the block 32
 // rows per iteration; a 4-deep register ring keeps the rows of the next 4 iterations in flight (8 KB per wave), so the loop runs at
 // its issue rate instead of one HBM round trip per iteration.  Online softmax per head in fp32; the 4 row slots of a wave are merged
-// with lane shuffles, the 8 waves through LDS.  head_dim = 128, G in {1, 4}.
+// with lane shuffles, the 8 waves through LDS.  head_dim = 128, G in {1, 4, 8}.
 // (History, profiles/r02_decode_step.txt: 4 waves, no prefetch -> 16 waves, one iteration ahead: 21 us per layer -> this form.)
 __device__ __forceinline__ void attn_ws_store(float* dst, float v) { __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float attn_ws_load(const float* src) {

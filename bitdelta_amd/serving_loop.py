@@ -111,12 +111,13 @@ class FusedDeltaLinear(nn.Module):
 
     use_tiled = True              # (A/B switch)
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, out_dtype=None):
+        """out_dtype=torch.float32: un-rounded partial sums (the row-parallel shards of tp.py reduce them across ranks)"""
         if self._decode_ok(x):
             w, wt = self._dec_weight(x)
             return binary_linear_decode(x, w, self.mask_packed, self.alpha, layout="packed", groups=self.groups,
-                                        residual=residual, weight_tiled=wt)
-        return binary_linear(x, self.weight, self.mask, self.alpha, groups=self.groups, residual=residual)
+                                        residual=residual, weight_tiled=wt, out_dtype=out_dtype)
+        return binary_linear(x, self.weight, self.mask, self.alpha, groups=self.groups, residual=residual, out_dtype=out_dtype)
 
     def forward_fused(self, x, norm_weight, eps, swiglu=False):
         """[RMSNorm(x; norm_weight) ->] this Linear [-> SwiGLU] in ONE launch.  With norm_weight, x is the un-normalised residual stream

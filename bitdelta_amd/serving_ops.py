@@ -75,7 +75,7 @@ def decode_attention(qkv, cos, sin, kcache, vcache, valid, pos, heads, kv_heads)
 
 
 def decode_attention_supported(heads, kv_heads, head_dim):
-    return head_dim == 128 and heads % kv_heads == 0 and heads // kv_heads in (1, 4)
+    return head_dim == 128 and heads % kv_heads == 0 and heads // kv_heads in (1, 4, 8)
 
 
 def rope_(x, cos, sin, heads, seq, pos0=0):

@@ -27,6 +27,7 @@ import torch.nn.functional as F
 from .binary_gemm_kernel import binary_linear
 from .diff import binarize
 from .dist import shard_mask_columns, shard_mask_rows
+from . import serving_ops as ops
 
 
 def _world():
@@ -69,6 +70,7 @@ class RowParallelBinaryDiff(nn.Module):
         self.register_buffer("mask", mask_shard.contiguous())               # [K/32/w, N]
         self.register_buffer("coeff", coeff.detach().float().reshape(1, 1))
         self.group = group
+        self._reduce = None
 
     @classmethod
     def from_full(cls, weight, mask, coeff, rank=None, world=None, group=None):
@@ -89,104 +91,271 @@ class RowParallelBinaryDiff(nn.Module):
         y = self.partial(x, out_dtype=torch.float32)
         if reduce_dtype != torch.float32:
             y = y.to(reduce_dtype)
-        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
-        return y.to(x.dtype)
+        if self._reduce is None:
+            self._reduce = PartialSumReducer(self.group)       # one-shot exchange for decode-sized messages, ring otherwise
+        return self._reduce(y).to(x.dtype)
+
+
+# ------------------------------------------------------------------------------------------------ small-message all-reduce
+class PartialSumReducer:
+    """All-reduce of the row-parallel Linears' fp32 partial sums.
+
+    Decode-sized messages ([rows <= 64, hidden] fp32: 32 KB at Llama-2-70B) are latency-bound: a ring all-reduce over 8 ranks is 14
+    dependent hops of point-to-point xGMI traffic (10-20 us each call, 160 calls per step -- as long as the step's compute).  They go
+    through a ONE-SHOT exchange instead: every rank keeps its partial in a symmetric (peer-mapped) buffer, signals, and sums the 8
+    buffers itself in rank order -- one xGMI read per peer, no hop chain, deterministic.  The peer mapping, the signal pads and the
+    kernel are torch's (torch.distributed._symmetric_memory / symm_mem.one_shot_all_reduce: device memory + collectives are plumbing
+    here, the product is the Linear kernel that fills the buffer).  Everything else -- prefill-sized messages, process groups without
+    peer access, the gloo groups of the CPU/one-GPU tests -- uses dist.all_reduce (RCCL ring over xGMI on a node).
+    UNMEASURED on hardware: no multi-GPU box was available to this repo's builder; the single-GPU tests drive both branches' control
+    flow (tests/test_dist_gloo.py)."""
+
+    ONE_SHOT_MAX_BYTES = 256 * 1024
+
+    def __init__(self, group=None, world=None):
+        self.group = group
+        self.world = world           # TP degree of the owner (None: the group's size); 1 = nothing to reduce
+        self._bufs = {}              # (shape, dtype) -> symmetric buffer
+        self._symm = None            # None = not probed yet, False = unavailable
+
+    def _symm_ok(self, device):
+        if self._symm is None:
+            self._symm = False
+            try:
+                if dist.is_initialized() and dist.get_backend(self.group) == "nccl" and device.type == "cuda":
+                    import torch.distributed._symmetric_memory as sm
+                    g = self.group or dist.group.WORLD
+                    sm.enable_symm_mem_for_group(g.group_name)
+                    self._sm, self._gname, self._symm = sm, g.group_name, True
+            except Exception:        # no peer access / unsupported build: the ring is always correct
+                self._symm = False
+        return self._symm
+
+    def __call__(self, y):
+        """y: fp32 (or 16-bit) partial sums, identical shape on every rank; returns the sum (may alias y)"""
+        if self.world == 1 or not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return y
+        if y.numel() * y.element_size() <= self.ONE_SHOT_MAX_BYTES and self._symm_ok(y.device):
+            key = (tuple(y.shape), y.dtype)
+            buf = self._bufs.get(key)
+            if buf is None:
+                buf = self._sm.empty(y.shape, dtype=y.dtype, device=y.device)
+                self._sm.rendezvous(buf, self._gname)
+                self._bufs[key] = buf
+            buf.copy_(y)
+            return torch.ops.symm_mem.one_shot_all_reduce(buf, "sum", self._gname)
+        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
+        return y
 
 
 # ------------------------------------------------------------------------------------------------ Llama-2-70B shaped TP decoder (bench)
 LLAMA_70B = (8192, 28672, 80, 64, 8, 32000)      # hidden, intermediate, layers, heads, kv heads, vocab
 
 
-def _synth_shard(n_out, n_in, device, dtype, gen, split, rank, world):
-    """Rank-local shard of a synthetic (base, fine-tune) pair WITHOUT materialising the full matrix on every rank: the shard itself is
-    generated (statistics of SURVEY.md section 8d); coeff is taken from the shard (same distribution as the whole matrix)."""
-    if split == "col":
-        n_out //= world
-    else:
-        n_in //= world
+def synth_full(n_out, n_in, device, dtype, gen):
+    """full synthetic (base weight, mask, coeff) of one projection (SURVEY.md section 8d statistics)"""
     w = (torch.randn(n_out, n_in, device=device, generator=gen) * 0.02).to(dtype)
     fine = (w.float() + torch.randn(n_out, n_in, device=device, generator=gen) * 5e-4).to(dtype)
     mask, coeff = binarize(w, fine)
     return w, mask, coeff
 
 
+def _col_shard(full, rank, world):
+    w, m, c = full
+    n = w.shape[0] // world
+    assert w.shape[0] % world == 0
+    return w[rank * n:(rank + 1) * n].contiguous(), shard_mask_columns(m, rank, world), c
+
+
+def _row_shard(full, rank, world):
+    w, m, c = full
+    k = w.shape[1] // world
+    assert w.shape[1] % world == 0 and k % 32 == 0, "K / world must be a multiple of 32"
+    return w[:, rank * k:(rank + 1) * k].contiguous(), shard_mask_rows(m, rank, world), c
+
+
 class TPDecoderLayer(nn.Module):
-    def __init__(self, cfg, device, dtype, gen, rank, world):
+    """One decoder layer's rank-local shards, at the serving loop's standard: q|k|v and gate|up are ONE FusedDeltaLinear each (the k / v
+    shards of Llama-2-70B are 128 columns wide -- far below what a launch of their own can stream), the glue runs on the HIP kernels of
+    serving_ops at decode (RMSNorm, RoPE + KV append + attention in one launch, SwiGLU in gate|up's epilogue), and the row-parallel
+    o / down shards leave fp32 partials that PartialSumReducer exchanges."""
+
+    def __init__(self, cfg, shards, norms, device, dtype, world, reducer, eps=1e-5):
         super().__init__()
+        from .serving_loop import FusedDeltaLinear
         hid, inter, _, heads, kvh, _ = cfg
         self.hd = hid // heads
-        self.h_loc, self.kv_loc = heads // world, max(kvh // world, 1)
-        hd = self.hd
-        mk_c = lambda o, i: ColumnParallelBinaryDiff(*_synth_shard(o, i, device, dtype, gen, "col", rank, world))
-        mk_r = lambda o, i: RowParallelBinaryDiff(*_synth_shard(o, i, device, dtype, gen, "row", rank, world))
-        self.q_proj, self.k_proj, self.v_proj = mk_c(heads * hd, hid), mk_c(kvh * hd, hid), mk_c(kvh * hd, hid)
-        self.o_proj = mk_r(hid, heads * hd)
-        self.gate_proj, self.up_proj = mk_c(inter, hid), mk_c(inter, hid)
-        self.down_proj = mk_r(hid, inter)
-        self.n1 = torch.ones(hid, device=device, dtype=dtype)
-        self.n2 = torch.ones(hid, device=device, dtype=dtype)
+        self.h_loc, self.kv_loc = heads // world, kvh // world
+        self.inter_loc = inter // world
+        self.eps = eps
+        one = lambda t: t.reshape(1)
+        q, k, v, o, gate, up, down = shards
+        self.qkv = FusedDeltaLinear([q[0], k[0], v[0]], [q[1][None], k[1][None], v[1][None]], [one(q[2]), one(k[2]), one(v[2])])
+        self.gate_up = FusedDeltaLinear([gate[0], up[0]], [gate[1][None], up[1][None]], [one(gate[2]), one(up[2])],
+                                        interleave8=(self.inter_loc % 8 == 0))
+        self.o = FusedDeltaLinear([o[0]], [o[1][None]], [one(o[2])])
+        self.down = FusedDeltaLinear([down[0]], [down[1][None]], [one(down[2])])
+        self.register_buffer("n1", norms[0].reshape(1, hid))
+        self.register_buffer("n2", norms[1].reshape(1, hid))
+        self.reduce = reducer
 
-    def forward(self, x, cos, sin, kv):
-        from .serving_loop import _rope
+    def _norm(self, x, w):
+        if x.shape[1] <= 16 and x.shape[-1] % 8 == 0:
+            return ops.rmsnorm_tenant(x if x.is_contiguous() else x.contiguous(), w, self.eps)
+        return F.rms_norm(x, (x.shape[-1],), w[0], self.eps)
+
+    def _row_parallel(self, lin, x, residual):
+        """residual + all-reduce(x_r . W_r^T + coeff * (x_r . S_r)): fp32 partials for decode-sized messages, the activation dtype for
+        prefill-sized ones (half the bytes on the wire; one extra rounding per partial)"""
+        rows = x.numel() // x.shape[-1]
+        y = lin(x, out_dtype=torch.float32)
+        if rows > 64:
+            y = y.to(x.dtype)
+        y = self.reduce(y)
+        return residual + y.to(residual.dtype)
+
+    def forward(self, x, cos, sin, cache, pos_idx, attn_mask):
+        """x [1, S, hidden] (replicated); cache = (k [1, kv_loc, L, hd], v, valid [1, L]); pos_idx [S] device positions"""
         B, S, hid = x.shape
-        h = F.rms_norm(x, (hid,), self.n1, 1e-5)
-        q = _rope(self.q_proj(h).view(B, S, self.h_loc, self.hd).transpose(1, 2), cos, sin)
-        k = _rope(self.k_proj(h).view(B, S, self.kv_loc, self.hd).transpose(1, 2), cos, sin)
-        v = self.v_proj(h).view(B, S, self.kv_loc, self.hd).transpose(1, 2)
-        if kv is not None:
-            pos = kv[2]
-            kv[0][:, :, pos:pos + S] = k
-            kv[1][:, :, pos:pos + S] = v
-            kv[2] = pos + S
-            k, v = kv[0][:, :, :pos + S], kv[1][:, :, :pos + S]
-        a = F.scaled_dot_product_attention(q, k, v, is_causal=(S > 1 and k.shape[2] == S), enable_gqa=(self.kv_loc != self.h_loc))
-        x = x + self.o_proj(a.transpose(1, 2).reshape(B, S, self.h_loc * self.hd))
-        h = F.rms_norm(x, (hid,), self.n2, 1e-5)
-        return x + self.down_proj(F.silu(self.gate_proj(h)) * self.up_proj(h))
+        hd = self.hd
+        qkv = self.qkv(self._norm(x, self.n1))
+        ck, cv, valid = cache
+        if S == 1 and ops.decode_attention_supported(self.h_loc, self.kv_loc, hd):
+            a = ops.decode_attention(qkv, cos, sin, ck, cv, valid, pos_idx, self.h_loc, self.kv_loc)       # RoPE + append + attention
+        else:
+            from .serving_loop import _rope
+            q, k, v = self.qkv.split(qkv)
+            c, s_ = cos[pos_idx], sin[pos_idx]
+            q = _rope(q.view(B, S, self.h_loc, hd).transpose(1, 2), c, s_)
+            k = _rope(k.view(B, S, self.kv_loc, hd).transpose(1, 2), c, s_)
+            v = v.view(B, S, self.kv_loc, hd).transpose(1, 2)
+            ck.index_copy_(2, pos_idx, k)
+            cv.index_copy_(2, pos_idx, v)
+            a = F.scaled_dot_product_attention(q, ck, cv, attn_mask=attn_mask, enable_gqa=(self.kv_loc != self.h_loc))
+            a = a.transpose(1, 2).reshape(B, S, self.h_loc * hd)
+        x = self._row_parallel(self.o, a, x)
+        h = self._norm(x, self.n2)
+        if S == 1 and self.gate_up.interleave8 and self.gate_up._decode_ok(h):
+            act = self.gate_up.forward_fused(h, None, self.eps, swiglu=True)                                # gate|up -> SwiGLU: one launch
+        else:
+            gu = self.gate_up(h)
+            if self.gate_up.interleave8 and gu.shape[-1] % 16 == 0:
+                act = ops.swiglu_interleaved8(gu)
+            else:
+                g, u = self.gate_up.split(gu)
+                act = F.silu(g) * u
+        return self._row_parallel(self.down, act, x)
 
 
 class TPDecoder(nn.Module):
-    def __init__(self, cfg, device, dtype, rank, world, layers=None, seed=0):
+    """Tensor-parallel decoder over `world` ranks.  `full=None`: every rank synthesises ITS OWN shards (no rank ever holds a full 70B
+    matrix).  `full=[...]` (tests): per-layer lists of the 7 full (weight, mask, coeff) triples, sharded here -- identical on every
+    rank, so that the TP result can be compared with the single-rank one."""
+
+    def __init__(self, cfg, device, dtype, rank, world, layers=None, seed=0, full=None, group=None, max_len=4096):
         super().__init__()
         from .serving_loop import _rope_tables
         hid, inter, nl, heads, kvh, vocab = cfg
-        assert heads % world == 0 and (kvh % world == 0 or world % kvh == 0)
+        assert heads % world == 0 and kvh % world == 0, "query and kv heads must both divide by the TP degree (no kv-head replication)"
+        assert (heads // kvh) in (1, 4, 8) or True
         gen = torch.Generator(device=device).manual_seed(seed + 1000 * rank)       # shards differ per rank
         rep = torch.Generator(device=device).manual_seed(seed)                      # replicated tensors agree on every rank
-        self.cfg, self.dtype, self.dev = cfg, dtype, device
-        self.layers = nn.ModuleList([TPDecoderLayer(cfg, device, dtype, gen, rank, world) for _ in range(layers or nl)])
+        self.cfg, self.dtype, self.dev, self.rank, self.world = cfg, dtype, device, rank, world
+        self.reducer = PartialSumReducer(group, world)
+        hd = hid // heads
+        self.hd = hd
+        shapes = [("col", heads * hd, hid), ("col", kvh * hd, hid), ("col", kvh * hd, hid), ("row", hid, heads * hd),
+                  ("col", inter, hid), ("col", inter, hid), ("row", hid, inter)]
+        ls = []
+        for li in range(layers or nl):
+            shards = []
+            for pi, (split, n_out, n_in) in enumerate(shapes):
+                if full is not None:
+                    shards.append(_col_shard(full[li][pi], rank, world) if split == "col" else _row_shard(full[li][pi], rank, world))
+                else:
+                    o_, i_ = (n_out // world, n_in) if split == "col" else (n_out, n_in // world)
+                    shards.append(synth_full(o_, i_, device, dtype, gen))
+            norms = (torch.ones(hid, device=device, dtype=dtype), torch.ones(hid, device=device, dtype=dtype))
+            ls.append(TPDecoderLayer(cfg, shards, norms, device, dtype, world, self.reducer))
+        self.layers = nn.ModuleList(ls)
         self.embed = (torch.randn(vocab, hid, device=device, generator=rep) * 0.02).to(dtype)
         self.lm_head = (torch.randn(vocab, hid, device=device, generator=rep) * 0.02).to(dtype)
-        self.norm = torch.ones(hid, device=device, dtype=dtype)
-        self.cos, self.sin = _rope_tables(4096, hid // heads, device, dtype)
+        self.norm = torch.ones(1, hid, device=device, dtype=dtype)
+        self.max_len = max_len
+        self.cos, self.sin = _rope_tables(max_len, hd, device, dtype)
+        self._capture_stream = None
 
-    def new_cache(self, batch, length):
+    def new_cache(self, length):
         l0 = self.layers[0]
-        mk = lambda: torch.zeros(batch, l0.kv_loc, length, l0.hd, device=self.dev, dtype=self.dtype)
-        return [[mk(), mk(), 0] for _ in self.layers]
+        mk = lambda: torch.zeros(1, l0.kv_loc, length, l0.hd, device=self.dev, dtype=self.dtype)
+        return {"k": [mk() for _ in self.layers], "v": [mk() for _ in self.layers],
+                "valid": torch.zeros(1, length, dtype=torch.bool, device=self.dev)}
 
     @torch.no_grad()
-    def forward(self, ids, pos0=0, cache=None):
+    def forward(self, ids, pos_idx, cache):
+        """ids [1, S]; pos_idx [S] int64 device tensor (cache positions of these tokens; S > 1: a prefill chunk starting anywhere).
+        Returns the logits of the last position [1, 1, vocab] (replicated on every rank)."""
         B, S = ids.shape
-        cos, sin = self.cos[pos0:pos0 + S], self.sin[pos0:pos0 + S]
+        Lc = cache["valid"].shape[1]
+        cache["valid"].index_fill_(1, pos_idx, True)
+        # query i (at position pos_idx[i]) sees the valid keys at positions <= pos_idx[i]: correct for a chunk that starts at pos > 0 too
+        keypos = torch.arange(Lc, device=self.dev)
+        mask = (keypos[None, :] <= pos_idx[:, None])[None, None] & cache["valid"][:, None, None, :]
         x = self.embed[ids]
-        for i, layer in enumerate(self.layers):
-            x = layer(x, cos, sin, None if cache is None else cache[i])
-        return F.rms_norm(x[:, -1:], (x.shape[-1],), self.norm, 1e-5) @ self.lm_head.T
+        for li, layer in enumerate(self.layers):
+            x = layer(x, self.cos, self.sin, (cache["k"][li], cache["v"][li], cache["valid"]), pos_idx, mask)
+        last = x[:, -1:, :]
+        last = ops.rmsnorm_tenant(last.contiguous(), self.norm, 1e-5) if last.shape[-1] % 8 == 0 else F.rms_norm(last, (last.shape[-1],), self.norm[0], 1e-5)
+        return last @ self.lm_head.T
+
+    def decode_runner(self, tok, pos, cache, use_graph=True):
+        """callable running ONE decode step on static buffers (tok [1,1], pos [1] device tensors, advanced by the step; logits are
+        written to the returned buffer).  With use_graph the per-rank step -- kernels AND collectives -- is captured once as a
+        hipGraph and replayed (RCCL and symmetric-memory collectives are capturable; gloo is not: those groups run eagerly)."""
+        out = torch.empty(1, 1, self.cfg[5], device=self.dev, dtype=self.dtype)
+
+        def step():
+            out.copy_(self.forward(tok, pos, cache))
+            pos.add_(1)
+        capturable = use_graph and (self.world == 1 or not dist.is_initialized() or dist.get_backend() == "nccl")
+        if not capturable:
+            return step, out
+        try:
+            if self._capture_stream is None:
+                self._capture_stream = torch.cuda.Stream(device=self.dev)
+            side = self._capture_stream
+            snap = (pos.clone(), cache["valid"].clone())
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                step()                                   # warm-up on the capture stream: scratch, symmetric buffers, rendezvous
+            torch.cuda.current_stream(self.dev).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                step()
+            torch.cuda.synchronize(self.dev)
+            pos.copy_(snap[0]); cache["valid"].copy_(snap[1])
+            return g.replay, out
+        except Exception:                                # capture refused (driver / collective): the eager step is always valid
+            torch.cuda.synchronize(self.dev)
+            return step, out
 
     def linear_bytes_per_rank(self):
-        return sum((m.weight.numel() * 2 + m.mask.numel() * 4) for m in self.modules()
-                   if isinstance(m, (ColumnParallelBinaryDiff, RowParallelBinaryDiff)))
+        from .serving_loop import FusedDeltaLinear
+        return sum(m.linear_bytes() for m in self.modules() if isinstance(m, FusedDeltaLinear))
 
 
 def bench_tp70b(args, dev, rank, world, timer):
     """bench.py --workload tp70b: Llama-2-70B shapes over `world` ranks (8 on a full node), prefill of one 2048-token sequence and
     decode steps; value = prefill tokens/s of the WHOLE job (strong scaling: the ranks share one sequence)."""
     from .dist import timed_region
-    dec = TPDecoder(LLAMA_70B, dev, torch.bfloat16, rank, world, layers=args.layers, seed=77)
+    dec = TPDecoder(LLAMA_70B, dev, torch.bfloat16, rank, world, layers=args.layers, seed=77, max_len=args.seq + args.kv_len + 64)
     ids = torch.randint(0, 32000, (1, args.seq), device=dev, generator=torch.Generator(device=dev).manual_seed(5))
-    step = lambda: dec(ids)
+    cache = dec.new_cache(max(args.seq, args.kv_len) + 64)
+    pos_prefill = torch.arange(args.seq, device=dev)
+
+    def step():
+        cache["valid"].zero_()
+        return dec(ids, pos_prefill, cache)
     for _ in range(args.warmup):
         step()
     timer.reset()
@@ -194,16 +363,16 @@ def bench_tp70b(args, dev, rank, world, timer):
     dt = timed_region(step, args.steps, device_sync=torch.cuda.synchronize)
     timer.enabled = False
     n_launch, k_ms, k_flops, _ = timer.summary()
-    # decode: one token with a KV cache of args.kv_len
-    cache = dec.new_cache(1, args.kv_len + 64)
-    dec(ids[:, :args.kv_len], 0, cache)
-    tok = ids[:, :1]
-    pos = [args.kv_len]
+    # decode: one token per step on a KV cache of args.kv_len, the per-rank step (kernels + collectives) replayed as a hipGraph
+    cache["valid"].zero_()
+    dec(ids[:, :args.kv_len], torch.arange(args.kv_len, device=dev), cache)
+    tok = ids[:, :1].clone()
+    pos = torch.tensor([args.kv_len], device=dev)
+    run, _ = dec.decode_runner(tok, pos, cache, use_graph=True)
 
     def dstep():
-        for c in cache:
-            c[2] = args.kv_len
-        dec(tok, args.kv_len, cache)
+        pos.fill_(args.kv_len)
+        run()
     for _ in range(3):
         dstep()
     ddt = timed_region(dstep, 20, device_sync=torch.cuda.synchronize)
@@ -214,11 +383,13 @@ def bench_tp70b(args, dev, rank, world, timer):
         "value": args.seq * args.steps / dt, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
         "data": "synthetic",
-        "config": {"workload": f"llama-2-70b shapes, TP={world}, prefill seq {args.seq}; {nl} layers x (5 column-parallel + 2 row-parallel "
-                               "BinaryDiff Linears), RCCL all-reduce after o_proj and down_proj",
+        "config": {"workload": f"llama-2-70b shapes, TP={world}, prefill seq {args.seq}; {nl} layers x (fused q|k|v and gate|up column-parallel "
+                               "shards + o / down row-parallel shards), all-reduce after o_proj and down_proj: RCCL ring at prefill, "
+                               "one-shot symmetric-memory exchange for the 32 KB decode messages",
                    "seq_len": args.seq, "parallelism": f"tp{world}", "valid": args.layers is None and world == 8,
                    "all_reduce_messages_per_step": 2 * nl, "all_reduce_bytes_each_prefill": msg_prefill,
-                   "all_reduce_bytes_each_decode": 8192 * 4},
+                   "all_reduce_bytes_each_decode": 8192 * 4,
+                   "measured_on_hardware": "never on > 1 GPU by the builder (no multi-GPU box); world = 1 / 2-rank gloo runs only"},
         "roofline": {"bound": "mfma", "achieved": k_flops / k_ms * 1e-9 if k_ms > 0 else None, "peak": 2500.0, "unit": "TFLOP/s",
                      "frac": (k_flops / k_ms * 1e-9 / 2500.0) if k_ms > 0 else None, "traffic": None, "launches": n_launch,
                      "share_of_step_time": (k_ms / 1e3) / dt if dt > 0 else None},
