@@ -197,10 +197,10 @@ int main(int argc, char** argv) {
             else if (v == 8) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 32>>(p0, 1, 0);    // ablation: no X-fragment reads in the loop
             else if (v == 9) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 8 | 32>>(p0, 1, 0);  // ablation: neither
             else if (v == 3) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 64>>(p0, 1, 0);    // split-form DMA
-            else if (v == 12) launch_w4<W4Cfg<DT_BF16, 256, 128, true, false, 64>>(p0, 1, 0);        // fused, split-form DMA
+            else if (v == 12) launch_w4<W4Cfg<DT_BF16, 256, 128, true, false, 0>>(p0, 1, 0);         // fused, VALU sign expansion (A/B)
             else if (v == 4) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 4>>(p0, 1, 0);     // energy A/B: sign fragment in the first MFMA slot (results wrong)
             else if (v == 10) launch_old<OldF>(delta_gemm_fx_kernel<OldF>, p0, 1, 0);
-            else launch_w4<W4Cfg<DT_BF16, 256, 128, true, false, 0>>(p0, 1, 0);
+            else launch_w4<W4Cfg<DT_BF16, 256, 128, true, false, 1>>(p0, 1, 0);      // 11: the shipped fused configuration
         };
         if (what.rfind("soakn", 0) == 0) {        // soakn<variant>: exactly `reps` launches (for rocprofv3 passes)
             for (int i = 0; i < reps; ++i) one();
@@ -229,8 +229,8 @@ int main(int argc, char** argv) {
         trace_one<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 8>>("w4 LUT no-dma", params(M, N, false, C1), 2.0 * M * N * K);
         trace_one<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 32>>("w4 LUT no-xread", params(M, N, false, C1), 2.0 * M * N * K);
         trace_one<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 8 | 32>>("w4 LUT neither", params(M, N, false, C1), 2.0 * M * N * K);
-        trace_one<W4Cfg<DT_BF16, 256, 128, true, false, 0>>("w4 fused", params(M, N, true, C1), 4.0 * M * N * K);
-        trace_one<W4Cfg<DT_BF16, 256, 128, true, false, 64>>("w4 fused split-dma", params(M, N, true, C1), 4.0 * M * N * K);
+        trace_one<W4Cfg<DT_BF16, 256, 128, true, false, 1>>("w4 fused (LUT, shipped)", params(M, N, true, C1), 4.0 * M * N * K);
+        trace_one<W4Cfg<DT_BF16, 256, 128, true, false, 0>>("w4 fused VALU expansion", params(M, N, true, C1), 4.0 * M * N * K);
     }
     return 0;
 #endif
@@ -263,7 +263,7 @@ int main(int argc, char** argv) {
             const double fl = 4.0 * M * Nn * K;
             printf("== fused  M=%d N=%d K=%d\n", M, Nn, K);
             using OldF = FxCfg<DT_BF16, 256, 128, 3, false, 1>;
-            using W4F = W4Cfg<DT_BF16, 256, 128, true, false, 0>;
+            using W4F = W4Cfg<DT_BF16, 256, 128, true, false, 1>;
             GemmParams p0 = params(M, Nn, true, C0), p1 = params(M, Nn, true, C1);
             launch_old<OldF>(delta_gemm_fx_kernel<OldF>, p0, 1, 0);
             CK(hipMemset(C1, 0xff, (size_t)M * Nn * 2));
