@@ -28,7 +28,7 @@ def bench_summary(fetch_csv, write_csv):
                    "sit on the L2's fabric side, so Infinity-Cache hits are included: an upper bound on DRAM traffic."}
     for key, needle, label, alg in (
             ("fused_gemm", "delta_gemm_w4_kernel<bd::W4Cfg<1, 256, 128, true", "bd::delta_gemm_w4_kernel<bf16,256x128,fused> (average over the launch mix of a Llama-2-7B layer at M = 2048)", None),
-            ("delta_gemm_4096", "delta_gemm_w4_kernel<bd::W4Cfg<1, 256, 256, false", "bd::delta_gemm_w4_kernel<bf16,256x256,delta-only,LUT> (average over the M = 4096 / 8192 / 16384 rows)", None)):
+            ("delta_gemm_rows", "delta_gemm_w4_kernel<bd::W4Cfg<1, 256, 256, false", "bd::delta_gemm_w4_kernel<bf16,256x256,delta-only,LUT> (average over the M = 4096 / 8192 / 16384 rows)", None)):
         f, nf = per_launch(fetch_csv, "FETCH_SIZE", needle)
         w, nw = per_launch(write_csv, "WRITE_SIZE", needle)
         out[key] = {"kernel": label, "launches_fetch_pass": nf, "launches_write_pass": nw, "fetch_size_kb_avg": f, "write_size_kb_avg": w,
