@@ -37,6 +37,7 @@ MODEL_CONFIGS = {
     "tiny128": (512, 1024, 2, 4, 1, 512),        # head_dim 128, 4 query heads per kv head: exercises the decode glue kernels
     "tiny4096": (4096, 4096, 2, 32, 8, 512),     # two Llama-width layers (the fused-norm launches need K >= 2048)
     "tiny2048": (2048, 2048, 2, 16, 4, 512),     # hidden % 2048 == 0: exercises the fused RMSNorm / SwiGLU launches
+    "mistral-1layer": (4096, 14336, 1, 32, 8, 512),   # ONE full-width Mistral-7B layer (small vocabulary): full-size loop parity tests
 }
 
 MAX_PROMPT = 1024      # demo/demo_backend.py:300-302
