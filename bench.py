@@ -107,45 +107,47 @@ class LaunchTimer:
         return len(self.records), ms, fl, by
 
 
-def cpu_baseline(seq=128):
-    """Reference-equivalent CPU path (oracle/torch_port.py) for ONE decoder layer's 7 projections (Llama-2-7B shapes) at `seq`
-    tokens on ALL host threads (torch.set_num_threads(os.cpu_count())), extrapolated x32 layers to tokens/s.
-    Variant 1 unpacks the masks inside the timed region (what a CPU run of the reference does); variant 2 is the pure
-    torch.matmul baseline with pre-unpacked signs.  Attention/norms are excluded (GPU side: < 5 % of the step)."""
+def cpu_baseline(seq=2048):
+    """Reference-equivalent CPU path (oracle/torch_port.py) on the SAME unit of work as the GPU step: one 2048-token sequence through
+    a decoder layer's 7 BinaryDiff projections (Llama-2-7B shapes) on ALL host threads (BASELINE.md 3:
+    torch.set_num_threads(os.cpu_count())).  The 7 projections have three distinct shapes, so the bounded sample is one timed call per
+    distinct shape at the full sequence length; a layer is 4 x [4096x4096] + 2 x [11008x4096] + 1 x [4096x11008] and the model is 32
+    layers.  Variant 1 unpacks the masks inside the timed region (what a CPU run of the reference does); variant 2 is the pure
+    torch.matmul baseline with pre-unpacked signs.  Attention/norms are excluded (GPU side: about 11 % of the step)."""
     from oracle import torch_port as tp
     ncpu = os.cpu_count() or 1
     torch.set_num_threads(ncpu)
     torch.manual_seed(0)
     hid, inter = 4096, 11008
-    shapes = [(hid, hid)] * 4 + [(inter, hid)] * 2 + [(hid, inter)]
-    layers = []
-    for n_out, n_in in shapes:
+    distinct = [((hid, hid), 4), ((inter, hid), 2), ((hid, inter), 1)]          # ((out, in), how many per layer)
+    warm = torch.randn(1, 16, 256).bfloat16()
+    tp.forward_unpack_in_loop(warm, (torch.randn(256, 256) * 0.02).bfloat16(), torch.zeros(8, 256, dtype=torch.int32), torch.tensor(1e-3))
+    t1 = t2 = 0.0
+    detail = []
+
+    def best_of(fn, budget=4.0, reps=3):            # one call when it is slow, the best of up to three when it is fast
+        best, spent = float("inf"), 0.0
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            dt = time.perf_counter() - t0
+            best, spent = min(best, dt), spent + dt
+            if spent > budget:
+                break
+        return best
+    for (n_out, n_in), count in distinct:
         w = (torch.randn(n_out, n_in) * 0.02).bfloat16()
         mask = torch.randint(-2 ** 31, 2 ** 31 - 1, (n_in // 32, n_out), dtype=torch.int64).to(torch.int32)
-        layers.append((w, mask, torch.tensor(4e-4)))
-    xs = {n_in: torch.randn(1, seq, n_in).bfloat16() for n_in in (hid, inter)}
-
-    def timeit(fn, budget):
-        fn()                                   # warm-up
-        t0 = time.perf_counter()
-        reps = 0
-        while reps < 3 or time.perf_counter() - t0 < budget:
-            fn()
-            reps += 1
-            if time.perf_counter() - t0 > 2.5 * budget:
-                break
-        return (time.perf_counter() - t0) / reps, reps
-
-    def v1():
-        for w, mask, c in layers:
-            tp.forward_unpack_in_loop(xs[w.shape[1]], w, mask, c)
-    t1, r1 = timeit(v1, 8.0)
-    signs = [(tp.unpack32(mask) * 2 - 1).to(torch.bfloat16) for _, mask, _ in layers]
-
-    def v2():
-        for (w, _, c), s in zip(layers, signs):
-            tp.forward_preunpacked(xs[w.shape[1]], w, s, c)
-    t2, r2 = timeit(v2, 4.0)
+        c = torch.tensor(4e-4)
+        x = torch.randn(1, seq, n_in).bfloat16()
+        a = best_of(lambda: tp.forward_unpack_in_loop(x, w, mask, c))
+        s = (tp.unpack32(mask) * 2 - 1).to(torch.bfloat16)
+        tp.forward_preunpacked(x[:, :64], w, s, c)
+        b = best_of(lambda: tp.forward_preunpacked(x, w, s, c))
+        t1 += count * a
+        t2 += count * b
+        detail.append(f"[{n_out}x{n_in}] {a:.2f} s / {b:.2f} s")
+        del w, mask, s, x
     cpu = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -157,10 +159,11 @@ def cpu_baseline(seq=128):
     return {"value": seq / (32 * t1), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
             "matmul_only": {"value": seq / (32 * t2), "unit": "tokens/s",
                             "what": "variant 2 of BASELINE.md 3: pre-unpacked signs, torch.matmul only (x@W.T + coeff*(x@S))",
-                            "reps": r2, "ms_per_layer": t2 * 1e3},
-            "sample": f"1 of 32 decoder layers' 7 BinaryDiff projections (Llama-2-7B shapes) at seq {seq}; value = variant 1 (unpack "
-                      f"inside the timed region, the reference's CPU-executable path), {r1} reps x {t1 * 1e3:.0f} ms, extrapolated x32 "
-                      f"layers; host: {cpu}, os.cpu_count()={ncpu}, torch threads={torch.get_num_threads()}, torch {torch.__version__}"}
+                            "ms_per_layer": t2 * 1e3},
+            "sample": f"same unit as the GPU step (one {seq}-token sequence, Llama-2-7B projections): one timed call per DISTINCT projection "
+                      f"shape at seq {seq} (variant 1 / variant 2: " + ", ".join(detail) + f"), layer = 4+2+1 of them = {t1:.1f} s, x32 layers; "
+                      f"value = variant 1 (unpack inside the timed region, the reference's CPU-executable path); host: {cpu}, "
+                      f"os.cpu_count()={ncpu}, torch threads={torch.get_num_threads()}, torch {torch.__version__}"}
 
 
 def parity_block(dev):
