@@ -139,11 +139,17 @@ class PartialSumReducer:
             key = (tuple(y.shape), y.dtype)
             buf = self._bufs.get(key)
             if buf is None:
-                buf = self._sm.empty(y.shape, dtype=y.dtype, device=y.device)
-                self._sm.rendezvous(buf, self._gname)
-                self._bufs[key] = buf
-            buf.copy_(y)
-            return torch.ops.symm_mem.one_shot_all_reduce(buf, "sum", self._gname)
+                try:                 # setup (peer mapping) is where an unsupported topology shows; every rank fails alike
+                    buf = self._sm.empty(y.shape, dtype=y.dtype, device=y.device)
+                    self._sm.rendezvous(buf, self._gname)
+                except Exception:
+                    self._symm = False
+                    buf = None
+                else:
+                    self._bufs[key] = buf
+            if buf is not None:
+                buf.copy_(y)
+                return torch.ops.symm_mem.one_shot_all_reduce(buf, "sum", self._gname)
         dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
         return y
 
