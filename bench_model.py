@@ -130,6 +130,7 @@ class DecoderLayer(nn.Module):
         # down + residual); `fuse=False` keeps the reference's seven separate BinaryDiff modules
         self.fused = (not tenants) and fuse and inter % 8 == 0
         self.swiglu_epilogue = False
+        self.hip_attention = True      # prefill attention through bd_srv_prefill_attention (False: torch SDPA, for A/B)
         if self.fused:
             self.qkv_proj = FusedSingleTenantLinear([(hid, hid), (kvh * self.hd, hid), (kvh * self.hd, hid)], device, dtype, gen)
             self.gate_up_proj = FusedSingleTenantLinear([(inter, hid), (inter, hid)], device, dtype, gen, interleave8=True)
@@ -154,6 +155,11 @@ class DecoderLayer(nn.Module):
             if self.hd == 128 and rope is not None:
                 ops.rope_(qf, rope[0], rope[1], self.heads, S, rope[2])
                 ops.rope_(kf, rope[0], rope[1], self.kvh, S, rope[2])
+                q4, k4, v4 = qf.view(B, S, self.heads, self.hd), kf.view(B, S, self.kvh, self.hd), vf.view(B, S, self.kvh, self.hd)
+                if kv is None and S > 1 and self.hip_attention and ops.prefill_attention_supported(q4, k4, v4):
+                    # whole-prompt causal attention straight on the three slices of the fused projection output (no head transposes,
+                    # no repeat_interleave for grouped queries); returns [B, S, heads * hd], what o_proj consumes
+                    return self._after_attention(x, ops.prefill_attention(q4, k4, v4, causal=True))
                 q = qf.view(B, S, self.heads, self.hd).transpose(1, 2)
                 k = kf.view(B, S, self.kvh, self.hd).transpose(1, 2)
             else:
@@ -181,7 +187,9 @@ class DecoderLayer(nn.Module):
             k = k.repeat_interleave(rep, dim=1)
             v = v.repeat_interleave(rep, dim=1)
         a = F.scaled_dot_product_attention(q, k, v, is_causal=(S > 1 and k.shape[2] == S))
-        a = a.transpose(1, 2).reshape(B, S, self.heads * self.hd)
+        return self._after_attention(x, a.transpose(1, 2).reshape(B, S, self.heads * self.hd))
+
+    def _after_attention(self, x, a):
         x = self.o_proj(a, residual=x) if self._res_epilogue(x, self.o_proj) else x + self.o_proj(a)
         h = self.post_attention_layernorm(x)
         if self.fused and self.swiglu_epilogue and self.gate_up_proj.lin.swiglu_ok(h):

@@ -40,6 +40,8 @@ SIGNATURES = {
     "bd_srv_rope": (_ci, [_vp, _vp, _vp, _ci, _ci, _ci, _i64, _ci, _ci, _ci, _vp]),
     "bd_srv_decode_attention": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _i64, _i64, _ci, _vp, _i64, _vp]),
     "bd_srv_decode_attention_workspace_bytes": (_i64, [_ci, _ci, _ci, _ci, _ci]),
+    "bd_srv_prefill_attention": (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
+                                       _vp, ctypes.c_float, _ci, _ci, _vp]),
     "bd_gemm_workspace_bytes": (_i64, [_ci, _ci, _ci, _ci]),
     "bd_binarize": (_ci, [_vp, _vp, _i64, _i64, _i64, _ci, _vp, _vp, _vp, _i64, _vp]),
     "bd_binarize_workspace_bytes": (_i64, [_i64, _i64]),

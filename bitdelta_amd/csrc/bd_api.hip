@@ -15,6 +15,7 @@
 #include "bd_gemv.h"
 #include "bd_gemv_stream.h"
 #include "bd_serving.h"
+#include "bd_attn_prefill.h"
 #include <algorithm>
 #include <atomic>
 
@@ -1146,6 +1147,34 @@ extern "C" int bd_srv_decode_attention(const void* QKV, const void* cos_t, const
     if (dtype == BD_BF16) { if (G == 1) BD_ATT(DT_BF16, 1); else if (G == 4) BD_ATT(DT_BF16, 4); else BD_ATT(DT_BF16, 8); }
     else { if (G == 1) BD_ATT(DT_F16, 1); else if (G == 4) BD_ATT(DT_F16, 4); else BD_ATT(DT_F16, 8); }
 #undef BD_ATT
+    return launch_status();
+}
+
+extern "C" int bd_srv_prefill_attention(const void* Q, const void* K, const void* V, void* O, int B, int S, int H, int KVH, int head_dim,
+                                        int64_t sqb, int64_t sqs, int64_t skb, int64_t sks, int64_t svb, int64_t svs,
+                                        int64_t sob, int64_t sos, const int32_t* kv_start, float scale, int causal, int dtype,
+                                        void* stream) {
+    if (B < 0 || S < 0 || H < 1 || KVH < 1 || H % KVH) return BD_E_BAD_SHAPE;
+    if (dtype != BD_F16 && dtype != BD_BF16) return BD_E_BAD_DTYPE;
+    if (B == 0 || S == 0) return BD_OK;
+    if (!Q || !K || !V || !O) return BD_E_NULL;
+    // other geometries: the caller keeps its torch attention
+    if (head_dim != 128 || S % 64 || (sqs | sks | svs | sos | sqb | skb | svb | sob) % 8 || !aligned16(Q) || !aligned16(K) || !aligned16(V) ||
+        !aligned16(O) || (int64_t)B * H * ((S + 127) / 128) > 0x7fffffffLL)
+        return BD_E_BAD_SHAPE;
+    PrefillAttnParams p;
+    p.q = (const unsigned short*)Q; p.k = (const unsigned short*)K; p.v = (const unsigned short*)V; p.o = (unsigned short*)O;
+    p.sqb = sqb; p.sqs = sqs; p.skb = skb; p.sks = sks; p.svb = svb; p.svs = svs; p.sob = sob; p.sos = sos;
+    p.kv_start = kv_start; p.B = B; p.S = S; p.H = H; p.KVH = KVH; p.nqb = (S + 127) / 128;
+    p.c = scale * 1.4426950408889634f; p.causal = causal ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)(p.nqb * H * B));
+    static std::atomic<uint64_t> lds_done[2];               // the kernel needs more than the default dynamic LDS limit
+    const int di = dtype == BD_BF16 ? 1 : 0;
+    const void* fn = di ? (const void*)prefill_attn_kernel<DT_BF16> : (const void*)prefill_attn_kernel<DT_F16>;
+    if (!ensure_dyn_lds(fn, PREFILL_ATTN_LDS, lds_done[di])) return BD_E_LAUNCH;
+    if (di) hipLaunchKernelGGL((prefill_attn_kernel<DT_BF16>), grid, dim3(256), PREFILL_ATTN_LDS, st, p);
+    else hipLaunchKernelGGL((prefill_attn_kernel<DT_F16>), grid, dim3(256), PREFILL_ATTN_LDS, st, p);
     return launch_status();
 }
 

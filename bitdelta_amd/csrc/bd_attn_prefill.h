@@ -34,9 +34,6 @@ struct PrefillAttnParams {
     int B, S, H, KVH, nqb;         // S % 64 == 0; nqb = ceil(S / 128)
     float c;                       // softmax scale * log2(e)
     int causal;
-#ifdef BD_ATTN_DEBUG
-    float* dbg;
-#endif
 };
 
 template <int DT>
@@ -148,11 +145,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     if ((p.causal && key_abs > q_abs) || key_abs < ks) sacc[t][r] = NEG_INF;
                 }
         }
-#ifdef BD_ATTN_DEBUG
-        if (blockIdx.x == 0 && wave == 0 && j == j_lo) {
-            for (int t = 0; t < 2; ++t) for (int r = 0; r < 16; ++r) p.dbg[lane * 64 + 16 * t + r] = sacc[t][r];
-        }
-#endif
         float mx = sacc[0][0];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -193,16 +185,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 const v4s_t ra = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(a0));
                 const v4s_t rb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(a0 + 8 * VROW));
                 const u32x2_t a2 = __builtin_bit_cast(u32x2_t, ra), b2 = __builtin_bit_cast(u32x2_t, rb);
-#ifdef BD_ATTN_DEBUG
-                if (blockIdx.x == 0 && wave == 0 && j == j_lo && ks4 == 1 && dt == 2) {
-                    p.dbg[lane * 64 + 32] = bf16_bits_to_f32(a2.x & 0xffff); p.dbg[lane * 64 + 33] = bf16_bits_to_f32(a2.x >> 16);
-                    p.dbg[lane * 64 + 34] = bf16_bits_to_f32(a2.y & 0xffff); p.dbg[lane * 64 + 35] = bf16_bits_to_f32(a2.y >> 16);
-                    p.dbg[lane * 64 + 36] = bf16_bits_to_f32(b2.x & 0xffff); p.dbg[lane * 64 + 37] = bf16_bits_to_f32(b2.x >> 16);
-                    p.dbg[lane * 64 + 38] = bf16_bits_to_f32(b2.y & 0xffff); p.dbg[lane * 64 + 39] = bf16_bits_to_f32(b2.y >> 16);
-                    for (int w = 0; w < 4; ++w) { p.dbg[lane * 64 + 40 + 2 * w] = bf16_bits_to_f32(pf[ks4][w] & 0xffff); p.dbg[lane * 64 + 41 + 2 * w] = bf16_bits_to_f32(pf[ks4][w] >> 16); }
-                    p.dbg[lane * 64 + 48] = m_run; p.dbg[lane * 64 + 49] = l_run; p.dbg[lane * 64 + 50] = alpha; p.dbg[lane * 64 + 51] = psum;
-                }
-#endif
                 oacc[dt] = mfma32<DT>(u32x4_t{a2.x, a2.y, b2.x, b2.y}, pf[ks4], oacc[dt]);
             }
         }

@@ -74,6 +74,36 @@ def decode_attention(qkv, cos, sin, kcache, vcache, valid, pos, heads, kv_heads)
     return out
 
 
+def prefill_attention_supported(q, k, v):
+    """the shapes bd_srv_prefill_attention takes: [B, S, heads, 128] views (any batch / sequence strides that are multiples of 8 elements,
+    heads contiguous), S a multiple of 64"""
+    if q.dim() != 4 or q.shape[3] != 128 or q.dtype not in DTYPE_CODE or q.shape[1] % 64 or q.shape[2] % k.shape[2]:
+        return False
+    for t in (q, k, v):
+        if t.stride(3) != 1 or t.stride(2) != 128 or t.stride(1) % 8 or t.stride(0) % 8 or t.data_ptr() % 16:
+            return False
+    return k.shape == v.shape and k.shape[:2] == q.shape[:2] and k.dtype == q.dtype == v.dtype
+
+
+def prefill_attention(q, k, v, kv_start=None, causal=True, scale=None):
+    """Flash-style attention of a whole prompt.  q [B, S, heads, 128], k / v [B, S, kv_heads, 128] -- views into a fused q|k|v projection
+    output are fine (after RoPE); kv_start: optional int32 [B] device tensor, first valid key of each sequence (left padding).
+    Returns [B, S, heads * 128] (what the o projection consumes)."""
+    require_gpu(q, k, v)
+    assert prefill_attention_supported(q, k, v), "prefill_attention: unsupported geometry"
+    B, S, H, hd = q.shape
+    out = torch.empty((B, S, H * hd), device=q.device, dtype=q.dtype)
+    if kv_start is not None:
+        assert kv_start.dtype == torch.int32 and kv_start.is_cuda and kv_start.numel() == B and kv_start.is_contiguous()
+    with torch.cuda.device(q.device):
+        check(lib().bd_srv_prefill_attention(ptr(q), ptr(k), ptr(v), ptr(out), B, S, H, k.shape[2], hd, q.stride(0), q.stride(1),
+                                             k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0), out.stride(1),
+                                             ptr(kv_start) if kv_start is not None else None,
+                                             float(scale if scale is not None else hd ** -0.5), int(bool(causal)),
+                                             DTYPE_CODE[q.dtype], stream_ptr()), "srv_prefill_attention")
+    return out
+
+
 def decode_attention_supported(heads, kv_heads, head_dim):
     return head_dim == 128 and heads % kv_heads == 0 and heads // kv_heads in (1, 4, 8)
 

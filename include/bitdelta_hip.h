@@ -171,6 +171,16 @@ int bd_srv_rope(void* X, const void* cos_t, const void* sin_t, int rows, int hea
 int bd_srv_decode_attention(const void* QKV, const void* cos_t, const void* sin_t, void* kcache, void* vcache, void* valid,
                             const int64_t* pos, void* out, int T, int H, int KVH, int head_dim, int Lc,
                             int64_t s_qkv, int64_t s_out, int dtype, void* ws, int64_t ws_bytes, void* stream);
+/* bd_srv_prefill_attention: attention of a whole prompt (the prefill call of the serving loop, demo/demo_backend.py:262-275 -> the HF
+ *   decoder layer's attention with the left-padded attention_mask; what F.scaled_dot_product_attention computes there), flash-style:
+ *   O[b, s, h] = softmax_k(Q[b, s, h] . K[b, k, h / (H/KVH)] * scale) . V[b, k, h / (H/KVH)] over the keys kv_start[b] <= k (<= s when
+ *   causal), fp32 online softmax, 16-bit in / out.  Q / K / V / O are [B, S, heads, 128] through their batch and sequence strides in
+ *   elements (head h at + 128 h): the three slices of a fused q|k|v projection output are passed as they lie.  kv_start [B] int32 on
+ *   the device (left padding) or NULL; query rows with no valid key return 0.  head_dim == 128, S % 64 == 0, strides % 8 == 0,
+ *   16-byte aligned pointers; anything else returns BD_E_BAD_SHAPE and the caller keeps its own attention. */
+int bd_srv_prefill_attention(const void* Q, const void* K, const void* V, void* O, int B, int S, int H, int KVH, int head_dim,
+                             int64_t sqb, int64_t sqs, int64_t skb, int64_t sks, int64_t svb, int64_t svs, int64_t sob, int64_t sos,
+                             const int32_t* kv_start, float scale, int causal, int dtype, void* stream);
 /* scratch for bd_srv_decode_attention's split of the key range over 4 blocks per (tenant, kv head), merged inside the launch by the
  * block that finishes last (0 = the cache is short enough to run unsplit; ws may then be NULL).  Without a workspace the kernel
  * runs unsplit.  CONTRACT: the first 16 KiB of ws (arrival counters) are ZERO when the launch is enqueued; the kernel puts them

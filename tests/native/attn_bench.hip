@@ -50,37 +50,10 @@ int main(int argc, char** argv) {
     p.c = scale * 1.4426950408889634f; p.causal = causal;
     CK(hipFuncSetAttribute((const void*)prefill_attn_kernel<DT_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, PREFILL_ATTN_LDS));
     const dim3 grid(p.nqb * H * B);
-#ifdef BD_ATTN_DEBUG
-    float* ddbg; CK(hipMalloc(&ddbg, 64 * 64 * 4)); CK(hipMemset(ddbg, 0, 64 * 64 * 4)); p.dbg = ddbg;
-#endif
     prefill_attn_kernel<DT_BF16><<<grid, 256, PREFILL_ATTN_LDS>>>(p);
     CK(hipDeviceSynchronize());
     std::vector<unsigned short> out((size_t)B * S * H * HD);
     CK(hipMemcpy(out.data(), dout, out.size() * 2, hipMemcpyDeviceToHost));
-#ifdef BD_ATTN_DEBUG
-    {   // block 0 = last query block, head 0, batch 0; wave 0 rows Q0 .. Q0+31; first tile
-        std::vector<float> dbg(64 * 64);
-        CK(hipMemcpy(dbg.data(), ddbg, dbg.size() * 4, hipMemcpyDeviceToHost));
-        const int Q0 = (p.nqb - 1) * 128;
-        for (int lane : {0, 1, 32, 33, 17}) {
-            const int q = Q0 + (lane & 31), hi = lane >> 5;
-            printf("lane %d (q %d, hi %d)\n  scores got/ref:", lane, q, hi);
-            for (int t = 0; t < 2; ++t) for (int r = 0; r < 16; ++r) {
-                const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                double sref = 0;
-                for (int d = 0; d < HD; ++d) sref += (double)bf2f(qkv[(size_t)q * row + d]) * bf2f(qkv[(size_t)key * row + (size_t)H * HD + d]);
-                printf(" %.2f/%.2f", dbg[lane * 64 + 16 * t + r], sref);
-            }
-            printf("\n  V frag (ks4 1, dt 2) got:");
-            for (int e = 0; e < 8; ++e) printf(" %.3f", dbg[lane * 64 + 32 + e]);
-            printf("\n  V frag expected   :");
-            for (int e = 0; e < 8; ++e) { const int key = 16 + 8 * (e >> 2) + 4 * hi + (e & 3); printf(" %.3f", bf2f(qkv[(size_t)key * row + (size_t)(H + KVH) * HD + 64 + (lane & 31)])); }
-            printf("\n  P frag:");
-            for (int e = 0; e < 8; ++e) printf(" %.4f", dbg[lane * 64 + 40 + e]);
-            printf("\n  m %.3f l %.4f alpha %.3f psum %.4f\n", dbg[lane * 64 + 48], dbg[lane * 64 + 49], dbg[lane * 64 + 50], dbg[lane * 64 + 51]);
-        }
-    }
-#endif
     // sampled rows
     double worst = 0, worst_rel = 0; int bad = 0, nrows = 0;
     std::mt19937 pick(7);

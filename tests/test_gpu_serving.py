@@ -602,3 +602,91 @@ def test_tile_major_weight_is_bit_identical(bd, dtype, T, K, N):
         nw = (1 + 0.1 * torch.randn(T, K, device="cuda", generator=g)).to(dtype)
         assert torch.equal(binary_linear_decode(x, wt, pk, alpha, layout="packed", groups=2, swiglu=True, norm_weight=nw, weight_tiled=True),
                            binary_linear_decode(x, w, pk, alpha, layout="packed", groups=2, swiglu=True, norm_weight=nw))
+
+
+# ---------------------------------------------------------------------------------------------------- prefill attention (caller glue)
+def _attention_fp32(q, k, v, kv_start, causal):
+    """plain fp32 softmax attention on [B, S, heads, 128] views; rows without a valid key -> 0"""
+    B, S, H, _ = q.shape
+    G = H // k.shape[2]
+    qf = q.float().transpose(1, 2)
+    kf = k.float().transpose(1, 2).repeat_interleave(G, dim=1)
+    vf = v.float().transpose(1, 2).repeat_interleave(G, dim=1)
+    sc = qf @ kf.transpose(-1, -2) * (128 ** -0.5)
+    keys = torch.arange(S, device=q.device)
+    ok = torch.ones(B, 1, S, S, dtype=torch.bool, device=q.device)
+    if causal:
+        ok &= (keys[None, :] <= keys[:, None])[None, None]
+    if kv_start is not None:
+        ok &= (keys[None, None, None, :] >= kv_start.view(B, 1, 1, 1))
+    sc = sc.masked_fill(~ok, float("-inf"))
+    p = torch.softmax(sc, dim=-1).nan_to_num(0.0)
+    return (p @ vf).transpose(1, 2).reshape(B, S, H * 128)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,S,H,KVH,causal,pad", [(1, 2048, 32, 32, True, False),      # configs[1]: Llama-2-7B prefill
+                                                  (2, 1024, 32, 8, True, True),        # Mistral heads, left-padded tenant batch
+                                                  (3, 64, 4, 4, True, True), (1, 192, 8, 2, True, False),
+                                                  (2, 256, 8, 1, False, False), (1, 4096, 8, 8, True, False)])
+def test_prefill_attention_vs_fp32_softmax(bd, dtype, B, S, H, KVH, causal, pad):
+    """bd_srv_prefill_attention on the three slices of a fused q|k|v buffer (as the prefill step passes them) against fp32 softmax attention
+    on the same 16-bit inputs and against torch's own SDPA: the gate is 'not worse than stock SDPA + a 16-bit rounding'."""
+    import torch.nn.functional as F
+    from bitdelta_amd import serving_ops as ops
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(B * 1000 + S + H)
+    qkv = torch.randn(B, S, (H + 2 * KVH) * 128, device=dev, generator=g).to(dtype)
+    q4 = qkv[..., :H * 128].view(B, S, H, 128)
+    k4 = qkv[..., H * 128:(H + KVH) * 128].view(B, S, KVH, 128)
+    v4 = qkv[..., (H + KVH) * 128:].view(B, S, KVH, 128)
+    kv_start = None
+    if pad:
+        kv_start = ((torch.arange(B, device=dev) * 37 + 5) % (S // 2)).to(torch.int32)
+    assert ops.prefill_attention_supported(q4, k4, v4)
+    out = ops.prefill_attention(q4, k4, v4, kv_start=kv_start, causal=causal)
+    assert out.shape == (B, S, H * 128) and out.dtype == dtype
+    ref = _attention_fp32(q4, k4, v4, kv_start, causal)
+    assert torch.isfinite(out).all()
+    err = (out.float() - ref).abs().max().item()
+    rel = relerr(out, ref)
+    # stock SDPA on the same inputs (no padding): the yardstick for the tolerance
+    if not pad:
+        sd = F.scaled_dot_product_attention(q4.transpose(1, 2), k4.transpose(1, 2), v4.transpose(1, 2), is_causal=causal,
+                                            enable_gqa=(KVH != H)).transpose(1, 2).reshape(B, S, H * 128)
+        rel_sd = relerr(sd, ref)
+        assert rel <= max(1.5 * rel_sd, 4e-3 if dtype == torch.bfloat16 else 6e-4), (rel, rel_sd)
+    assert rel <= (4e-3 if dtype == torch.bfloat16 else 6e-4), rel
+    assert err <= (3e-2 if dtype == torch.bfloat16 else 4e-3), err
+    if pad:      # query rows in the padding have no valid key: zeros, not NaN
+        for b in range(B):
+            assert (out[b, :int(kv_start[b])] == 0).all()
+
+
+def test_prefill_attention_rejects_other_geometries(bd):
+    from bitdelta_amd import serving_ops as ops
+    x = torch.randn(1, 96, 4, 128, device="cuda", dtype=torch.bfloat16)          # S % 64 != 0
+    assert not ops.prefill_attention_supported(x, x, x)
+    y = torch.randn(1, 128, 4, 64, device="cuda", dtype=torch.bfloat16)          # head_dim 64
+    assert not ops.prefill_attention_supported(y, y, y)
+    with pytest.raises(AssertionError):
+        ops.prefill_attention(x, x, x)
+
+
+def test_prefill_layer_with_hip_attention_matches_sdpa_layer(bd):
+    """the prefill step's decoder layer (bench_model.DecoderLayer) with the HIP attention against the same layer through torch SDPA"""
+    import bench_model as bm
+    dev, dtype = "cuda", torch.bfloat16
+    gen = torch.Generator(device=dev).manual_seed(3)
+    layer = bm.DecoderLayer((1024, 2816, 1, 8, 8, 1000), dev, dtype, gen)
+    x = torch.randn(1, 256, 1024, device=dev, generator=gen).to(dtype)
+    cos, sin = bm.rope_tables(256, 128, dev)
+    cs, sn = cos.to(dtype), sin.to(dtype)
+    half = torch.cat([-sn[:, :64], sn[:, 64:]], dim=1).contiguous()
+    rope = (cs.contiguous(), half, 0)
+    with torch.no_grad():
+        layer.hip_attention = True
+        a = layer(x.clone(), cs, sn, None, rope)
+        layer.hip_attention = False
+        b = layer(x.clone(), cs, sn, None, rope)
+    assert relerr(a, b) < 3e-3, relerr(a, b)
