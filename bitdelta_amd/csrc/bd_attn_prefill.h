@@ -4,7 +4,7 @@
 // demo/demo_backend.py's prefill (HF attention with the left-padded attention_mask, :262-275), without materialising [S, S] scores.
 //
 // One workgroup = 4 waves = 128 query rows of one (batch, head); wave w owns 32 rows.  K / V tiles of 64 keys are register-staged
-// (global -> VGPR while the previous tile computes -> LDS), double-buffered, one barrier per tile; two workgroups per CU (73 KiB of LDS
+// (global -> VGPR while the previous tile computes -> LDS), double-buffered, one barrier per tile; two workgroups per CU (74 KiB of LDS
 // each, 2 waves per SIMD) so that one workgroup's softmax VALU work runs under the other's MFMAs.
 //   S^T = K . Q^T   (v_mfma 32x32x16, A = K fragment, B = Q fragment): D column = query (lane & 31), D rows = keys -> a lane holds 16 of
 //                   the 32 scores of ITS query row per 32-key tile; the row maximum is 31 v_max + one exchange with lane ^ 32.
@@ -12,8 +12,8 @@
 //                   exp2(m_old - m_new) and the final 1 / l are per-LANE scalars, and the P fragment is exactly the lane's own
 //                   exponentiated scores packed in register order: the MFMA k index (hi, e) <-> key 16 kk + 8 (e >> 2) + 4 hi + (e & 3)
 //                   is a permutation the V fragment reads through (two 4-key transposing reads), so no cross-lane traffic for P at all.
-// LDS images: K [64 keys][256 B], 16-byte chunks XOR-swizzled with (key & 15): the b128 fragment reads of 32 keys x 2 chunks are
-// conflict-free; V [64 keys][320 B]: rows 64 bytes apart modulo the 256-byte bank span, so the 16 quads (4 keys x 32 bytes) of a
+// LDS images: K [64 keys][272 B]: rows 16 bytes apart modulo the bank span, so the b128 fragment reads of 16 keys are conflict-free and
+// every read address is one lane constant + an immediate; V [64 keys][320 B]: rows 64 bytes apart modulo the 256-byte bank span, so the 16 quads (4 keys x 32 bytes) of a
 // transposing read group and its neighbour group cover all banks once.
 // Causal: tiles past the diagonal of the workgroup are never loaded, a wave skips the tiles past ITS diagonal, and only tiles that
 // straddle it are masked.  Heavy (late) query blocks are dispatched first.
@@ -22,7 +22,7 @@
 
 namespace bd {
 
-constexpr int PREFILL_ATTN_LDS = 2 * (64 * 256 + 64 * 320);
+constexpr int PREFILL_ATTN_LDS = 2 * (64 * 272 + 64 * 320);
 
 struct PrefillAttnParams {
     const unsigned short* q;       // [B, S, H, 128] through strides (elements): batch, sequence; head h at + 128 h
@@ -39,7 +39,7 @@ struct PrefillAttnParams {
 template <int DT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) prefill_attn_kernel(const PrefillAttnParams p) {
     constexpr int HD = 128, QW = 32, QB = 128, KVB = 64;
-    constexpr int KROW = 256, VROW = 320;
+    constexpr int KROW = 272, VROW = 320;
     constexpr int K_BYTES = KVB * KROW, V_BYTES = KVB * VROW, BUF = K_BYTES + V_BYTES;
     extern __shared__ __attribute__((aligned(16))) char lds[];      // 2 * BUF = 72 KiB (dynamic: above the static limit)
     typedef short v4s_t __attribute__((ext_vector_type(4)));
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int key = ld_key + 16 * i;
-            *(u32x4_t*)(base + key * KROW + ((ld_ch ^ (key & 15)) * 16)) = kst[i];
+            *(u32x4_t*)(base + key * KROW + ld_ch * 16) = kst[i];
             *(u32x4_t*)(base + K_BYTES + key * VROW + ld_ch * 16) = vst[i];
         }
     };
@@ -102,8 +102,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     // transposing-read lane constants: group G = lane >> 4 (G >> 1 = hi, G & 1 = 16-column half), source lane t16: key row t16 >> 2, quad t16 & 3
     const int t16 = lane & 15, G = lane >> 4;
     const uint32_t v_lane = (uint32_t)((4 * hi + (t16 >> 2)) * VROW + (16 * (G & 1) + 4 * (t16 & 3)) * 2);
-    const uint32_t k_lane_row = (uint32_t)l31;
+    const uint32_t k_lane = (uint32_t)(l31 * KROW + 16 * hi);         // key row l31 (+ 32 t), chunk 2 s + hi
 
+    // value of lane ^ 32: v_permlane32_swap exchanges the upper half of one register with the lower half of the other (no LDS round trip)
+    auto other_half = [](float x) -> float {
+        const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+        return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
+    };
     auto pack2 = [&](float lo, float hi_) -> uint32_t {
         if constexpr (DT == DT_BF16) {
             // s_nop: the operands come straight from v_exp_f32, and a transcendental result needs one wait state before a VALU
@@ -119,20 +124,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     auto compute = [&](int buf, int j) {
         const int kv0 = j * KVB;
         if (p.causal && kv0 > qw0 + QW - 1) return;                        // past this wave's diagonal (wave-uniform)
-        const char* kb = lds + buf * BUF;
-        const char* vb = kb + K_BYTES;
+        const char* kb = lds + (uint32_t)(buf * BUF) + k_lane;             // + immediates: no per-read address arithmetic
+        const char* vb = lds + (uint32_t)(buf * BUF + K_BYTES) + v_lane;
         f32x16_t sacc[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[t][r] = 0.f;
-            const uint32_t key = 32u * t + k_lane_row;
+        // the two 32-key accumulators alternate: a dependent MFMA chain on one accumulator leaves the matrix pipe idle between links
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const u32x4_t kf = *(const u32x4_t*)(kb + key * KROW + (((2 * s + hi) ^ (key & 15)) * 16));
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const u32x4_t kf = *(const u32x4_t*)(kb + (32 * t * KROW + 32 * s));
                 sacc[t] = mfma32<DT>(kf, qf[s], sacc[t]);
             }
-        }
         // masks: keys past the query (causal) or before the first valid key (left padding); only on tiles that straddle either edge
         const bool edge = (p.causal && kv0 + KVB - 1 > qw0) || ks > kv0;
         if (edge) {
@@ -150,7 +156,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[t][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = fmaxf(mx, other_half(mx));
         const float m_new = fmaxf(m_run, mx);
         const float m_safe = m_new == NEG_INF ? 0.f : m_new;               // a row with no valid key so far: every p = exp2(-inf) = 0
         const float mc = m_safe * p.c;
@@ -181,7 +187,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int ks4 = 0; ks4 < 4; ++ks4) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const char* a0 = vb + v_lane + (uint32_t)(16 * ks4 * VROW + 64 * dt);
+                const char* a0 = vb + (16 * ks4 * VROW + 64 * dt);
                 const v4s_t ra = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(a0));
                 const v4s_t rb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(a0 + 8 * VROW));
                 const u32x2_t a2 = __builtin_bit_cast(u32x2_t, ra), b2 = __builtin_bit_cast(u32x2_t, rb);
@@ -193,6 +199,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (j_lo <= j_hi) {
         gload(j_lo);
         lwrite(0);
+        // every load so far (the query fragments too) has landed BEFORE the loop: left pending, the compiler's wait-count pass carries them
+        // across the back edge and makes each QK^T MFMA of every tile wait for the loads of the NEXT tile issued just above it
+        __builtin_amdgcn_s_waitcnt(0x0f70);                                // vmcnt(0)
         __syncthreads();
         for (int j = j_lo; j <= j_hi; ++j) {
             const int cur = (j - j_lo) & 1;
@@ -204,7 +213,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
 
     // ---- epilogue: 1 / l per lane, this wave's [32 rows][128] image through LDS (row pitch 272 B), whole 256-byte rows out
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = l_run + other_half(l_run);
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
     constexpr int OROW = 272;
     char* ob = lds + wave * (QW * OROW);
