@@ -192,6 +192,7 @@ class TenantDecoder(nn.Module):
         self.register_buffer("sin", sin, persistent=False)
         self._graph = None
         self.fast_glue = True       # decode steps use the HIP glue kernels (serving_ops); False = stock torch ops everywhere
+        self.hip_prefill_attention = True      # prefill: RoPE + flash-style attention kernels instead of torch SDPA over a [L, Lc] mask
         self.fuse_glue = True       # ... and fold RMSNorm / SwiGLU into the Linear launches where the shapes allow (bit-identical)
         # Which glue is folded where, by same-process A/B of the whole step (profiles/r02_decode_step.txt; ms per step, Mistral-7B x 6,
         # tile-major weights): separate launches 5.35 | SwiGLU in gate|up's epilogue 5.11 | + RMSNorm in gate|up's prologue 5.17 |
@@ -289,6 +290,18 @@ class TenantDecoder(nn.Module):
         if S == 1 and self.fast_glue and ops.decode_attention_supported(heads, kvh, hd):
             # decode: RoPE + cache append + attention over the valid keys in ONE launch (pos_idx is a one-element device tensor)
             a = ops.decode_attention(qkv, self.cos, self.sin, ck, cv, cache["valid"], pos_idx, heads, kvh)
+        elif (S > 1 and self.fast_glue and cache.get("kv_start") is not None and hd == 128 and S % 64 == 0 and qkv.is_contiguous()
+              and not layer.qkv.interleave8):
+            # prefill from position 0: in-place RoPE on the q and k slices of the fused projection output, flash-style attention over the
+            # left-padded prompts (keys kv_start[t] .. query position), then the K / V rows go into the cache
+            nq, nk = heads * hd, kvh * hd
+            qf, kf, vf = qkv[..., :nq], qkv[..., nq:nq + nk], qkv[..., nq + nk:]
+            ops.rope_(qf, self.cos, self.sin, heads, S, 0)
+            ops.rope_(kf, self.cos, self.sin, kvh, S, 0)
+            k4, v4 = kf.view(T, S, kvh, hd), vf.view(T, S, kvh, hd)
+            a = ops.prefill_attention(qf.view(T, S, heads, hd), k4, v4, kv_start=cache["kv_start"], causal=True)
+            ck[:, :, :S] = k4.transpose(1, 2)
+            cv[:, :, :S] = v4.transpose(1, 2)
         else:
             q, k, v = layer.qkv.split(qkv)
             q = _rope(q.view(T, S, heads, hd).transpose(1, 2), cos, sin)
@@ -354,7 +367,15 @@ class TenantDecoder(nn.Module):
         mask = causal[None, None] & cache["valid"][:, None, None, :]
         # fully masked query rows (left pads) would be NaN in softmax: let a pad see itself; its output is never used
         mask = mask | torch.eye(L, Lc, dtype=torch.bool, device=self.dev)[None, None]
-        return self.forward(ids, pos_idx, cache, mask)
+        # left-padded prompts (prepare() builds them so): the HIP prefill attention takes the first valid key of each tenant instead of
+        # the [T, 1, L, Lc] mask; any other mask shape keeps the torch attention
+        am = attention_mask.bool()
+        left_padded = bool((am[:, 1:] | ~am[:, :-1]).all()) if L > 1 else True
+        cache["kv_start"] = (L - am.sum(dim=1)).to(torch.int32) if (left_padded and self.hip_prefill_attention) else None
+        try:
+            return self.forward(ids, pos_idx, cache, mask)
+        finally:
+            cache["kv_start"] = None
 
     def _decode_step(self, st):
         """one greedy step on static buffers: st['tok'] [T,1] -> logits -> argmax -> st['tok']; position / masks advance on device"""

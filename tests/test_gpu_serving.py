@@ -466,7 +466,7 @@ def test_serving_loop_fast_glue_matches_torch_glue(bd):
     slow, _ = dec.generate(prompts, max_new_tokens=8, use_graph=False)
     agree = (fast == slow).float().mean().item()
     assert agree >= 0.9, (agree, fast, slow)                              # greedy paths may fork at a near-tie; they must not diverge wholesale
-    assert torch.equal(fast[:, 0], slow[:, 0])                            # the prefill token is produced by identical code
+    assert torch.equal(fast[:, 0], slow[:, 0])                            # same prefill token through either attention
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -690,3 +690,30 @@ def test_prefill_layer_with_hip_attention_matches_sdpa_layer(bd):
         layer.hip_attention = False
         b = layer(x.clone(), cs, sn, None, rope)
     assert relerr(a, b) < 3e-3, relerr(a, b)
+
+
+@pytest.mark.parametrize("name,lens", [("tiny128", (9, 64, 33, 70)), ("mistral-1layer", (5, 200, 128, 77, 256, 31))])
+def test_serving_loop_prefill_through_hip_attention_matches_torch_attention(bd, name, lens):
+    """the prefill call of the serving loop (left-padded tenant batch): RoPE + bd_srv_prefill_attention against rope + SDPA over the
+    [T, 1, L, Lc] mask -- logits of the last position and the cached K / V rows of the valid positions"""
+    from bitdelta_amd.serving_loop import TenantDecoder
+    T = len(lens)
+    dec = TenantDecoder.synthetic(name, T, "cuda", dtype=torch.bfloat16, seed=5, max_len=320, shared_heads=True)
+    g = torch.Generator().manual_seed(4)
+    prompts = [torch.randint(1, 500, (n,), generator=g).tolist() for n in lens]
+    ids, am = dec.prepare(prompts)
+    out = {}
+    for flag in (True, False):
+        dec.hip_prefill_attention = flag
+        cache = dec.new_cache(ids.shape[1] + 8)
+        logits = dec.prefill(ids, am, cache)
+        assert cache["kv_start"] is None
+        out[flag] = (logits.float(), [k.float().clone() for k in cache["k"]], [v.float().clone() for v in cache["v"]])
+    a, b = out[True], out[False]
+    assert relerr(a[0][:, -1], b[0][:, -1]) < 2e-2
+    L = ids.shape[1]
+    for t, n in enumerate(lens):                     # valid rows only: the padding rows differ by construction (zeros vs self-attention)
+        for ka, kb_ in zip(a[1], b[1]):
+            assert relerr(ka[t, :, L - n:L], kb_[t, :, L - n:L]) < 2e-2
+        for va, vb in zip(a[2], b[2]):
+            assert relerr(va[t, :, L - n:L], vb[t, :, L - n:L]) < 2e-2
