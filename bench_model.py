@@ -153,8 +153,7 @@ class DecoderLayer(nn.Module):
             nq, nk = self.heads * self.hd, self.kvh * self.hd
             qf, kf, vf = qkv[..., :nq], qkv[..., nq:nq + nk], qkv[..., nq + nk:]
             if self.hd == 128 and rope is not None:
-                ops.rope_(qf, rope[0], rope[1], self.heads, S, rope[2])
-                ops.rope_(kf, rope[0], rope[1], self.kvh, S, rope[2])
+                ops.rope_(qkv[..., :nq + nk], rope[0], rope[1], self.heads + self.kvh, S, rope[2])      # q and k heads: one launch
                 q4, k4, v4 = qf.view(B, S, self.heads, self.hd), kf.view(B, S, self.kvh, self.hd), vf.view(B, S, self.kvh, self.hd)
                 if kv is None and S > 1 and self.hip_attention and ops.prefill_attention_supported(q4, k4, v4):
                     # whole-prompt causal attention straight on the three slices of the fused projection output (no head transposes,

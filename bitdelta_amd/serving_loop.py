@@ -296,8 +296,7 @@ class TenantDecoder(nn.Module):
             # left-padded prompts (keys kv_start[t] .. query position), then the K / V rows go into the cache
             nq, nk = heads * hd, kvh * hd
             qf, kf, vf = qkv[..., :nq], qkv[..., nq:nq + nk], qkv[..., nq + nk:]
-            ops.rope_(qf, self.cos, self.sin, heads, S, 0)
-            ops.rope_(kf, self.cos, self.sin, kvh, S, 0)
+            ops.rope_(qkv[..., :nq + nk], self.cos, self.sin, heads + kvh, S, 0)          # q and k heads: one launch
             k4, v4 = kf.view(T, S, kvh, hd), vf.view(T, S, kvh, hd)
             a = ops.prefill_attention(qf.view(T, S, heads, hd), k4, v4, kv_start=cache["kv_start"], causal=True)
             ck[:, :, :S] = k4.transpose(1, 2)
