@@ -483,6 +483,7 @@ def main():
         "config": {"workload": f"{args.model} base + one 1-bit delta, prefill seq {args.seq}, batch 1 per GPU "
                                f"(BASELINE.json configs[1]); {n_layers} layers x 7 fused BinaryDiff projections",
                    "seq_len": args.seq, "global_batch": world, "parallelism": f"dp{world} independent replicas, no collective",
+                   "glue": "RMSNorm: torch; RoPE (q|k in place), causal attention (bd_srv_prefill_attention), SwiGLU: HIP kernels of this library",
                    "valid": args.layers is None},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_BF16_TFLOPS,
