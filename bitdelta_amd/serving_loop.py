@@ -192,6 +192,7 @@ class TenantDecoder(nn.Module):
         self.register_buffer("sin", sin, persistent=False)
         self._graph = None
         self.fast_glue = True       # decode steps use the HIP glue kernels (serving_ops); False = stock torch ops everywhere
+        self.swiglu_epilogue = False  # prefill: SwiGLU inside the gate|up GEMM (256-row tiles only; measured slower than GEMM + one pass)
         self.hip_prefill_attention = True      # prefill: RoPE + flash-style attention kernels instead of torch SDPA over a [L, Lc] mask
         self.fuse_glue = True       # ... and fold RMSNorm / SwiGLU into the Linear launches where the shapes allow (bit-identical)
         # Which glue is folded where, by same-process A/B of the whole step (profiles/r02_decode_step.txt; ms per step, Mistral-7B x 6,
@@ -315,11 +316,12 @@ class TenantDecoder(nn.Module):
             act = layer.gate_up.forward_fused(x, layer.norm2, self.eps, swiglu=True)   # RMSNorm -> gate|up -> SwiGLU: one launch
         elif fuse and layer.gate_up.interleave8 and layer.gate_up._decode_ok(x):
             act = layer.gate_up.forward_fused(self._norm(x, layer.norm2), None, self.eps, swiglu=True)   # gate|up -> SwiGLU: one launch
-        elif self.fast_glue and layer.gate_up.swiglu_ok(x):
-            act = layer.gate_up.forward_swiglu(self._norm(x, layer.norm2))       # prefill: gate|up -> SwiGLU in the GEMM's epilogue
+        elif self.fast_glue and self.swiglu_epilogue and S >= 256 and layer.gate_up.swiglu_ok(x):
+            act = layer.gate_up.forward_swiglu(self._norm(x, layer.norm2))       # prefill: gate|up -> SwiGLU in the GEMM's epilogue (A/B)
         else:
             gu = layer.gate_up(self._norm(x, layer.norm2))
-            if S <= 16 and self.fast_glue and inter % 8 == 0:
+            if self.fast_glue and inter % 8 == 0 and (S <= 16 or layer.gate_up.interleave8):
+                # one elementwise pass on the projection output (any prompt length when the rows are interleaved in blocks of 8)
                 act = ops.swiglu_interleaved8(gu) if layer.gate_up.interleave8 else ops.swiglu(gu, inter)
             else:
                 g, u = layer.gate_up.split(gu)
