@@ -60,3 +60,42 @@ def test_delta_bmm_linear_and_odd(bd, b, m, kw, n, seed, dtype):
     assert torch.allclose(f(x, ~p), -y, rtol=1e-5, atol=1e-5)
     x2 = (x.float() * 2).to(dtype)
     assert torch.equal(f(x2, p), 2 * y)
+
+
+def test_prefill_attention_random_geometries():
+    """bd_srv_prefill_attention over random (batch, length, heads, kv heads, padding, causal) against fp32 softmax attention"""
+    import random
+    from bitdelta_amd import serving_ops as ops
+    rnd = random.Random(11)
+    dev = "cuda"
+    for case in range(24):
+        B = rnd.choice([1, 2, 3, 5])
+        S = 64 * rnd.randint(1, 9)
+        KVH = rnd.choice([1, 2, 4])
+        H = KVH * rnd.choice([1, 2, 4, 8])
+        causal = rnd.random() < 0.75
+        dtype = rnd.choice([torch.bfloat16, torch.float16])
+        g = torch.Generator(device=dev).manual_seed(case)
+        # separately allocated q / k / v with their own (padded) strides
+        q = torch.randn(B, S, H * 128 + 64, device=dev, generator=g).to(dtype)[..., :H * 128].view(B, S, H, 128)
+        k = (torch.randn(B, S, KVH * 128, device=dev, generator=g) * rnd.choice([0.3, 1.0, 3.0])).to(dtype).view(B, S, KVH, 128)
+        v = torch.randn(B, S + 3, KVH * 128, device=dev, generator=g).to(dtype)[:, :S].view(B, S, KVH, 128)
+        kv_start = None
+        if rnd.random() < 0.6:
+            kv_start = torch.tensor([rnd.randint(0, S - 1) for _ in range(B)], dtype=torch.int32, device=dev)
+        assert ops.prefill_attention_supported(q, k, v)
+        out = ops.prefill_attention(q, k, v, kv_start=kv_start, causal=causal).float().view(B, S, H, 128)
+        G = H // KVH
+        sc = torch.einsum("bqhd,bkhd->bhqk", q.float(), k.float().repeat_interleave(G, dim=2)) * 128 ** -0.5
+        keys = torch.arange(S, device=dev)
+        ok = torch.ones(B, 1, S, S, dtype=torch.bool, device=dev)
+        if causal:
+            ok &= (keys[None, :] <= keys[:, None])[None, None]
+        if kv_start is not None:
+            ok &= keys[None, None, None, :] >= kv_start.view(B, 1, 1, 1)
+        p = torch.softmax(sc.masked_fill(~ok, float("-inf")), dim=-1).nan_to_num(0.0)
+        ref = torch.einsum("bhqk,bkhd->bqhd", p, v.float().repeat_interleave(G, dim=2))
+        assert torch.isfinite(out).all()
+        err = (out - ref).abs().max().item()
+        tol = 4e-2 if dtype == torch.bfloat16 else 5e-3
+        assert err <= tol, (case, B, S, H, KVH, causal, dtype, err)
