@@ -1109,7 +1109,10 @@ extern "C" int bd_srv_rope(void* X, const void* cos_t, const void* sin_t, int ro
     return launch_status();
 }
 
-constexpr int ATTN_SPLITS = 4;
+#ifndef BD_ATTN_SPLITS
+#define BD_ATTN_SPLITS 4
+#endif
+constexpr int ATTN_SPLITS = BD_ATTN_SPLITS;   // (a build-time knob for A/B runs; 4 measured best, profiles/r03_decode_attn_splits.txt)
 constexpr int64_t ATTN_TICKET_BYTES = 16384;       // one arrival counter per (tenant, kv head): T * KVH <= 4096
 extern "C" int64_t bd_srv_decode_attention_workspace_bytes(int T, int H, int KVH, int head_dim, int Lc) {
     if (T <= 0 || H <= 0 || KVH <= 0 || Lc < 256) return 0;       // short caches run unsplit
