@@ -77,3 +77,55 @@ def test_m0_only_written_by_the_dma_statements(kernels):
     for name, body in ks.items():
         writers = [l.strip() for l in body if re.search(r"\bm0\b", l) and not l.strip().startswith(";")]
         assert writers and all(w.startswith("s_add_u32 m0,") for w in writers), (name, [w for w in writers if not w.startswith("s_add_u32 m0,")][:5])
+
+
+# ---------------------------------------------------------------------------------------------------- prefill attention kernel
+@pytest.fixture(scope="module")
+def attn_kernels(tmp_path_factory):
+    import isa_gaps
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "attn.s"
+    src = os.path.join(ROOT, "tests", "native", "attn_isa_probe.hip")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-o", str(out), src])
+    ks = {name: body for name, body in isa_gaps.kernels(str(out)) if "prefill_attn_kernel" in name}
+    assert len(ks) == 2
+    return ks
+
+
+def test_prefill_attention_isa(attn_kernels):
+    """The compile-time properties the attention kernel's correctness and speed hang on, each a bug found on the device:
+    * two workgroups per CU: <= 256 VGPRs, no scratch;
+    * every inline-assembly v_cvt_pk_bf16_f32 is preceded by its s_nop (its operands come straight from v_exp_f32; without the wait
+      state the P fragments were wrong);
+    * no vmcnt wait between the top of the tile loop and the last QK^T MFMA (query-fragment loads left pending at loop entry made every
+      tile wait for the NEXT tile's K / V loads there);
+    * per tile: 32 MFMAs, 33 exponentials, 16 + 32 LDS fragment reads, the lane ^ 32 exchange on the VALU (no ds_bpermute)."""
+    for name, body in attn_kernels.items():
+        blob = "\n".join(body)
+        bf16 = "ILi1E" in name
+        assert "scratch_" not in blob, name
+        nxt = re.search(r"\.amdhsa_next_free_vgpr (\d+)", blob)
+        assert nxt and int(nxt.group(1)) <= 256, (name, nxt)
+        mf = "v_mfma_f32_32x32x16_bf16" if bf16 else "v_mfma_f32_32x32x16_f16"
+        idx = [i for i, l in enumerate(body) if mf in l]
+        assert len(idx) == 32, (name, len(idx))
+        # the tile loop: backward branch target that precedes the first MFMA
+        labels = {l.split(":")[0]: i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)}
+        back = [(labels[m.group(1)], i) for i, l in enumerate(body)
+                for m in [re.search(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", l)] if m and m.group(1) in labels and labels[m.group(1)] < i]
+        loops = [(lo, hi) for lo, hi in back if lo < idx[0] and hi > idx[-1]]
+        assert loops, name
+        lo, hi = max(loops)                                           # innermost loop around all 32 MFMAs
+        qk_section = body[lo:idx[15] + 1]
+        assert not any(re.search(r"s_waitcnt.*vmcnt", l) for l in qk_section), [l for l in qk_section if "vmcnt" in l]
+        loop = body[lo:hi]
+        assert sum("v_exp_f32" in l for l in loop) == 33, name
+        assert sum("ds_read_b64_tr_b16" in l for l in loop) == 32 and sum(re.search(r"\bds_read_b128\b", l) is not None for l in loop) == 16, name
+        assert "ds_bpermute" not in blob and "v_permlane32_swap" in blob, name
+        if bf16:
+            code = [l.strip() for l in body if l.strip() and not l.strip().startswith((";", "."))]
+            for i, l in enumerate(code):
+                if l.startswith("v_cvt_pk_bf16_f32"):
+                    assert code[i - 1].startswith("s_nop"), (name, code[i - 2:i + 1])
