@@ -5,14 +5,18 @@
 
 Workload of `value` (BASELINE.json configs[1]): Llama-2-7B base + one 1-bit delta (Vicuna-7B-v1.5 shapes), prefill of one
 2048-token sequence per GPU, synthetic weights/activations (SURVEY.md 8d recipe).  A "step" is one full prefill forward:
-32 layers x 7 fused BinaryDiff projections (the hot path, hand-written HIP) + attention/norm/embedding/lm_head (stock torch,
-the callers of the path).  N GPUs = N independent replicas (weak scaling, no data-path collective).
+32 layers x 4 fused-Linear launches (q|k|v, o + residual, gate|up, down + residual = the layer's 7 BinaryDiff projections; the hot
+path, hand-written HIP) + attention / RoPE / SwiGLU (HIP glue of this library) + norm / embedding / lm_head (stock torch).
+N GPUs = N independent replicas (weak scaling, no data-path collective).
 
 Prints ONE JSON line (rank 0) with the driver contract fields plus
   roofline      the dominant kernel (fused base+delta MFMA GEMM): algorithmic FLOPs of its launches / their summed durations,
                 measured live with HIP events on the launch stream inside the timed region.  `traffic` is null unless THIS run
                 measured it (PMC counters cannot be read in-process; the rocprofv3 passes live under profiles/)
-  delta_gemm    the W1A16 delta-GEMM alone at 4096x4096, M = 4096 (the north star's 70 %-of-peak target), same method
+  delta_gemm    the W1A16 delta-GEMM alone at K = N = 4096, M in {4096, 8192, 16384} (the north star's 70 %-of-peak target), same method
+  vendor_gemm   the vendor's bf16 GEMM (torch.matmul -> hipBLASLt) at the same three shapes, same process, same warm-up: the
+                calibration row for "what fraction of 2.5 PF does ANY dense bf16 GEMM reach on this board at its power cap"
+  decode_7b     SURVEY.md 8(d) C2 "plus decode steps": Llama-2-7B + ONE delta, single-sequence greedy decode tokens/s (hipGraph)
   mt_decode     BASELINE.json configs[2] in the same run: Mistral-7B base + 6 tenant deltas, batched greedy decode through the
                 serving loop (fused q+k+v / gate+up launches, per-tenant embedding / norms / lm_head, argmax feedback, KV cache),
                 eager and as a hipGraph replay; HBM roofline of its Linear launches
@@ -107,47 +111,75 @@ class LaunchTimer:
         return len(self.records), ms, fl, by
 
 
-def cpu_baseline(seq=2048):
+def physical_cores():
+    """One hardware thread per physical core (first SMT sibling of each core), from sysfs; falls back to every visible CPU."""
+    firsts = set()
+    try:
+        allowed = os.sched_getaffinity(0)
+        for c in sorted(allowed):
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as fh:
+                sib = fh.read().strip().replace("-", ",").split(",")
+            first = min(int(t) for t in sib if t != "")
+            firsts.add(first if first in allowed else c)
+    except OSError:
+        return sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    return sorted(firsts)
+
+
+def cpu_baseline(seq=2048, reps=5):
     """Reference-equivalent CPU path (oracle/torch_port.py) on the SAME unit of work as the GPU step: one 2048-token sequence through
-    a decoder layer's 7 BinaryDiff projections (Llama-2-7B shapes) on ALL host threads (BASELINE.md 3:
-    torch.set_num_threads(os.cpu_count())).  The 7 projections have three distinct shapes, so the bounded sample is one timed call per
-    distinct shape at the full sequence length; a layer is 4 x [4096x4096] + 2 x [11008x4096] + 1 x [4096x11008] and the model is 32
-    layers.  Variant 1 unpacks the masks inside the timed region (what a CPU run of the reference does); variant 2 is the pure
-    torch.matmul baseline with pre-unpacked signs.  Attention/norms are excluded (GPU side: about 11 % of the step)."""
+    a decoder layer's 7 BinaryDiff projections (Llama-2-7B shapes).  BASELINE.md 3 hygiene: the process is pinned to ONE hardware
+    thread per PHYSICAL core and torch runs that many threads (SMT siblings and over-subscription made round 3's figure swing 14x
+    between boxes); every distinct projection shape gets one untimed warm-up call, then the MEDIAN of `reps` timed calls.  A layer is
+    4 x [4096x4096] + 2 x [11008x4096] + 1 x [4096x11008], the model 32 layers.  Variant 1 unpacks the masks inside the timed region
+    (what a CPU run of the reference does); variant 2 is the pure torch.matmul baseline with pre-unpacked signs.  Attention / norms
+    are excluded (GPU side: about 10 % of the step)."""
     from oracle import torch_port as tp
-    ncpu = os.cpu_count() or 1
-    torch.set_num_threads(ncpu)
+    cores = physical_cores()
+    old_aff = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    old_threads = torch.get_num_threads()
+    try:
+        if old_aff is not None:
+            os.sched_setaffinity(0, cores)
+    except OSError:
+        pass
+    torch.set_num_threads(len(cores))
     torch.manual_seed(0)
     hid, inter = 4096, 11008
     distinct = [((hid, hid), 4), ((inter, hid), 2), ((hid, inter), 1)]          # ((out, in), how many per layer)
-    warm = torch.randn(1, 16, 256).bfloat16()
-    tp.forward_unpack_in_loop(warm, (torch.randn(256, 256) * 0.02).bfloat16(), torch.zeros(8, 256, dtype=torch.int32), torch.tensor(1e-3))
     t1 = t2 = 0.0
-    detail = []
+    detail, spread = [], []
 
-    def best_of(fn, budget=4.0, reps=3):            # one call when it is slow, the best of up to three when it is fast
-        best, spent = float("inf"), 0.0
+    def median_of(fn):
+        fn()                                          # warm-up (page faults, thread pool, oneDNN primitive cache)
+        ts = []
         for _ in range(reps):
             t0 = time.perf_counter()
             fn()
-            dt = time.perf_counter() - t0
-            best, spent = min(best, dt), spent + dt
-            if spent > budget:
-                break
-        return best
-    for (n_out, n_in), count in distinct:
-        w = (torch.randn(n_out, n_in) * 0.02).bfloat16()
-        mask = torch.randint(-2 ** 31, 2 ** 31 - 1, (n_in // 32, n_out), dtype=torch.int64).to(torch.int32)
-        c = torch.tensor(4e-4)
-        x = torch.randn(1, seq, n_in).bfloat16()
-        a = best_of(lambda: tp.forward_unpack_in_loop(x, w, mask, c))
-        s = (tp.unpack32(mask) * 2 - 1).to(torch.bfloat16)
-        tp.forward_preunpacked(x[:, :64], w, s, c)
-        b = best_of(lambda: tp.forward_preunpacked(x, w, s, c))
-        t1 += count * a
-        t2 += count * b
-        detail.append(f"[{n_out}x{n_in}] {a:.2f} s / {b:.2f} s")
-        del w, mask, s, x
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return ts[len(ts) // 2], ts[-1] / ts[0]
+    try:
+        for (n_out, n_in), count in distinct:
+            w = (torch.randn(n_out, n_in) * 0.02).bfloat16()
+            mask = torch.randint(-2 ** 31, 2 ** 31 - 1, (n_in // 32, n_out), dtype=torch.int64).to(torch.int32)
+            c = torch.tensor(4e-4)
+            x = torch.randn(1, seq, n_in).bfloat16()
+            a, sa = median_of(lambda: tp.forward_unpack_in_loop(x, w, mask, c))
+            s_ = (tp.unpack32(mask) * 2 - 1).to(torch.bfloat16)
+            b, sb = median_of(lambda: tp.forward_preunpacked(x, w, s_, c))
+            t1 += count * a
+            t2 += count * b
+            spread += [sa, sb]
+            detail.append(f"[{n_out}x{n_in}] {a:.2f} s / {b:.2f} s")
+            del w, mask, s_, x
+    finally:
+        torch.set_num_threads(old_threads)
+        try:
+            if old_aff is not None:
+                os.sched_setaffinity(0, old_aff)
+        except OSError:
+            pass
     cpu = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -156,14 +188,16 @@ def cpu_baseline(seq=2048):
                 break
     except OSError:
         pass
-    return {"value": seq / (32 * t1), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": seq / (32 * t1), "unit": "tokens/s", "cores": len(cores), "kind": "port",
             "matmul_only": {"value": seq / (32 * t2), "unit": "tokens/s",
                             "what": "variant 2 of BASELINE.md 3: pre-unpacked signs, torch.matmul only (x@W.T + coeff*(x@S))",
                             "ms_per_layer": t2 * 1e3},
-            "sample": f"same unit as the GPU step (one {seq}-token sequence, Llama-2-7B projections): one timed call per DISTINCT projection "
-                      f"shape at seq {seq} (variant 1 / variant 2: " + ", ".join(detail) + f"), layer = 4+2+1 of them = {t1:.1f} s, x32 layers; "
-                      f"value = variant 1 (unpack inside the timed region, the reference's CPU-executable path); host: {cpu}, "
-                      f"os.cpu_count()={ncpu}, torch threads={torch.get_num_threads()}, torch {torch.__version__}"}
+            "max_over_min_of_timed_calls": max(spread) if spread else None,
+            "sample": f"same unit as the GPU step (one {seq}-token sequence, Llama-2-7B projections): per DISTINCT projection shape one "
+                      f"warm-up + the median of {reps} timed calls at seq {seq} (variant 1 / variant 2: " + ", ".join(detail) +
+                      f"), layer = 4+2+1 of them = {t1:.1f} s, x32 layers; value = variant 1 (unpack inside the timed region, the "
+                      f"reference's CPU-executable path); host: {cpu}, os.cpu_count()={os.cpu_count()}, pinned to {len(cores)} physical "
+                      f"cores, torch threads={len(cores)}, torch {torch.__version__}"}
 
 
 def parity_block(dev):
@@ -222,6 +256,37 @@ def parity_block(dev):
         "bit_equal": float((d == 0).float().mean()),
         "fp32_mode_rel_frobenius": float(((y32[:, :, cols.to(dev)].cpu().double() - ref32.double()).norm() / ref32.double().norm())),
         "rel_frobenius_16bit_vs_fp32_oracle": float(((got.double() - ref32.double()).norm() / ref32.double().norm()))}
+    # (3) the launches the headline number is made of: q|k|v as ONE Linear (three scale groups) and gate|up as ONE 8-row-interleaved
+    #     Linear (two scales), M = 2048, built exactly as bench_model.DecoderLayer builds them; oracle on stored rows that straddle
+    #     every group / interleave / tile boundary, each with its own scale
+    from bench_model import FusedSingleTenantLinear
+    for name, shapes, il8 in (("fused_qkv_2048x4096_to_12288_G3", [(4096, 4096)] * 3, False),
+                              ("fused_gate_up_2048x4096_to_22016_il8", [(11008, 4096)] * 2, True)):
+        gd = torch.Generator(device=dev).manual_seed(77)
+        lin = FusedSingleTenantLinear(shapes, dev, torch.bfloat16, gd, interleave8=il8).lin
+        N = lin.weight.shape[0]
+        gsz = N // lin.groups
+        cs = set([0, 1, 7, 8, 15, 16, 127, 128, 255, 256, N - 257, N - 256, N - 129, N - 128, N - 17, N - 16, N - 9, N - 8, N - 1])
+        for gi in range(1, lin.groups if not il8 else 4):
+            b = gi * gsz if not il8 else gi * (N // 4) // 16 * 16
+            cs.update([b - 2, b - 1, b, b + 1, b + 7, b + 8])
+        cs.update(torch.randint(0, N, (32,), generator=torch.Generator().manual_seed(3)).tolist())
+        cols = torch.tensor(sorted(c for c in cs if 0 <= c < N))
+        x = torch.randn(1, 2048, K, device=dev, generator=gd).bfloat16()
+        y16 = lin(x)
+        v = _lib.lib().bd_last_gemm_variant()
+        y32 = lin(x, out_dtype=torch.float32)
+        ca = lin.column_alpha(0)[cols.to(dev)].float().cpu().reshape(1, -1)
+        ref32 = o.binary_linear(x.cpu(), lin.weight[cols.to(dev)].cpu().contiguous(), lin.mask[:, :, cols.to(dev)].cpu().contiguous(), ca,
+                                G=len(cols), out_dtype=torch.float32, round_mode=0)
+        got = y16[:, :, cols.to(dev)].cpu().contiguous()
+        d = ulp(got, ref32.bfloat16())
+        floor = 2.0 ** -22 * (K ** 0.5) * float(ref32.abs().max())
+        ok = (d <= 1) | ((got.float() - ref32.bfloat16().float()).abs() <= floor)
+        out[name] = {"kernel_variant": v, "scale_groups": lin.groups, "sampled_columns": len(cols), "max_ulp": int(d.max()),
+                     "all_within_gate": bool(ok.all()), "bit_equal": float((d == 0).float().mean()),
+                     "fp32_mode_rel_frobenius": float(((y32[:, :, cols.to(dev)].cpu().double() - ref32.double()).norm() / ref32.double().norm()))}
+        del lin, x, y16, y32
     return out
 
 
@@ -270,6 +335,37 @@ def delta_gemm_microbench(dev, Ms=(4096, 8192, 16384), N=4096, K=4096, iters=100
                      "bytes_per_launch": 2.0 * M * K + K * N / 8 + 2.0 * M * N, "launches": iters, "warmup_launches": warmup,
                      "kernel_variant": _lib.lib().bd_last_gemm_variant()})
         del x, p, out
+    return rows
+
+
+def vendor_gemm_microbench(dev, Ms=(4096, 8192, 16384), N=4096, K=4096, iters=100, warmup=100):
+    """Calibration of the 2.5 PF denominator: the vendor's dense bf16 GEMM (torch.matmul -> hipBLASLt) at the delta-GEMM's shapes,
+    [M, 4096] x [4096, 4096]^T, same process, same 100 + 100 launches, each launch between two HIP events on the launch stream.  It
+    does the same MFMA work as the delta-GEMM with a B operand 16x the bytes.  If it sits at or below the delta-GEMM rows, 2.5 PF
+    is not reachable by a dense bf16 GEMM at this board's power cap; if it reaches 0.70, that argument is void."""
+    rows = []
+    for M in Ms:
+        g = torch.Generator(device=dev).manual_seed(2)
+        x = torch.randn(M, K, device=dev, generator=g).bfloat16()
+        w = (torch.randn(N, K, device=dev, generator=g) * 0.02).bfloat16()
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        wt = w.t()
+        for _ in range(warmup):
+            torch.matmul(x, wt, out=out)
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for a, b in ev:
+            a.record()
+            torch.matmul(x, wt, out=out)
+            b.record()
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) for a, b in ev)
+        avg = sum(ts) / len(ts)
+        fl = 2.0 * M * N * K
+        rows.append({"shape": [M, N, K], "what": "torch.matmul(x[M,K] bf16, W[N,K]^T) -> hipBLASLt", "avg_ms": avg,
+                     "median_ms": ts[len(ts) // 2], "tflops": fl / avg * 1e-9, "tflops_median": fl / ts[len(ts) // 2] * 1e-9,
+                     "frac_of_peak": fl / avg * 1e-9 / PEAK_BF16_TFLOPS, "launches": iters, "warmup_launches": warmup})
+        del x, w, out
     return rows
 
 
@@ -344,6 +440,22 @@ def run_mt_decode(dev, timer, model_name, tenants, kv_len, steps, warmup, layers
                 run()
                 ab[name].append(bdd.timed_region(run, steps, device_sync=torch.cuda.synchronize) / steps * 1e3)
         dec.fuse_glue, dec.fuse_qkv_norm, dec.fuse_gateup_norm = keep
+        # non-temporal policy on the tile-major base-weight loads of the streaming kernel (bd_set_stream_tuning 16 = on, 32 = off),
+        # each captured as its own graph (the dispatch decision is taken at capture time)
+        from bitdelta_amd import _lib as _bl
+        L = _bl.lib()
+        nt_runs = {}
+        for name, flag in (("weight_nt_on_ms", 16), ("weight_nt_off_ms", 32)):
+            L.bd_set_stream_tuning(flag)
+            restore()
+            nt_runs[name] = dec._graph_runner(st)
+            ab[name] = []
+        L.bd_set_stream_tuning(0)
+        for _ in range(3):
+            for name, run in nt_runs.items():
+                restore()
+                run()
+                ab[name].append(bdd.timed_region(run, steps, device_sync=torch.cuda.synchronize) / steps * 1e3)
         # shipped defaults with the row-major base weight instead of its tile-major decode copy
         from bitdelta_amd.serving_loop import FusedDeltaLinear
         FusedDeltaLinear.use_tiled = False
@@ -444,6 +556,7 @@ def main():
                          "kernel": "bd::gemv_stream_kernel via bd_binary_linear (event-timed in the eager loop)",
                          "launches": d["delta_linear_launches"], "step_frac_of_hbm_peak": d["step_frac_of_hbm_peak"]},
             "mt_decode": d,
+            **bdd.runtime_info(),
         }
         print(json.dumps(out), flush=True)
         return
@@ -481,7 +594,8 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{args.model} base + one 1-bit delta, prefill seq {args.seq}, batch 1 per GPU "
-                               f"(BASELINE.json configs[1]); {n_layers} layers x 7 fused BinaryDiff projections",
+                               f"(BASELINE.json configs[1]); {n_layers} layers x 4 fused-Linear launches (q|k|v, o, gate|up, down = the 7 BinaryDiff "
+                               f"projections of a layer)",
                    "seq_len": args.seq, "global_batch": world, "parallelism": f"dp{world} independent replicas, no collective",
                    "glue": "RMSNorm: torch; RoPE (q|k in place), causal attention (bd_srv_prefill_attention), SwiGLU: HIP kernels of this library",
                    "valid": args.layers is None},
@@ -498,7 +612,9 @@ def main():
                                "bd::delta_gemm_fx_kernel<128x128>)",
                      "launches": n_launch, "kernel_ms_total": k_ms, "algorithmic_flops_total": k_flops,
                      "share_of_step_time": (k_ms / 1e3) / dt if dt > 0 else None},
+        **bdd.runtime_info(),
         "delta_gemm": mb,
+        "vendor_gemm": vendor_gemm_microbench(dev),
         "linear_params": lin_params,
     }
     if world == 1 and not args.no_mt_decode:
@@ -506,6 +622,15 @@ def main():
             out["mt_decode"] = run_mt_decode(dev, timer, "mistral-7b", args.tenants or 6, args.kv_len, 20, 3, layers=args.layers)
         except Exception as e:
             out["mt_decode"] = {"error": f"{type(e).__name__}: {e}"}
+    if world == 1 and not args.no_mt_decode:
+        # SURVEY.md 8(d) C2 "plus decode steps": the headline model itself, one sequence, one delta, greedy decode (hipGraph replay)
+        try:
+            d7 = run_mt_decode(dev, timer, "llama-2-7b", 1, args.kv_len, 20, 3, layers=args.layers)
+            out["decode_7b"] = {k: d7[k] for k in ("workload", "tenants", "steps", "valid", "eager_ms_per_step", "hipgraph_ms_per_step",
+                                                   "hipgraph_error", "tokens_per_s", "delta_linear_bytes_per_step", "lm_head_bytes_per_step",
+                                                   "linear_gbs", "linear_frac_of_hbm_peak", "step_gbs", "step_frac_of_hbm_peak")}
+        except Exception as e:
+            out["decode_7b"] = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
         try:

@@ -56,6 +56,8 @@ SIGNATURES = {
     "bd_set_decode_small_lut": (_ci, [_ci]),
     "bd_set_stream_tuning": (_ci, [_ci]),
     "bd_set_decode_generic_loop": (_ci, [_ci]),
+    "bd_set_decode_engine": (_ci, [_ci]),
+    "bd_set_ring_tuning": (_ci, [_ci]),
 }
 
 _lib = None

@@ -14,6 +14,7 @@
 #include "bd_gemm_w4.h"
 #include "bd_gemv.h"
 #include "bd_gemv_stream.h"
+#include "bd_gemv_ring.h"
 #include "bd_serving.h"
 #include "bd_attn_prefill.h"
 #include <algorithm>
@@ -34,6 +35,11 @@ static thread_local int g_gemv_two_launch = 1;       // 1 (default) = split-k pa
                                         // (measured slower: the last-arriver tail is serial inside every tile; bd_gemv.h)
 static thread_local int g_gemv_target_blocks = 512;
 static thread_local int g_stream_tune = 0;            // A/B hook (harness build): bit 0 = natural-order W, bit 1 = nt cache policy, bit 2 = 8-wave blocks, bit 3 = deeper prefetch
+static thread_local int g_decode_engine = -1;         // packed-layout decode launches: -1 = library default (DECODE_ENGINE_DEFAULT), 0 = streaming
+                                                      // register-load kernel (variant 600), 1 = LDS-DMA loader / consumer kernel (variant 700)
+static thread_local int g_ring_tune = -1;             // variant 700 knobs, -1 = defaults: bit 0 = nt weight / sign streams, bit 1 = activations ride the
+                                                      // ring even when a resident copy fits, bit 2 = ONE loader wave (default two), bits 8..13 = cap on
+                                                      // the ring slots (0 = none)
 static thread_local int t_last_variant = -1;
 
 extern "C" int bd_version(void) { return 1; }
@@ -46,6 +52,8 @@ extern "C" int bd_set_decode_wave_spec(int on) { g_gemv_wave_spec = on ? 1 : 0; 
 extern "C" int bd_set_launch_chunking(int on) { g_launch_chunking = on ? 1 : 0; return BD_OK; }
 extern "C" int bd_set_decode_generic_loop(int on) { g_col16_no_per4 = on ? 1 : 0; return BD_OK; }
 extern "C" int bd_set_stream_tuning(int flags) { g_stream_tune = flags; return BD_OK; }
+extern "C" int bd_set_decode_engine(int engine) { g_decode_engine = engine < 0 ? -1 : (engine ? 1 : 0); return BD_OK; }
+extern "C" int bd_set_ring_tuning(int flags) { g_ring_tune = flags; return BD_OK; }
 extern "C" int bd_set_decode_small_lut(int mode) { g_col16_small_lut = mode < 0 ? -1 : (mode ? 1 : 0); return BD_OK; }
 
 extern "C" const char* bd_error_string(int code) {
@@ -310,6 +318,9 @@ int launch_gemv_col16_chunk(const Problem& q) {
 
 // ---- streaming decode kernel (gemv_stream_kernel, variant 600): one 8-wave block per CU, contiguous column range per block
 constexpr int STREAM_MIN_N = 512;
+constexpr int STREAM_WT_NT_DEFAULT = 1;           // (-3.6 % on the 6-tenant Mistral decode step, same process: profiles/r04_decode_ab.txt)
+constexpr int STREAM_XRES_DEFAULT = 1;            // activation rows resident in LDS + deeper prefetch (XL = 2) where the rule below says so
+// (STREAM_WT_NT_DEFAULT: non-temporal policy on the tile-major weight loads of the streaming kernel)
 inline bool stream_ok(const Problem& q, int rows, int nmask) {
     if (rows > GEMV_MAX_R || nmask > 8 || q.N < STREAM_MIN_N) return false;
     // 32-bit buffer offsets with an out-of-range sentinel at 2 GiB: every extent must stay below it
@@ -345,15 +356,47 @@ int launch_stream_tuned(const StreamParams& sp, dim3 grid, hipStream_t st) {
         constexpr int A4 = NM == 6 ? 4 : 8, B4 = NM == 6 ? 6 : 12;         // 4-wave blocks
         switch (g_stream_tune & 15) {
 #define BD_T(code, NS, NW, WN, AX) case code: return launch_stream_inst<DT, NM, HASW, NS, NW, WN, AX>(sp, grid, st)
-            BD_T(0, A4, 4, 0, 0); BD_T(1, A4, 4, 1, 0); BD_T(2, A4, 4, 0, 2); BD_T(3, A4, 4, 1, 2);
-            BD_T(4, A8, 8, 0, 0); BD_T(5, A8, 8, 1, 0); BD_T(6, A8, 8, 0, 2); BD_T(7, A8, 8, 1, 2);
-            BD_T(8, B4, 4, 0, 0); BD_T(9, B4, 4, 1, 0); BD_T(10, B4, 4, 0, 2); BD_T(11, B4, 4, 1, 2);
-            BD_T(12, B8, 8, 0, 0); BD_T(13, B8, 8, 1, 0); BD_T(14, B8, 8, 0, 2); BD_T(15, B8, 8, 1, 2);
+            BD_T(0, A4, 4, 0, 0); BD_T(1, A4, 4, 1, 0); BD_T(2, A4, 4, 0, 6); BD_T(3, A4, 4, 1, 6);
+            BD_T(4, A8, 8, 0, 0); BD_T(5, A8, 8, 1, 0); BD_T(6, A8, 8, 0, 6); BD_T(7, A8, 8, 1, 6);
+            BD_T(8, B4, 4, 0, 0); BD_T(9, B4, 4, 1, 0); BD_T(10, B4, 4, 0, 6); BD_T(11, B4, 4, 1, 6);
+            BD_T(12, B8, 8, 0, 0); BD_T(13, B8, 8, 1, 0); BD_T(14, B8, 8, 0, 6); BD_T(15, B8, 8, 1, 6);
 #undef BD_T
         }
     }
 #endif
     return launch_stream_inst<DT, NM, HASW, NS4, 4, 0, 0>(sp, grid, st);
+}
+
+// ---- loader / consumer decode kernel (gemv_ring_kernel, variant 700): packed sign layout, fused Linear, K % 128 == 0
+constexpr int DECODE_ENGINE_DEFAULT = 0;          // what packed-layout decode launches run when nobody called bd_set_decode_engine
+constexpr int RING_TUNE_DEFAULT = 1;              // nt streams, resident activations when they fit, as many slots as fit
+inline bool ring_wanted() {
+    if (g_forced_variant == 700) return true;
+    if (g_forced_variant >= 0) return false;
+    return (g_decode_engine < 0 ? DECODE_ENGINE_DEFAULT : g_decode_engine) == 1;
+}
+// fills the LDS geometry of `rp`; false when the launch does not fit the kernel's envelope (the caller falls back to variant 600,
+// or answers BD_E_BAD_SHAPE when 700 was forced)
+inline bool ring_plan(const Problem& q, RingParams& rp) {
+    const int tune = g_ring_tune < 0 ? RING_TUNE_DEFAULT : g_ring_tune;
+    if (!q.W || q.mask_tiled != 2) return false;
+    rp.epi = q.epilogue == 1;
+    rp.nw = (const unsigned short*)q.norm_w; rp.sNw = q.sNw; rp.eps = q.eps;
+    return ring_plan_geometry(rp, q.B * q.M, q.K, q.t_pad, q.w_tiled != 0, q.ldw, q.norm_w != nullptr, tune);
+}
+template <int DT, int NM, int NT>
+int launch_ring_inst2(const RingParams& rp, unsigned grid, hipStream_t st) {
+    auto kern = gemv_ring_kernel<DT, NM, NT>;
+    static std::atomic<uint64_t> lds_done{0};
+    if (!ensure_dyn_lds((const void*)kern, RING_LDS_MAX, lds_done)) return BD_E_LAUNCH;
+    const unsigned lds = ring_lds_bytes(rp);
+    if (lds > (unsigned)RING_LDS_MAX) return BD_E_BAD_SHAPE;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (4 + rp.nl)), lds, st, rp);
+    return BD_OK;
+}
+template <int DT, int NM>
+int launch_ring_inst(const RingParams& rp, unsigned grid, hipStream_t st) {
+    return rp.nt ? launch_ring_inst2<DT, NM, 1>(rp, grid, st) : launch_ring_inst2<DT, NM, 0>(rp, grid, st);
 }
 
 template <int DT>
@@ -398,13 +441,59 @@ int launch_gemv_stream_chunk(const Problem& q) {
     int rc;
     if (q.mask_tiled == 2) {      // packed layout: all tenants of the call in one chunk, interleaved; extent from the pack's own geometry
         sp.p_bytes = (uint32_t)((int64_t)((q.N + 15) / 16) * ((q.K + 127) / 128) * 4 * 16 * q.t_pad * 4);
+        if (ring_wanted()) {      // loader / consumer kernel (variant 700); launches outside its envelope stay on the streaming kernel
+            RingParams rp{};
+            rp.g = gp; rp.cpb = cpb;
+            if (ring_plan(q, rp)) {
+                int rrc;
+                switch (q.t_pad) {
+                    case 1: rrc = launch_ring_inst<DT, 1>(rp, grid, q.st); break;
+                    case 2: rrc = launch_ring_inst<DT, 2>(rp, grid, q.st); break;
+                    case 4: rrc = launch_ring_inst<DT, 4>(rp, grid, q.st); break;
+                    case 6: rrc = launch_ring_inst<DT, 6>(rp, grid, q.st); break;
+                    default: rrc = launch_ring_inst<DT, 8>(rp, grid, q.st); break;
+                }
+                if (rrc != BD_OK) return rrc;
+                t_last_variant = 700;
+                return launch_status();
+            }
+            if (g_forced_variant == 700) return BD_E_BAD_SHAPE;
+        }
         // kernel kinds: plain | RMSNorm prologue (XL) | XL + SwiGLU epilogue | SwiGLU epilogue only; tile-major W (WT) for the three
         // the serving loop uses (a norm prologue without SwiGLU on tile-major W answers BD_E_BAD_SHAPE)
+        // tile-major W: optional nt policy on the weight loads (STREAM_WT_NT_DEFAULT, or bd_set_stream_tuning bit 4 = on / bit 5 = off)
+        const bool wnt = (g_stream_tune & 16) ? true : (g_stream_tune & 32) ? false : (STREAM_WT_NT_DEFAULT != 0);
+        // ... and optionally the activation rows resident in LDS with a deeper weight prefetch (XL = 2; bd_set_stream_tuning bit 6 = on,
+        // bit 7 = off): plain and SwiGLU launches inside the fused-norm envelope (M = 1, K = 2048 * 2^s, R * K <= 32768)
+        const bool xres_ok = q.w_tiled && !q.norm_w && q.M == 1 && q.K >= 2048 && !(q.K & (q.K - 1)) && (int64_t)q.B * q.K <= 16 * 2048 &&
+                             (int64_t)STREAM_XS_OFF + (int64_t)q.B * (2 * (int64_t)q.K + 16) <= STREAM_LDS_MAX;
+        // Default rule from the same-process A/B (profiles/r04_decode_ring_ab.txt): the copy costs ~3 us in front of the launch, so it pays
+        // where the per-stage activation loads are a large share of the load instructions (one or two rows: -7..-10 % on every K = 4096
+        // launch of the single-delta Llama-2-7B decode) or the launch is long (6 tenants: gate|up -3.5 %, but o +25 %, q|k|v +4 %)
+        const bool xres_auto = STREAM_XRES_DEFAULT != 0 && (q.B * q.M <= 2 || (int64_t)q.N * q.K >= (64ll << 20));
+        const bool xres = xres_ok && ((g_stream_tune & 64) ? true : (g_stream_tune & 128) ? false : xres_auto);
+        if (xres) {
+#define BD_XR(NM, NS8) rc = q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS8, 4, 1, 2, 1, 2, 1, 1>(sp, dim3(grid), q.st)   \
+                                            : launch_stream_inst<DT, NM, true, NS8, 4, 1, 2, 1, 2, 0, 1>(sp, dim3(grid), q.st)
+            switch (q.t_pad) {
+                // prefetch depth: the 16 activation-row loads of the prologue + NS stages of (4 W + sign) loads stay under the 63-entry vmcnt
+                case 1: BD_XR(1, 8); break;
+                case 2: BD_XR(2, 8); break;
+                case 4: BD_XR(4, 8); break;
+                case 6: BD_XR(6, 6); break;
+                case 8: BD_XR(8, 6); break;
+                default: return BD_E_BAD_SHAPE;
+            }
+#undef BD_XR
+            if (rc != BD_OK) return rc;
+            return launch_status();
+        }
+#define BD_PKW(NM, NS4, AX) (q.norm_w ? (q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS4, 4, 1, AX, 1, 1, 1, 1>(sp, dim3(grid), q.st)   \
+                                                         : BD_E_BAD_SHAPE)                                                                \
+                                      : q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS4, 4, 1, AX, 1, 0, 1, 1>(sp, dim3(grid), q.st)   \
+                                                        : launch_stream_inst<DT, NM, true, NS4, 4, 1, AX, 1, 0, 0, 1>(sp, dim3(grid), q.st))
 #define BD_PK(NM, NS4) rc = q.w_tiled                                                                                                   \
-                     ? (q.norm_w ? (q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1, 1, 1, 1>(sp, dim3(grid), q.st)    \
-                                                    : BD_E_BAD_SHAPE)                                                                 \
-                                 : q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1, 0, 1, 1>(sp, dim3(grid), q.st)    \
-                                                   : launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1, 0, 0, 1>(sp, dim3(grid), q.st))   \
+                     ? (wnt ? BD_PKW(NM, NS4, 2) : BD_PKW(NM, NS4, 0))                                                                  \
                      : q.norm_w ? (q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1, 1, 1>(sp, dim3(grid), q.st)   \
                                                         : launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1, 1, 0>(sp, dim3(grid), q.st))  \
                      : q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1, 0, 1>(sp, dim3(grid), q.st)            \
@@ -419,6 +508,7 @@ int launch_gemv_stream_chunk(const Problem& q) {
             default: return BD_E_BAD_SHAPE;
         }
 #undef BD_PK
+#undef BD_PKW
         if (rc != BD_OK) return rc;
         return launch_status();
     }
@@ -698,6 +788,10 @@ int dispatch3(const Problem& q) {
     if (v > 400 && v <= 464) v = 400;        // 400 (+ KS): force the MFMA + LUT decode kernel
     if (v > 500 && v <= 564) v = 500;        // 500 (+ KS): force the no-split-k 16-column decode kernel
     if (v > 600 && v <= 664) v = 600;        // 600 (+ columns per block / 4): force the streaming decode kernel
+    if (v == 700) {                           // 700: the loader / consumer decode kernel (packed sign layout, fused Linear only); the
+        if (q.mask_tiled != 2 || !q.W) return BD_E_BAD_SHAPE;     // stream path picks it up (launch_gemv_stream_chunk, ring_wanted)
+        v = 600;
+    }
     if (q.epilogue == 1 && q.M > GEMV_MAX_M) {        // prefill-size SwiGLU launch (bd_binary_linear_swiglu): one kernel can do it
         if (v >= 0 && v != 15) return BD_E_BAD_SHAPE;
         v = 15;
@@ -945,7 +1039,8 @@ static int binary_linear_impl(const void* X, const void* W, const int32_t* P, co
     q.ws = ws; q.ws_bytes = ws_bytes; q.st = (hipStream_t)stream;
     // tile-major masks exist for the streaming decode kernel only (serving-side repack; the reference layout works everywhere)
     if (q.mask_tiled) {
-        const bool forced_other = g_forced_variant >= 0 && g_forced_variant != 200 && !(g_forced_variant >= 600 && g_forced_variant <= 664);
+        const bool forced_other = g_forced_variant >= 0 && g_forced_variant != 200 && g_forced_variant != 700 &&
+                                  !(g_forced_variant >= 600 && g_forced_variant <= 664);
         if (M < 1 || M > GEMV_MAX_M || forced_other || !gemv_ok(q)) return BD_E_BAD_SHAPE;
         const int cb = GEMV_MAX_R / M, bc = B < cb ? B : cb;
         if (!stream_ok(q, bc * M, sPb == 0 ? 1 : bc)) return BD_E_BAD_SHAPE;

@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int h = hb % p.H, b = hb / p.H;
     const int kvh = h / (p.H / p.KVH);
     const int Q0 = qb * QB, qw0 = Q0 + wave * QW;
-    const int ks = p.kv_start ? p.kv_start[b] : 0;
+    const int ks = p.kv_start ? min(max(p.kv_start[b], 0), p.S) : 0;      // device data the host cannot validate: clamp into [0, S]
     const unsigned short* qp = p.q + (long long)b * p.sqb + (long long)h * HD;
     const unsigned short* kp = p.k + (long long)b * p.skb + (long long)kvh * HD;
     const unsigned short* vp = p.v + (long long)b * p.svb + (long long)kvh * HD;

@@ -93,9 +93,12 @@ struct StreamParams {
 //   exactly one instruction); the sign operand keeps the word-row order (a lane's word is 32 consecutive k), which needs its own
 //   activation fragments: x is loaded in both orders (L2 hits).  WNAT = 0: one activation fragment set, W in the word-row order
 //   (each W instruction touches 64 sectors and uses 16 bytes of each; the 4 instructions of a stage complete them).
-// AUX = cache policy of the weight / sign streams (0 = default, 2 = nt).  Measured (profiles/r02_decode_stream_ab.txt): with the
-//   word-row order nt costs 35 % of the pure weight stream (3.4 vs 5.2 TB/s at 235 MB): the 4 load instructions of a stage each
-//   use 16 bytes of the same 64-byte sectors, and a non-temporal line does not stay in L1 for the next one.
+// AUX = cache policy of the streams: bit 1 (value 2) = nt on the base-weight loads, bit 2 (value 4) = nt on the sign loads.  Measured
+//   (profiles/r02_decode_stream_ab.txt): with the word-row order nt costs 35 % of the pure weight stream (3.4 vs 5.2 TB/s at 235 MB): the
+//   4 load instructions of a stage each use 16 bytes of the same 64-byte sectors, and a non-temporal line does not stay in L1 for the
+//   next one.  With the TILE-MAJOR weight (WT) every load instruction reads its own contiguous 1-KiB run, and the pure-stream probe
+//   (profiles/r04_stream_probe.txt) has nt register loads at 6.56 TB/s against 5.66 default; the packed sign dwords of a lane still
+//   span two load instructions, so the sign stream keeps the default policy.
 // PK = 1: PACKED sign layout, everything in the natural k order with ONE activation fragment set.  The serving side repacks a tenant
 //   set's masks once (binary_gemm_kernel.pack_decode_masks) into  P[tile n/16][iteration k/128][lane group g][column n%16][tenant t]
 //   dwords whose byte s holds the 8 signs of k = 128 it + 32 s + 8 g .. + 7 (a 4 x 4 byte transpose of the 4 word rows of an
@@ -109,6 +112,10 @@ struct StreamParams {
 //   model -- while its first weight stages are in flight), keeps the result in LDS and reads its activation fragments from there.
 //   Same arithmetic, same order as rmsnorm_tenant_kernel (bd_serving.h: shared helpers), so the result is bit-identical to
 //   "rmsnorm launch, then Linear launch"; what disappears is a 4 us launch + gap in front of two of the four Linears of a layer.
+// XL = 2 (packed layout, 4-wave blocks): the same resident-activation machinery WITHOUT the norm -- the R activation rows are copied
+//   into LDS once (R * K * 2 bytes from L2, behind the first weight stages) and every stage reads its fragments from there.  A stage
+//   is then 4 W loads + the sign loads: no per-stage activation loads (4 of the 10 load instructions of a 6-tenant stage, a quarter of
+//   the bytes through the texture path), which is what lets NS = 8 stages fit the 6-bit vmcnt counter: twice the weight bytes in flight.
 // EPI = 1 (packed layout): SwiGLU epilogue for a fused gate|up projection whose output rows are interleaved in blocks of 8
 //   ([g0..7 | u0..7 | g8..15 | ...]): a 16-column tile holds 8 gate and the 8 matching up columns, the reducing wave rounds both to
 //   16 bits (what the separate Linear would have stored), and stores round16(silu(g)) * u -- N/2 output columns.  Scale group of
@@ -122,6 +129,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
     static_assert(!PK || (WNAT == 1 && NM > 0), "packed layout = natural order, with a sign operand");
     static_assert(!(XL || EPI) || (PK && NW == 4), "fused prologue / epilogue: packed layout, 256-thread blocks");
     static_assert(!XL || NS % 2 == 0, "stage parity selects the activation fragment set");
+    constexpr int AUXW = AUX & 2, AUXP = (AUX & 4) ? 2 : 0;
     GemvParams p = sp.g;
     if constexpr (NM == 0) {       // blockIdx.y = tenant: its own activation rows, weight matrix and output rows
         p.X += (long long)blockIdx.y * sp.sXt;
@@ -172,7 +180,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
     // XL: the R raw rows (and their norm weights) are the OLDEST loads of the wave -- like the scales above, consuming them never
     // waits for a weight stage.  Thread t owns the 16-byte chunks c = 8 t + 2048 i of every row: rmsnorm_tenant_kernel's mapping.
     constexpr int XCH = 16;                                              // chunks per thread: R * K <= 16 * 2048 (host-checked)
-    [[maybe_unused]] u32x4_t xraw[XL ? XCH : 1], graw[XL ? XCH : 1];
+    [[maybe_unused]] u32x4_t xraw[XL ? XCH : 1], graw[XL == 1 ? XCH : 1];
     [[maybe_unused]] const int jsh = sp.jsh;                             // log2(chunks per row per thread): K = 2048 << jsh (host-checked)
     if constexpr (XL) {
         const __amdgpu_buffer_rsrc_t rn = make_rsrc(sp.nw, sp.n_bytes);
@@ -181,7 +189,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
             const int r = j >> jsh, c = ((int)threadIdx.x + 256 * (j - (r << jsh))) * 8;      // M == 1 (host-checked): row = tenant
             const bool ok = r < p.R;
             xraw[j] = buf_load16<0>(rx, ok ? (uint32_t)(((long long)r * p.sXb + c) * 2) : STREAM_OOB);
-            graw[j] = buf_load16<0>(rn, ok ? (uint32_t)(((long long)r * sp.sNw + c) * 2) : STREAM_OOB);
+            if constexpr (XL == 1) graw[j] = buf_load16<0>(rn, ok ? (uint32_t)(((long long)r * sp.sNw + c) * 2) : STREAM_OOB);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -208,17 +216,17 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
                 const bool ok = it_ok && (k0 + 32 * s < p.K);
                 if constexpr (!XL) st.xn[s] = buf_load16<0>(rx, ok ? x_off + (uint32_t)(k0 + 32 * s) * 2u : STREAM_OOB);
                 if constexpr (HASW && WT)
-                    st.wf[s] = buf_load16<AUX>(rw, (it_ok && it < nit && col_ok)
+                    st.wf[s] = buf_load16<AUXW>(rw, (it_ok && it < nit && col_ok)
                                                        ? ((uint32_t)(n >> 4) * (uint32_t)nit + (uint32_t)it) * 4096u + (uint32_t)s * 1024u +
                                                              (uint32_t)(n & 15) * 64u + (uint32_t)g * 16u
                                                        : STREAM_OOB);
                 else if constexpr (HASW)
-                    st.wf[s] = buf_load16<AUX>(rw, (ok && col_ok) ? (uint32_t)n * (uint32_t)p.ldw * 2u + (uint32_t)(k0 + 32 * s) * 2u : STREAM_OOB);
+                    st.wf[s] = buf_load16<AUXW>(rw, (ok && col_ok) ? (uint32_t)n * (uint32_t)p.ldw * 2u + (uint32_t)(k0 + 32 * s) * 2u : STREAM_OOB);
             }
         } else if constexpr (HASW) {
             const uint32_t wo = (krow_ok && col_ok) ? (uint32_t)n * (uint32_t)p.ldw * 2u + (uint32_t)irow * 64u : STREAM_OOB;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) st.wf[s] = buf_load16<AUX>(rw, wo + 16u * s);
+            for (int s = 0; s < 4; ++s) st.wf[s] = buf_load16<AUXW>(rw, wo + 16u * s);
         }
         if constexpr (PK) {
             // dword index ((tile_g * nit + it) * 4 + g) * 16 + (n & 15), tp dwords each; iterations past K are zero padding in the pack
@@ -226,19 +234,19 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
             const uint32_t po = ok ? ((((uint32_t)(n >> 4) * (uint32_t)nit + (uint32_t)it) * 4u + (uint32_t)g) * 16u + (uint32_t)(n & 15)) * sp.tp * 4u
                                    : STREAM_OOB;
             if constexpr (NM == 1) {
-                st.wd[0] = buf_load4<AUX>(rp, po);
+                st.wd[0] = buf_load4<AUXP>(rp, po);
             } else if constexpr (NM == 2) {
-                const u32x2_t v = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rp, (int)po, 0, AUX));
+                const u32x2_t v = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rp, (int)po, 0, AUXP));
                 st.wd[0] = v[0]; st.wd[1] = v[1];
             } else {
-                const u32x4_t v = buf_load16<AUX>(rp, po);
+                const u32x4_t v = buf_load16<AUXP>(rp, po);
 #pragma unroll
                 for (int t = 0; t < 4 && t < NM; ++t) st.wd[t] = v[t];
                 if constexpr (NM == 6) {
-                    const u32x2_t v2 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rp, (int)(po == STREAM_OOB ? STREAM_OOB : po + 16u), 0, AUX));
+                    const u32x2_t v2 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rp, (int)(po == STREAM_OOB ? STREAM_OOB : po + 16u), 0, AUXP));
                     st.wd[4] = v2[0]; st.wd[5] = v2[1];
                 } else if constexpr (NM == 8) {
-                    const u32x4_t v2 = buf_load16<AUX>(rp, po == STREAM_OOB ? STREAM_OOB : po + 16u);
+                    const u32x4_t v2 = buf_load16<AUXP>(rp, po == STREAM_OOB ? STREAM_OOB : po + 16u);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) st.wd[4 + t] = v2[t];
                 }
@@ -249,7 +257,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
 #pragma unroll
             for (int t = 0; t < NM; ++t) {
                 const uint32_t tb = (uint32_t)(min(t, nmask - 1)) * (uint32_t)p.sPb * 4u;
-                st.wd[t] = buf_load4<AUX>(rp, po == STREAM_OOB ? STREAM_OOB : po + tb);
+                st.wd[t] = buf_load4<AUXP>(rp, po == STREAM_OOB ? STREAM_OOB : po + tb);
             }
         }
         // the stages must enter the load queue in stream order: without this fence hipcc clusters the loads of ALL prologue stages
@@ -278,7 +286,14 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
             *(u32x4_t*)(dyn_lds + slot * 16) = w;
         }
     }
-    if constexpr (XL) {
+    if constexpr (XL == 2) {                      // raw rows -> LDS (same thread mapping as the norm form)
+#pragma unroll
+        for (int j = 0; j < XCH; ++j) {
+            const int r = j >> jsh, c = ((int)threadIdx.x + 256 * (j - (r << jsh))) * 8;
+            if (r < p.R) *(u32x4_t*)(dyn_lds + sp.xs_off + (uint32_t)r * sp.xrow + (uint32_t)c * 2u) = xraw[j];
+        }
+    }
+    if constexpr (XL == 1) {
         float* const part = red;                  // [row][wave] partial sums (the reduction buffers are idle until the first tile ends)
         float ss = 0.f;
 #pragma unroll

@@ -89,6 +89,35 @@ class _DeltaLinearFn(torch.autograd.Function):
         return gx, None, None, None, None, gc_
 
 
+class _RefLinearFn(torch.autograd.Function):
+    """The reference-faithful training forward (BinaryDiff.delta_input_grad = False, the default) as ONE launch.
+
+    The reference computes `x @ base + coeff * binary_bmm(x, mask)` (bitdelta/diff.py:33-39): a BLAS GEMM, a Triton launch with no
+    autograd.Function, and two elementwise passes.  Its gradients are therefore d/dx = g . W only (the delta path contributes nothing:
+    the kernel output carries no grad_fn) and d/dcoeff = sum(g * c) with c the kernel's 16-bit output.  This function keeps exactly
+    those gradients -- the quirk that train.py's scale distillation (bitdelta/train.py:60-88) was run with -- and replaces the four
+    forward launches by the fused HIP kernel (fp32 accumulate, fp32 alpha, one rounding).
+    backward: dx = g @ W            the op autograd runs for `x @ base`
+              dcoeff = sum(g * c)   c = the delta GEMM with the reference's fp32 -> fp16 -> dtype epilogue, product and sum in the
+                                    activation dtype like autograd's mul / sum_to_size, then cast to coeff's fp32"""
+
+    @staticmethod
+    def forward(ctx, x3, weight_nk, mask, coeff):
+        ctx.save_for_backward(x3, weight_nk, mask, coeff)
+        return binary_linear(x3, weight_nk, mask.unsqueeze(0), coeff.detach().reshape(1, 1))
+
+    @staticmethod
+    def backward(ctx, g):
+        x3, weight_nk, mask, coeff = ctx.saved_tensors
+        gx = gc_ = None
+        if ctx.needs_input_grad[0]:
+            gx = g @ weight_nk
+        if ctx.needs_input_grad[3]:
+            c = delta_bmm(x3, mask.unsqueeze(0), round_mode=1)
+            gc_ = (g * c).sum().to(coeff.dtype).reshape(coeff.shape)
+        return gx, None, None, gc_
+
+
 # ------------------------------------------------------------------------------------------------ the module
 class BinaryDiff(nn.Module):
     """16-bit base weight + 1-bit delta Linear (reference bitdelta/diff.py:8-39); same buffers, parameter and state_dict order."""
@@ -97,6 +126,9 @@ class BinaryDiff(nn.Module):
     # (False) reproduces the reference exactly, including its quirk that d/dx of the delta path is dropped (its Triton launch has
     # no autograd.Function, bitdelta/diff.py:39), which is what train.py's scale distillation was run with.
     delta_input_grad = False
+    # True: run the training forward as the reference's four separate launches (BLAS GEMM + delta GEMM + two elementwise passes)
+    # instead of the one fused launch with the same gradients (_RefLinearFn).  A/B and parity hook.
+    reference_composition = False
 
     def __init__(self, base, finetune):
         super().__init__()
@@ -106,6 +138,7 @@ class BinaryDiff(nn.Module):
         self.register_parameter("coeff", nn.Parameter(mean_abs.detach().clone().to(torch.float32).requires_grad_(True)))
         self._mask_t = None          # lazily packed S^T for the opt-in backward (not a buffer: the state_dict stays the reference's)
         self._weight_kn = None       # ... and the base weight stored [in, out] (the backward launch's "W")
+        self._mask_t_key = self._weight_kn_key = None
 
     def _weight_nk(self):
         w = self.base.T                      # [out, in]; contiguous while `base` is still the .T view it was built as
@@ -115,13 +148,21 @@ class BinaryDiff(nn.Module):
         """base weight as a contiguous [in, out] matrix: what the fused kernel needs as its row-major `W` when it computes
         dx = g . W + coeff * (g . S^T).  `self.base` IS that matrix logically ([in, out] view of the [out, in] storage); this is its
         contiguous copy, made once (training only, opt-in: +2 bytes per parameter)."""
-        if self._weight_kn is None or self._weight_kn.device != self.base.device:
-            self._weight_kn = self.base.contiguous()
+        key = self._src_key(self.base)
+        if self._weight_kn is None or self._weight_kn_key != key:
+            self._weight_kn, self._weight_kn_key = self.base.contiguous(), key
         return self._weight_kn
 
+    @staticmethod
+    def _src_key(t):
+        """identity AND content version of a buffer: a load_state_dict, an in-place update, a dtype cast or a device move all change it,
+        so the derived copies below are rebuilt instead of silently feeding the backward a stale W^T / S^T"""
+        return (t.data_ptr(), t._version, t.dtype, t.device, tuple(t.shape), tuple(t.stride()))
+
     def _transposed_mask(self):
-        if self._mask_t is None or self._mask_t.device != self.mask.device:
-            self._mask_t = transpose_mask(self.mask)
+        key = self._src_key(self.mask)
+        if self._mask_t is None or self._mask_t_key != key:
+            self._mask_t, self._mask_t_key = transpose_mask(self.mask), key
         return self._mask_t
 
     def forward(self, x, *, residual=None):
@@ -142,11 +183,14 @@ class BinaryDiff(nn.Module):
             y = binary_linear(x3, self._weight_nk(), self.mask.unsqueeze(0), self.coeff.reshape(1, 1))
         elif self.delta_input_grad:
             y = _DeltaLinearFn.apply(x3, self._weight_nk(), self.mask, self._transposed_mask(), self._transposed_weight(), self.coeff)
-        else:
-            # training form, reference composition (diff.py:39): d/dcoeff flows through `coeff * c`, d/dx only through
-            # `x @ base` -- the kernel output carries no grad_fn, exactly like the reference's Triton launch.
+        elif self.reference_composition:
+            # the reference's own four launches (diff.py:39), kept as the A/B / parity reference of the fused training forward:
+            # d/dcoeff flows through `coeff * c`, d/dx only through `x @ base` -- the kernel output carries no grad_fn
             c = delta_bmm(x3.detach(), self.mask.unsqueeze(0), round_mode=1)
             y = x3 @ self.base + self.coeff * c
+        else:
+            # training form, reference gradients (d/dx through the base GEMM only, d/dcoeff = sum(g * c)), ONE forward launch
+            y = _RefLinearFn.apply(x3, self._weight_nk(), self.mask, self.coeff)
         return y.reshape(*shape[:-1], y.shape[-1])
 
 

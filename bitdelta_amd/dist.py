@@ -31,6 +31,13 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def runtime_info():
+    """What actually got initialised -- goes into every bench line, so a multi-GPU run says which transport it measured."""
+    if dist.is_available() and dist.is_initialized():
+        return {"n_ranks_seen": dist.get_world_size(), "backend": dist.get_backend()}
+    return {"n_ranks_seen": 1, "backend": "none (single process)"}
+
+
 def tenants_for_rank(n_tenants, rank, world):
     """Contiguous, balanced partition of tenant ids over ranks (earlier ranks take the remainder)."""
     q, r = divmod(n_tenants, world)

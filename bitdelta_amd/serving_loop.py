@@ -177,6 +177,9 @@ class TenantDecoder(nn.Module):
     """Llama / Mistral decoder for T tenants over one base: every `*proj*` Linear is base + T 1-bit deltas (fused HIP launches),
     embedding / norms / lm_head are per tenant (stacked)."""
 
+    MIN_STOP_WIDTH = 8          # stop ids per tenant the static stop table holds before it has to grow (to the next power of two)
+    MAX_STATIC_SLOTS = 4        # captured decode-step graphs kept alive at once (LRU over stop-table width x glue switches)
+
     def __init__(self, cfg, tenants, device, dtype, max_len=MAX_PROMPT + 64, eps=1e-5):
         super().__init__()
         self.cfg, self.T, self.dtype, self.dev, self.eps = cfg, tenants, dtype, torch.device(device), eps
@@ -199,7 +202,8 @@ class TenantDecoder(nn.Module):
         # tile-major weights): separate launches 5.35 | SwiGLU in gate|up's epilogue 5.11 | + RMSNorm in gate|up's prologue 5.17 |
         # + RMSNorm in q|k|v's prologue 5.28.  The epilogue is free; a norm prologue makes 256 blocks each re-read and re-normalise
         # all rows (~6 us in front of the launch) to save a 4.4 us kernel -- at best a wash on the long launch, a loss on the short one.
-        self._static = {}               # (max_new_tokens, stop width) -> static request state + captured decode-step graph
+        self._static = {}               # (stop-table width, glue switches) -> static request state + captured decode-step graph (LRU)
+        self._kv_cache = None           # ONE KV cache per decoder, shared by every slot
         self._capture_stream = None
         self.fuse_qkv_norm = False      # RMSNorm folded into the q|k|v launch
         self.fuse_gateup_norm = False   # RMSNorm folded into the gate|up launch (SwiGLU stays in its epilogue either way)
@@ -401,18 +405,29 @@ class TenantDecoder(nn.Module):
         T, L = ids.shape
         assert L + max_new_tokens <= self.max_len
         nstop = max((len(s) for s in stop_token_ids), default=0) if stop_token_ids else 0
-        # Static request state, reused by every generate() call of the same shape: the KV cache, the feedback buffers and -- with them --
-        # the captured hipGraph of the decode step (capturing per call re-allocated scratch for a fresh side stream every time and
-        # replayed a full-buffer memset node: ADVICE r02).  Stale keys of an earlier request are masked by cache["valid"].
-        key = (max_new_tokens, max(nstop, 1), self.fast_glue, self.fuse_glue, self.fuse_qkv_norm, self.fuse_gateup_norm, FusedDeltaLinear.use_tiled)
-        slot = self._static.get(key)
+        # Static request state, reused by every generate() call: ONE KV cache per decoder (it does not depend on the request), feedback
+        # buffers sized to fixed maxima (`out` holds max_len tokens, the stop table MIN_STOP_WIDTH ids or the next power of two), so
+        # the captured hipGraph of the decode step is keyed by the stop-table width and the glue switches only -- not by caller-chosen
+        # max_new_tokens (every new key used to allocate a full KV cache + a graph and nothing was ever evicted).  The
+        # few slots that can exist are kept in a small LRU; an evicted slot's graph and buffers are released.
+        # Stale keys of an earlier request are masked by cache["valid"].
+        width = max(self.MIN_STOP_WIDTH, 1 << max(nstop - 1, 0).bit_length())
+        key = (width, self.fast_glue, self.fuse_glue, self.fuse_qkv_norm, self.fuse_gateup_norm, FusedDeltaLinear.use_tiled)
+        if self._kv_cache is None:
+            self._kv_cache = self.new_cache()
+        slot = self._static.pop(key, None)
         if slot is None:
-            slot = self._static[key] = {"st": {
-                "cache": self.new_cache(), "tok": torch.zeros(T, 1, dtype=torch.long, device=self.dev),
+            slot = {"st": {
+                "cache": self._kv_cache, "tok": torch.zeros(T, 1, dtype=torch.long, device=self.dev),
                 "pos": torch.zeros(1, dtype=torch.long, device=self.dev), "step": torch.zeros(1, dtype=torch.long, device=self.dev),
-                "stop_ids": torch.full((T, max(nstop, 1)), -1, dtype=torch.long, device=self.dev),
-                "out": torch.zeros(T, max_new_tokens + 1, dtype=torch.long, device=self.dev),
+                "stop_ids": torch.full((T, width), -1, dtype=torch.long, device=self.dev),
+                "out": torch.zeros(T, self.max_len + 1, dtype=torch.long, device=self.dev),
                 "stopped": torch.zeros(T, dtype=torch.bool, device=self.dev)}, "graph": None}
+        self._static[key] = slot                              # (re-)inserted last: dict order is the LRU order
+        while len(self._static) > self.MAX_STATIC_SLOTS:
+            old = self._static.pop(next(iter(self._static)))
+            old["graph"] = None                               # drops the captured graph (and with it the references to the buffers)
+            old["st"].clear()
         st = slot["st"]
         cache = st["cache"]
         logits = self.prefill(ids, am, cache)

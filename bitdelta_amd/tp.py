@@ -115,43 +115,98 @@ class PartialSumReducer:
     def __init__(self, group=None, world=None):
         self.group = group
         self.world = world           # TP degree of the owner (None: the group's size); 1 = nothing to reduce
-        self._bufs = {}              # (shape, dtype) -> symmetric buffer
-        self._symm = None            # None = not probed yet, False = unavailable
+        self._bufs = {}              # (shape, dtype) -> symmetric buffer, or None = this message shape stays on the ring
+        self._symm = None            # None = not probed yet, False = unavailable (on ANY rank: the decision is collective)
+        self.calls = {"one_shot": 0, "ring": 0}      # which transport each call took (bench lines report it)
+        self.why_ring = None         # first reason the one-shot path was ruled out, for the bench line
+
+    # Every decision below is made by ALL ranks together: a rank whose local setup failed and went to the ring while its peers sat in
+    # the symmetric-memory rendezvous would hang the job.  A local attempt is followed by an all-reduce(MIN) of an "ok" flag over the
+    # ring, and the one-shot path is used only if every rank said yes.
+    def _all_agree(self, ok, device):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(flag.item())
+
+    def _local_enable(self):
+        """this rank's attempt to switch symmetric memory on for the group; raises when the build / topology cannot"""
+        import torch.distributed._symmetric_memory as sm
+        g = self.group or dist.group.WORLD
+        sm.enable_symm_mem_for_group(g.group_name)
+        self._sm, self._gname = sm, g.group_name
+
+    def _local_alloc(self, y):
+        return self._sm.empty(y.shape, dtype=y.dtype, device=y.device)
+
+    def _rendezvous(self, buf):
+        self._sm.rendezvous(buf, self._gname)
+
+    def _one_shot(self, buf):
+        return torch.ops.symm_mem.one_shot_all_reduce(buf, "sum", self._gname)
+
+    def _capable(self, device):
+        """job-wide facts (same answer on every rank): RCCL process group and device memory"""
+        return dist.get_backend(self.group) == "nccl" and device.type == "cuda"
 
     def _symm_ok(self, device):
         if self._symm is None:
-            self._symm = False
+            if not self._capable(device):
+                self._symm = False                   # same answer on every rank (backend and device type are job-wide): no vote needed
+                self.why_ring = f"backend {dist.get_backend(self.group)} / device {device.type}: no peer-mapped memory"
+                return False
+            ok, err = True, None
             try:
-                if dist.is_initialized() and dist.get_backend(self.group) == "nccl" and device.type == "cuda":
-                    import torch.distributed._symmetric_memory as sm
-                    g = self.group or dist.group.WORLD
-                    sm.enable_symm_mem_for_group(g.group_name)
-                    self._sm, self._gname, self._symm = sm, g.group_name, True
-            except Exception:        # no peer access / unsupported build: the ring is always correct
-                self._symm = False
+                self._local_enable()
+            except Exception as e:                   # no peer access / unsupported build
+                ok, err = False, f"{type(e).__name__}: {e}"
+            self._symm = self._all_agree(ok, device)
+            if not self._symm:
+                self.why_ring = err or "symmetric-memory setup failed on another rank"
         return self._symm
+
+    def _buffer_for(self, y):
+        key = (tuple(y.shape), y.dtype)
+        if key in self._bufs:
+            return self._bufs[key]
+        buf, ok, err = None, True, None
+        try:
+            buf = self._local_alloc(y)               # local; the collective rendezvous comes only after everybody has a buffer
+        except Exception as e:
+            ok, err = False, f"{type(e).__name__}: {e}"
+        if self._all_agree(ok, y.device):
+            try:
+                self._rendezvous(buf)
+            except Exception as e:
+                ok, err = False, f"{type(e).__name__}: {e}"
+            ok = self._all_agree(ok, y.device)
+        else:
+            ok = False
+        if not ok:
+            buf = None
+            self.why_ring = self.why_ring or err or "symmetric buffer setup failed on another rank"
+        self._bufs[key] = buf
+        return buf
 
     def __call__(self, y):
         """y: fp32 (or 16-bit) partial sums, identical shape on every rank; returns the sum (may alias y)"""
         if self.world == 1 or not dist.is_initialized() or dist.get_world_size(self.group) == 1:
             return y
         if y.numel() * y.element_size() <= self.ONE_SHOT_MAX_BYTES and self._symm_ok(y.device):
-            key = (tuple(y.shape), y.dtype)
-            buf = self._bufs.get(key)
-            if buf is None:
-                try:                 # setup (peer mapping) is where an unsupported topology shows; every rank fails alike
-                    buf = self._sm.empty(y.shape, dtype=y.dtype, device=y.device)
-                    self._sm.rendezvous(buf, self._gname)
-                except Exception:
-                    self._symm = False
-                    buf = None
-                else:
-                    self._bufs[key] = buf
+            buf = self._buffer_for(y)
             if buf is not None:
                 buf.copy_(y)
-                return torch.ops.symm_mem.one_shot_all_reduce(buf, "sum", self._gname)
+                self.calls["one_shot"] += 1
+                return self._one_shot(buf)
         dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
+        self.calls["ring"] += 1
         return y
+
+    def report(self):
+        """what the bench line says about the exchange: the transport of each message class and, if the ring carried the small messages,
+        why"""
+        return {"one_shot_calls": self.calls["one_shot"], "ring_calls": self.calls["ring"],
+                "one_shot_available": bool(self._symm), "one_shot_max_bytes": self.ONE_SHOT_MAX_BYTES,
+                "ring_reason": self.why_ring}
 
 
 # ------------------------------------------------------------------------------------------------ Llama-2-70B shaped TP decoder (bench)
@@ -220,14 +275,26 @@ class TPDecoderLayer(nn.Module):
         y = self.reduce(y)
         return residual + y.to(residual.dtype)
 
-    def forward(self, x, cos, sin, cache, pos_idx, attn_mask):
-        """x [1, S, hidden] (replicated); cache = (k [1, kv_loc, L, hd], v, valid [1, L]); pos_idx [S] device positions"""
+    def forward(self, x, cos, sin, cache, pos_idx, attn_mask, from_zero=False):
+        """x [1, S, hidden] (replicated); cache = (k [1, kv_loc, L, hd], v, valid [1, L]); pos_idx [S] device positions;
+        from_zero: the caller knows pos_idx == arange(S) (a prompt prefilled from position 0 into an empty cache)"""
         B, S, hid = x.shape
         hd = self.hd
         qkv = self.qkv(self._norm(x, self.n1))
         ck, cv, valid = cache
+        nq, nk = self.h_loc * hd, self.kv_loc * hd
         if S == 1 and ops.decode_attention_supported(self.h_loc, self.kv_loc, hd):
             a = ops.decode_attention(qkv, cos, sin, ck, cv, valid, pos_idx, self.h_loc, self.kv_loc)       # RoPE + append + attention
+        elif (from_zero and S > 1 and hd == 128 and S % 64 == 0 and qkv.is_contiguous() and not self.qkv.interleave8 and
+              ops.prefill_attention_supported(qkv[..., :nq].view(B, S, self.h_loc, hd), qkv[..., nq:nq + nk].view(B, S, self.kv_loc, hd),
+                                              qkv[..., nq + nk:].view(B, S, self.kv_loc, hd))):
+            # whole-prompt causal attention straight on the three slices of the fused projection output (as serving_loop does): in-place
+            # RoPE of the q and k heads in one launch, flash-style kernel over S keys -- no [S, Lc] mask, no SDPA over the cache length
+            ops.rope_(qkv[..., :nq + nk], cos, sin, self.h_loc + self.kv_loc, S, 0)
+            k4, v4 = qkv[..., nq:nq + nk].view(B, S, self.kv_loc, hd), qkv[..., nq + nk:].view(B, S, self.kv_loc, hd)
+            a = ops.prefill_attention(qkv[..., :nq].view(B, S, self.h_loc, hd), k4, v4, causal=True)
+            ck[:, :, :S] = k4.transpose(1, 2)
+            cv[:, :, :S] = v4.transpose(1, 2)
         else:
             from .serving_loop import _rope
             q, k, v = self.qkv.split(qkv)
@@ -237,6 +304,9 @@ class TPDecoderLayer(nn.Module):
             v = v.view(B, S, self.kv_loc, hd).transpose(1, 2)
             ck.index_copy_(2, pos_idx, k)
             cv.index_copy_(2, pos_idx, v)
+            if attn_mask is None:                     # (the caller expected the prefill-attention kernel to take this chunk)
+                keypos = torch.arange(ck.shape[2], device=x.device)
+                attn_mask = (keypos[None, :] <= pos_idx[:, None])[None, None] & valid[:, None, None, :]
             a = F.scaled_dot_product_attention(q, ck, cv, attn_mask=attn_mask, enable_gqa=(self.kv_loc != self.h_loc))
             a = a.transpose(1, 2).reshape(B, S, self.h_loc * hd)
         x = self._row_parallel(self.o, a, x)
@@ -263,7 +333,6 @@ class TPDecoder(nn.Module):
         from .serving_loop import _rope_tables
         hid, inter, nl, heads, kvh, vocab = cfg
         assert heads % world == 0 and kvh % world == 0, "query and kv heads must both divide by the TP degree (no kv-head replication)"
-        assert (heads // kvh) in (1, 4, 8) or True
         gen = torch.Generator(device=device).manual_seed(seed + 1000 * rank)       # shards differ per rank
         rep = torch.Generator(device=device).manual_seed(seed)                      # replicated tensors agree on every rank
         self.cfg, self.dtype, self.dev, self.rank, self.world = cfg, dtype, device, rank, world
@@ -298,18 +367,22 @@ class TPDecoder(nn.Module):
                 "valid": torch.zeros(1, length, dtype=torch.bool, device=self.dev)}
 
     @torch.no_grad()
-    def forward(self, ids, pos_idx, cache):
+    def forward(self, ids, pos_idx, cache, from_zero=False):
         """ids [1, S]; pos_idx [S] int64 device tensor (cache positions of these tokens; S > 1: a prefill chunk starting anywhere).
+        from_zero=True: the caller asserts pos_idx == arange(S) on an empty cache (a whole prompt) -- the layers then run RoPE + the
+        flash-style prefill attention kernel instead of SDPA over a dense [S, cache length] mask.
         Returns the logits of the last position [1, 1, vocab] (replicated on every rank)."""
         B, S = ids.shape
         Lc = cache["valid"].shape[1]
         cache["valid"].index_fill_(1, pos_idx, True)
-        # query i (at position pos_idx[i]) sees the valid keys at positions <= pos_idx[i]: correct for a chunk that starts at pos > 0 too
-        keypos = torch.arange(Lc, device=self.dev)
-        mask = (keypos[None, :] <= pos_idx[:, None])[None, None] & cache["valid"][:, None, None, :]
+        mask = None
+        if not (from_zero and S > 1 and S % 64 == 0 and self.hd == 128):
+            # query i (at position pos_idx[i]) sees the valid keys at positions <= pos_idx[i]: correct for a chunk that starts at pos > 0 too
+            keypos = torch.arange(Lc, device=self.dev)
+            mask = (keypos[None, :] <= pos_idx[:, None])[None, None] & cache["valid"][:, None, None, :]
         x = self.embed[ids]
         for li, layer in enumerate(self.layers):
-            x = layer(x, self.cos, self.sin, (cache["k"][li], cache["v"][li], cache["valid"]), pos_idx, mask)
+            x = layer(x, self.cos, self.sin, (cache["k"][li], cache["v"][li], cache["valid"]), pos_idx, mask, from_zero=from_zero)
         last = x[:, -1:, :]
         last = ops.rmsnorm_tenant(last.contiguous(), self.norm, 1e-5) if last.shape[-1] % 8 == 0 else F.rms_norm(last, (last.shape[-1],), self.norm[0], 1e-5)
         return last @ self.lm_head.T
@@ -353,7 +426,7 @@ class TPDecoder(nn.Module):
 def bench_tp70b(args, dev, rank, world, timer):
     """bench.py --workload tp70b: Llama-2-70B shapes over `world` ranks (8 on a full node), prefill of one 2048-token sequence and
     decode steps; value = prefill tokens/s of the WHOLE job (strong scaling: the ranks share one sequence)."""
-    from .dist import timed_region
+    from .dist import timed_region, runtime_info
     dec = TPDecoder(LLAMA_70B, dev, torch.bfloat16, rank, world, layers=args.layers, seed=77, max_len=args.seq + args.kv_len + 64)
     ids = torch.randint(0, 32000, (1, args.seq), device=dev, generator=torch.Generator(device=dev).manual_seed(5))
     cache = dec.new_cache(max(args.seq, args.kv_len) + 64)
@@ -361,7 +434,7 @@ def bench_tp70b(args, dev, rank, world, timer):
 
     def step():
         cache["valid"].zero_()
-        return dec(ids, pos_prefill, cache)
+        return dec(ids, pos_prefill, cache, from_zero=True)
     for _ in range(args.warmup):
         step()
     timer.reset()
@@ -401,4 +474,8 @@ def bench_tp70b(args, dev, rank, world, timer):
                      "share_of_step_time": (k_ms / 1e3) / dt if dt > 0 else None},
         "decode": {"ms_per_step": ddt / 20 * 1e3, "kv_len": args.kv_len, "linear_bytes_per_rank": dec.linear_bytes_per_rank(),
                    "linear_gbs_per_rank_if_only_linears": dec.linear_bytes_per_rank() / (ddt / 20) * 1e-9},
+        # which transport the partial-sum exchange actually took on this run (prefill messages: ring; decode messages: one-shot when
+        # every rank could set symmetric memory up, else ring + the first reason it was ruled out)
+        "all_reduce": dec.reducer.report() if hasattr(dec, "reducer") else None,
+        **runtime_info(),
     }

@@ -234,8 +234,11 @@ int bd_set_tail_split(int on);
 int bd_set_decode_two_launch(int on);
 /* A/B hook: 1 (default) = fused launches of the VALU decode kernel run wave-specialised (4 weight-streaming + 4 sign waves per block) */
 int bd_set_decode_wave_spec(int on);
-/* A/B hook of the streaming decode kernel (effective only in -DBD_AB_VARIANTS builds; the shipped library ignores it):
- * bit 0 = natural-order base-weight loads, bit 1 = nt cache policy, bit 2 = 8-wave blocks, bit 3 = deeper prefetch */
+/* A/B hook of the streaming decode kernel.  Bits 0-3 are effective only in -DBD_AB_VARIANTS builds (the shipped library ignores them):
+ * bit 0 = natural-order base-weight loads, bit 1 = nt cache policy, bit 2 = 8-wave blocks, bit 3 = deeper prefetch.
+ * Bits 4 / 5 work in the shipped library: 16 = non-temporal policy ON for the tile-major base-weight loads of the packed-layout kernels,
+ * 32 = OFF (neither: the library default); 64 = activation rows resident in LDS + deeper weight prefetch (tile-major weight, M = 1,
+ * K = 2048 * 2^s, B * K <= 32768) ON wherever it applies, 128 = OFF (neither: the library's shape rule). */
 int bd_set_stream_tuning(int flags);
 /* A/B hook, sign LUT of the no-split-k decode kernel: -1 (default) automatic, 1 = single 4-KiB table, 0 = 16-copy conflict-free
  * 64-KiB table whenever it fits in LDS */
@@ -243,6 +246,16 @@ int bd_set_decode_small_lut(int mode);
 /* A/B hook: 1 = the no-split-k decode kernel always runs its generic one-iteration-ahead loop (default 0: delta-only K = 4096
  * launches use the straight-line instantiation: iterations 0-1 in flight during activation staging, 2-3 issued after the barrier) */
 int bd_set_decode_generic_loop(int on);
+/* Which kernel serves the packed-layout decode launches (bd_binary_linear_decode[_fused] with mask_layout 2) of the calling thread:
+ * -1 = the library default, 0 = streaming register-load kernel (gemv_stream_kernel, variant 600), 1 = LDS-DMA loader / consumer
+ * kernel (gemv_ring_kernel, variant 700; launches outside its envelope -- K % 128 != 0, K < 512, no base weight -- stay on 600).
+ * bd_set_gemm_variant(700) forces the same kernel and answers BD_E_BAD_SHAPE outside the envelope. */
+int bd_set_decode_engine(int engine);
+/* Knobs of variant 700 (-1 = defaults): bit 0 = non-temporal policy on the weight / sign streams, bit 1 = the activation rows ride the
+ * ring even when a resident LDS copy would fit, bit 2 = one loader wave instead of two, bit 3 = 4-copy LDS sign table instead of VALU expansion, bit 4 = per-block
+ * rotation of the k walk, bits 8..13 = cap on the number of ring slots
+ * (0 = as many as fit). */
+int bd_set_ring_tuning(int flags);
 
 #ifdef __cplusplus
 }

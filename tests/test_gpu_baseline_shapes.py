@@ -149,6 +149,86 @@ def test_config2_llama2_7b_prefill2048(bd, oracle, name):
     check_delta(bd, oracle, x[:, :256].contiguous(), p, cols=cols[:24])      # the un-fused op (M = 256 rows)
 
 
+def fused_boundary_columns(lin, n=40, seed=0):
+    """Stored output rows of a FusedDeltaLinear that straddle every scale-group boundary, 8-row interleave block, 128 / 256-column
+    tile edge and the tail split of the timed launch, plus random ones."""
+    N = lin.weight.shape[0]
+    gsz = N // lin.groups
+    cols = set([0, 1, 7, 8, 15, 16, 127, 128, 255, 256, N - 257, N - 256, N - 129, N - 128, N - 17, N - 16, N - 9, N - 8, N - 1])
+    if lin.interleave8:
+        for b in (1, N // 16, N // 8 - 1):                                 # gate block / up block of a few 16-row tiles
+            cols.update([16 * b - 1, 16 * b, 16 * b + 7, 16 * b + 8, 16 * b + 15])
+    else:
+        for gi in range(1, lin.groups):                                     # both sides of every scale-group boundary
+            cols.update([gi * gsz - 2, gi * gsz - 1, gi * gsz, gi * gsz + 1])
+        acc = 0
+        for wd in lin.widths[:-1]:                                          # ... and of every projection boundary
+            acc += wd
+            cols.update([acc - 1, acc])
+    g = torch.Generator().manual_seed(seed)
+    cols.update(torch.randint(0, N, (n,), generator=g).tolist())
+    return torch.tensor(sorted(c for c in cols if 0 <= c < N), dtype=torch.long)
+
+
+FUSED_PREFILL = {
+    # name: (projection shapes, interleave8)  -- exactly what bench_model.DecoderLayer builds (bench_model.py:135-136) and Mistral-7B's
+    "llama7b_qkv_12288_G3": ([(4096, 4096), (4096, 4096), (4096, 4096)], False),
+    "llama7b_gate_up_22016_il8": ([(11008, 4096), (11008, 4096)], True),
+    "mistral7b_qkv_6144_G6": ([(4096, 4096), (1024, 4096), (1024, 4096)], False),
+    "mistral7b_gate_up_28672_il8": ([(14336, 4096), (14336, 4096)], True),
+}
+
+
+@pytest.mark.parametrize("name", list(FUSED_PREFILL))
+def test_config2_fused_launches_of_the_timed_prefill_step(bd, oracle, name):
+    """The launches bench.py's headline number is made of: q|k|v as ONE Linear (one scale group per projection) and gate|up as ONE
+    8-row-interleaved Linear (two scales), M = 2048, bf16, through FusedDeltaLinear -> bd_binary_linear -> delta_gemm_w4_kernel
+    <fused> (variant 14; gate|up: + the 128x128 tail launch).  Oracle on sampled stored rows with each row's own scale."""
+    from bitdelta_amd import _lib
+    from bitdelta_amd.diff import binarize
+    from bitdelta_amd.serving_loop import FusedDeltaLinear
+    shapes, il8 = FUSED_PREFILL[name]
+    dev = torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(1234 + len(name))
+    ws, ms, cs = [], [], []
+    for n_out, n_in in shapes:
+        w = (torch.randn(n_out, n_in, device=dev, generator=gen) * 0.02).bfloat16()
+        fine = (w.float() + torch.randn(n_out, n_in, device=dev, generator=gen) * 5e-4).bfloat16()
+        m, c = binarize(w, fine)
+        ws.append(w); ms.append(m[None]); cs.append((c * (1.0 + 0.25 * len(cs))).reshape(1))       # distinct scales per projection
+    lin = FusedDeltaLinear(ws, ms, cs, interleave8=il8, decode_copies=False)
+    N, K = lin.weight.shape
+    M = 2048
+    x = torch.randn(1, M, K, device=dev, generator=gen).bfloat16()
+    L = _lib.lib()
+    y16 = lin(x)
+    assert L.bd_last_gemm_variant() == 14, L.bd_last_gemm_variant()
+    y32 = lin(x, out_dtype=torch.float32)
+    cols = fused_boundary_columns(lin, seed=N)
+    col_alpha = lin.column_alpha(0)[cols.to(dev)].float().cpu().reshape(1, -1)
+    ref32 = oracle.binary_linear(x.cpu(), lin.weight[cols.to(dev)].cpu().contiguous(), lin.mask[:, :, cols.to(dev)].cpu().contiguous(),
+                                 col_alpha, G=len(cols), out_dtype=torch.float32, round_mode=0)
+    got32, got16 = y32[:, :, cols.to(dev)].cpu(), y16[:, :, cols.to(dev)].cpu().contiguous()
+    assert relerr(got32, ref32) <= 1e-5
+    ref16 = ref32.bfloat16()
+    d = ulp_diff(got16, ref16)
+    ok = (d <= 1) | ((got16.float() - ref16.float()).abs() <= cancel_floor(ref16, K))
+    assert bool(ok.all()), d.max().item()
+    assert (d == 0).float().mean().item() >= 0.99
+    # the tail split (last, mostly empty round of 256x128 tiles handed to the 128x128 kernel) fires for Llama's gate|up and the two
+    # paths agree bit for bit: same launch with the split switched off
+    if name == "llama7b_gate_up_22016_il8":
+        L.bd_set_tail_split(0)
+        try:
+            y_nosplit = lin(x)
+        finally:
+            L.bd_set_tail_split(1)
+        assert torch.equal(y_nosplit, y16)
+    # the split() views give back the per-projection outputs in the reference's order
+    parts = lin.split(y16)
+    assert [t.shape[-1] for t in parts] == [s[0] for s in shapes]
+
+
 def test_config2_llama2_7b_decode_single_token(bd, oracle):
     """the same model one token at a time (BinaryDiff.forward at M = 1: the streaming decode kernel, one mask)"""
     for name, (N, K) in LLAMA7B.items():
