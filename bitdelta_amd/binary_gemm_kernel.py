@@ -211,12 +211,13 @@ def tile_weight(weight):
 def pack_decode_masks(mask):
     """Repack packed sign words [T, K/32, N] (reference / diff.pt layout) into the PACKED layout of the streaming decode kernel:
     int32 [ceil(N/16), ceil(K/128), 4, 16, t_pad] with element [tile][it][g][c][t] = tenant t's dword whose byte s holds the 8 signs
-    of k = 128 it + 32 s + 8 g .. + 7 of column 16 tile + c; tenants interleaved, zero-padded to t_pad in {1, 2, 4, 6, 8}.
+    of k = 128 it + 32 s + 8 g .. + 7 of column 16 tile + c; tenants interleaved, zero-padded to t_pad in {1, 2, 4, 6, 8, 12, 16}
+    (up to 16 tenants in one launch: the reference's own batched benchmark runs B = 16, notebooks/binary_gemm_kernel_triton.ipynb:759).
     Exact byte shuffling (torch ops on the device), done once per registered tenant set."""
     assert mask.dim() == 3 and mask.dtype == torch.int32
     T, KW, N = mask.shape
-    assert T <= 8, "the packed decode layout holds at most 8 tenants per call"
-    tp = next(v for v in (1, 2, 4, 6, 8) if v >= T)
+    assert T <= 16, "the packed decode layout holds at most 16 tenants per call"
+    tp = next(v for v in (1, 2, 4, 6, 8, 12, 16) if v >= T)
     KW4, N16 = (KW + 3) // 4 * 4, (N + 15) // 16 * 16
     if KW4 != KW or N16 != N:
         mask = torch.nn.functional.pad(mask, (0, N16 - N, 0, KW4 - KW))
@@ -229,12 +230,13 @@ def pack_decode_masks(mask):
     return out.contiguous()
 
 
-def decode_shape_ok(B, M, N, K, n_masks):
-    """True when bd_binary_linear_decode accepts the problem (the streaming decode kernel's envelope)."""
+def decode_shape_ok(B, M, N, K, n_masks, layout="packed"):
+    """True when bd_binary_linear_decode accepts the problem (the streaming decode kernel's envelope): up to 16 activation rows, and up
+    to 16 masks in the packed layout (8 in the tile-major one)."""
     if M < 1 or M > 16 or N < 512 or K % 32:
         return False
     chunk = min(B, 16 // M)
-    return (1 if n_masks == 1 else chunk) <= 8
+    return (1 if n_masks == 1 else chunk) <= (16 if layout == "packed" else 8)
 
 
 def fused_norm_ok(B, M, K):

@@ -14,7 +14,9 @@
 #include "bd_gemm_w4.h"
 #include "bd_gemv.h"
 #include "bd_gemv_stream.h"
-#include "bd_gemv_ring.h"
+#ifdef BD_AB_VARIANTS
+#include "../../tests/native/ab/bd_gemv_ring.h"     // LDS-DMA loader / consumer decode kernel: lost its A/B (profiles/r04_decode_ring_ab.txt)
+#endif
 #include "bd_serving.h"
 #include "bd_attn_prefill.h"
 #include <algorithm>
@@ -35,8 +37,8 @@ static thread_local int g_gemv_two_launch = 1;       // 1 (default) = split-k pa
                                         // (measured slower: the last-arriver tail is serial inside every tile; bd_gemv.h)
 static thread_local int g_gemv_target_blocks = 512;
 static thread_local int g_stream_tune = 0;            // A/B hook (harness build): bit 0 = natural-order W, bit 1 = nt cache policy, bit 2 = 8-wave blocks, bit 3 = deeper prefetch
-static thread_local int g_decode_engine = -1;         // packed-layout decode launches: -1 = library default (DECODE_ENGINE_DEFAULT), 0 = streaming
-                                                      // register-load kernel (variant 600), 1 = LDS-DMA loader / consumer kernel (variant 700)
+static thread_local int g_decode_engine = -1;         // (harness builds) packed-layout decode launches: -1 / 0 = streaming register-load kernel
+                                                      // (variant 600), 1 = LDS-DMA loader / consumer kernel (variant 700, tests/native/ab/)
 static thread_local int g_ring_tune = -1;             // variant 700 knobs, -1 = defaults: bit 0 = nt weight / sign streams, bit 1 = activations ride the
                                                       // ring even when a resident copy fits, bit 2 = ONE loader wave (default two), bits 8..13 = cap on
                                                       // the ring slots (0 = none)
@@ -322,7 +324,7 @@ constexpr int STREAM_WT_NT_DEFAULT = 1;           // (-3.6 % on the 6-tenant Mis
 constexpr int STREAM_XRES_DEFAULT = 1;            // activation rows resident in LDS + deeper prefetch (XL = 2) where the rule below says so
 // (STREAM_WT_NT_DEFAULT: non-temporal policy on the tile-major weight loads of the streaming kernel)
 inline bool stream_ok(const Problem& q, int rows, int nmask) {
-    if (rows > GEMV_MAX_R || nmask > 8 || q.N < STREAM_MIN_N) return false;
+    if (rows > GEMV_MAX_R || nmask > (q.mask_tiled == 2 ? 16 : 8) || q.N < STREAM_MIN_N) return false;
     // 32-bit buffer offsets with an out-of-range sentinel at 2 GiB: every extent must stay below it
     const int64_t lim = (1ll << 31) - 64;
     const int64_t xb = ((int64_t)(q.B - 1) * q.sAb + (int64_t)(q.M - 1) * q.sAm + q.K) * 2;
@@ -367,6 +369,7 @@ int launch_stream_tuned(const StreamParams& sp, dim3 grid, hipStream_t st) {
     return launch_stream_inst<DT, NM, HASW, NS4, 4, 0, 0>(sp, grid, st);
 }
 
+#ifdef BD_AB_VARIANTS
 // ---- loader / consumer decode kernel (gemv_ring_kernel, variant 700): packed sign layout, fused Linear, K % 128 == 0
 constexpr int DECODE_ENGINE_DEFAULT = 0;          // what packed-layout decode launches run when nobody called bd_set_decode_engine
 constexpr int RING_TUNE_DEFAULT = 1;              // nt streams, resident activations when they fit, as many slots as fit
@@ -398,6 +401,8 @@ template <int DT, int NM>
 int launch_ring_inst(const RingParams& rp, unsigned grid, hipStream_t st) {
     return rp.nt ? launch_ring_inst2<DT, NM, 1>(rp, grid, st) : launch_ring_inst2<DT, NM, 0>(rp, grid, st);
 }
+
+#endif
 
 template <int DT>
 int launch_gemv_stream_chunk(const Problem& q) {
@@ -441,6 +446,7 @@ int launch_gemv_stream_chunk(const Problem& q) {
     int rc;
     if (q.mask_tiled == 2) {      // packed layout: all tenants of the call in one chunk, interleaved; extent from the pack's own geometry
         sp.p_bytes = (uint32_t)((int64_t)((q.N + 15) / 16) * ((q.K + 127) / 128) * 4 * 16 * q.t_pad * 4);
+#ifdef BD_AB_VARIANTS
         if (ring_wanted()) {      // loader / consumer kernel (variant 700); launches outside its envelope stay on the streaming kernel
             RingParams rp{};
             rp.g = gp; rp.cpb = cpb;
@@ -461,6 +467,9 @@ int launch_gemv_stream_chunk(const Problem& q) {
         }
         // kernel kinds: plain | RMSNorm prologue (XL) | XL + SwiGLU epilogue | SwiGLU epilogue only; tile-major W (WT) for the three
         // the serving loop uses (a norm prologue without SwiGLU on tile-major W answers BD_E_BAD_SHAPE)
+#else
+        if (g_forced_variant == 700) return BD_E_BAD_SHAPE;      // harness-only kernel (round 4 A/B loser): never silently replaced
+#endif
         // tile-major W: optional nt policy on the weight loads (STREAM_WT_NT_DEFAULT, or bd_set_stream_tuning bit 4 = on / bit 5 = off)
         const bool wnt = (g_stream_tune & 16) ? true : (g_stream_tune & 32) ? false : (STREAM_WT_NT_DEFAULT != 0);
         // ... and optionally the activation rows resident in LDS with a deeper weight prefetch (XL = 2; bd_set_stream_tuning bit 6 = on,
@@ -505,6 +514,18 @@ int launch_gemv_stream_chunk(const Problem& q) {
             case 4: BD_PK(4, 4); break;
             case 6: BD_PK(6, 4); break;
             case 8: BD_PK(8, 4); break;
+            // 9 .. 16 tenants in ONE launch (the reference publishes B = 16: notebooks/binary_gemm_kernel_triton.ipynb:759): plain and SwiGLU
+            // launches; the fused-norm / resident-row forms end at 8 rows of K = 4096 anyway
+#define BD_PKL(NM) rc = (q.norm_w || !q.W) ? BD_E_BAD_SHAPE                                                                             \
+                     : q.w_tiled ? (q.epilogue == 1 ? (wnt ? launch_stream_inst<DT, NM, true, 4, 4, 1, 2, 1, 0, 1, 1>(sp, dim3(grid), q.st)    \
+                                                            : launch_stream_inst<DT, NM, true, 4, 4, 1, 0, 1, 0, 1, 1>(sp, dim3(grid), q.st))  \
+                                                    : (wnt ? launch_stream_inst<DT, NM, true, 4, 4, 1, 2, 1, 0, 0, 1>(sp, dim3(grid), q.st)    \
+                                                            : launch_stream_inst<DT, NM, true, 4, 4, 1, 0, 1, 0, 0, 1>(sp, dim3(grid), q.st))) \
+                     : q.epilogue == 1 ? launch_stream_inst<DT, NM, true, 4, 4, 1, 0, 1, 0, 1>(sp, dim3(grid), q.st)                     \
+                                       : launch_stream_inst<DT, NM, true, 4, 4, 1, 0, 1>(sp, dim3(grid), q.st)
+            case 12: BD_PKL(12); break;
+            case 16: BD_PKL(16); break;
+#undef BD_PKL
             default: return BD_E_BAD_SHAPE;
         }
 #undef BD_PK
@@ -780,6 +801,54 @@ int launch_fused_splitk(const Problem& q, int KS) {
     return q.M <= 64 ? launch_fused_splitk_bm<DT, 64>(q, KS) : launch_fused_splitk_bm<DT, 128>(q, KS);
 }
 
+// ---- pair tiles (bd_gemm_fx.h, PAIR): two batch entries of <= 64 rows share one 128 x 128 tile (and its W stream); optional split-k
+inline bool pair_ok(const Problem& q) {
+    return q.W && q.B >= 2 && q.M >= 1 && q.M <= 64 && fast_ok(q) && q.sAb >= 0 && q.sAb < (1ll << 30) && q.sPb >= 0 && q.sPb < (1ll << 29);
+}
+inline int pair_splitk_dims(int B, int N, int K) {    // k slices so that pairs x column tiles x slices ~ fills the CUs (>= 512 k per slice)
+    const long long cus = num_cus();
+    const long long tiles = (long long)((B + 1) / 2) * ((N + 127) / 128);
+    if (K % 64 || N % 8 || tiles * 2 > cus) return 1;
+    long long ks = cus / tiles;
+    if (ks > 8) ks = 8;
+    while (ks > 1 && K / ks < 512) --ks;
+    return (int)ks;
+}
+inline int pair_splitk(const Problem& q) { return pair_splitk_dims(q.B, q.N, q.K); }
+template <int DT, bool OUT_F32>
+int launch_pair(const Problem& q) {
+    using Cfg = FxCfg<DT, 128, 128, 4, OUT_F32, 1, 1>;
+    GemmParams p = make_params(q, Cfg::BM, Cfg::BN);          // tiles_m = 1: the tile's two halves are two batch entries
+    auto kern = delta_gemm_fx_kernel<Cfg>;
+    static std::atomic<uint64_t> lds_done{0};
+    if (!ensure_dyn_lds((const void*)kern, Cfg::LDS_BYTES, lds_done)) return BD_E_LAUNCH;
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)((q.B + 1) / 2));
+    hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, q.st, p);
+    return launch_status();
+}
+template <int DT>
+int launch_pair_splitk(const Problem& q, int KS) {
+    const int64_t need = GEMV_TICKET_BYTES + (int64_t)q.B * KS * q.M * q.N * 4;
+    if (!q.ws || q.ws_bytes < need) return BD_E_WORKSPACE;
+    float* part = (float*)((char*)q.ws + GEMV_TICKET_BYTES);
+    Problem c = q;
+    c.C = part; c.out_dtype = BD_F32; c.sCm = q.N; c.sCb = (int64_t)q.M * q.N;     // slab y = entry * KS + ks
+    c.accumulate = 0;                                                                // (the residual is added by the reduce launch)
+    using Cfg = FxCfg<DT, 128, 128, 4, true, 1, 1>;
+    GemmParams p = make_params(c, Cfg::BM, Cfg::BN);
+    p.ksplit = KS;
+    auto kern = delta_gemm_fx_kernel<Cfg>;
+    static std::atomic<uint64_t> lds_done{0};
+    if (!ensure_dyn_lds((const void*)kern, Cfg::LDS_BYTES, lds_done)) return BD_E_LAUNCH;
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)(((q.B + 1) / 2) * KS));
+    hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, q.st, p);
+    const long long per = (long long)q.M * q.N / 4;
+    dim3 g2((unsigned)((per + 255) / 256), (unsigned)q.B);
+    hipLaunchKernelGGL((splitk_reduce_kernel<DT>), g2, dim3(256), 0, q.st, (const float*)part, q.C, q.B, KS, q.M, q.N,
+                       (long long)q.sCb, (int)q.sCm, q.out_dtype == BD_F32 ? 1 : 0, q.accumulate);
+    return launch_status();
+}
+
 template <int DT, bool FUSED, bool OUT_F32>
 int dispatch3(const Problem& q) {
     int v = g_forced_variant;
@@ -799,6 +868,14 @@ int dispatch3(const Problem& q) {
     if (v < 0) {
         if (gemv_ok(q)) v = 200;
         else if (!fast_ok(q)) v = 100;
+        else if (FUSED && q.M > 16 && q.M <= 64 && q.B >= 2 && pair_ok(q)) {
+            // several batch entries of <= 64 rows (multi-tenant prefill of short prompts, demo_backend.py:297-299): two entries per 128-row
+            // tile share one W stream; narrow outputs add split-k (tools/bench_mt_prefill.py, 6 tenants x 64 rows, Mistral-7B shapes:
+            // q|k|v 59 -> 50 us, o 39 -> 33, gate|up 201 -> 177, down 130 -> 91; profiles/r04_mt_prefill_tiles.txt)
+            const int kp = pair_splitk(q);
+            v = (kp > 1 && q.N % 8 == 0 && q.sCm % 4 == 0 && q.sCb % 4 == 0 && q.ws &&
+                 q.ws_bytes >= GEMV_TICKET_BYTES + (int64_t)q.B * kp * q.M * q.N * 4) ? 17 : 16;
+        }
         else if (FUSED && q.M > 16 && !q.accumulate && q.sCm % 4 == 0 && q.sCb % 4 == 0 && splitk_factor(q.B, q.M, q.N, q.K) > 1 && q.ws &&
                  q.ws_bytes >= GEMV_TICKET_BYTES + (int64_t)q.B * splitk_factor(q.B, q.M, q.N, q.K) * q.M * q.N * 4) v = 10;
         else if (FUSED && q.M > 16 && q.M <= 64)                  // (not split: there are enough 64-row tiles)
@@ -820,13 +897,14 @@ int dispatch3(const Problem& q) {
         else v = 3;
     } else {
         if ((v == 200 || v == 300 || v == 400 || v == 500 || v == 600) && !gemv_ok(q)) return BD_E_BAD_SHAPE;
-        if (v >= 0 && v <= 15 && !fast_ok(q)) return BD_E_BAD_SHAPE;
+        if (v >= 0 && v <= 17 && !fast_ok(q)) return BD_E_BAD_SHAPE;
+        if ((v == 16 || v == 17) && !FUSED) return BD_E_BAD_SHAPE;
         if (v == 15 && (!FUSED || OUT_F32 || q.epilogue != 1)) return BD_E_BAD_SHAPE;
         if (v == 13 && FUSED) return BD_E_BAD_SHAPE;
         if (v == 14 && !FUSED) return BD_E_BAD_SHAPE;
         if ((v == 8 || v == 9 || v == 10 || v == 11 || v == 12) && !FUSED) return BD_E_BAD_SHAPE;
         if (v == 10 && (q.N % 8 || q.sCm % 4 || q.sCb % 4 || q.accumulate)) return BD_E_BAD_SHAPE;
-        if (FUSED && q.accumulate && !(v == 8 || v == 9 || v == 11 || v == 12 || v == 14 || v == 200 || v == 300 || v == 400 || v == 500 || v == 600))
+        if (FUSED && q.accumulate && !(v == 8 || v == 9 || v == 11 || v == 12 || v == 14 || v == 16 || v == 17 || v == 200 || v == 300 || v == 400 || v == 500 || v == 600))
             return BD_E_BAD_SHAPE;            // residual epilogue: one-pass fused tiles and the decode kernels only
     }
     t_last_variant = v;
@@ -872,6 +950,18 @@ int dispatch3(const Problem& q) {
         case 12:     // one-pass fused, 64x256 tile: wide outputs / many tenants (see the rule above)
             if constexpr (FUSED) return launch_tile<FxCfg<DT, 64, 256, 3, OUT_F32, 1>, 3>(q);
             else return BD_E_BAD_SHAPE;
+        case 16:     // pair tiles: two batch entries of <= 64 rows per 128x128 tile (multi-tenant prefill of short prompts)
+            if constexpr (FUSED) { if (!pair_ok(q)) return BD_E_BAD_SHAPE; return launch_pair<DT, OUT_F32>(q); }
+            else return BD_E_BAD_SHAPE;
+        case 17: {   // pair tiles + split-k (narrow outputs: o / down of a 6-tenant request are 96 tiles on 256 CUs)
+            if constexpr (FUSED) {
+                if (!pair_ok(q) || q.N % 8 || q.sCm % 4 || q.sCb % 4) return BD_E_BAD_SHAPE;
+                int ks = pair_splitk(q);
+                if (ks < 2) ks = (q.K / 64 >= 2) ? 2 : 1;
+                if (ks < 2) return BD_E_BAD_SHAPE;
+                return launch_pair_splitk<DT>(q, ks);
+            } else return BD_E_BAD_SHAPE;
+        }
         case 9:      // one-pass fused, 128x128 tile, 4-slot ring: twice the tiles when 256x128 cannot fill the CUs (128 < M <~ 768)
             if constexpr (FUSED) return launch_tile<FxCfg<DT, 128, 128, 4, OUT_F32, 1>, 3>(q);
             else return BD_E_BAD_SHAPE;
@@ -959,6 +1049,11 @@ extern "C" int64_t bd_gemm_workspace_bytes(int B, int M, int N, int K) {
         if (M > 16 && M <= 512 && K % 64 == 0 && N % 8 == 0) {
             int ks = splitk_factor(B, M, N, K);
             if (ks < 2 && g_forced_variant == 10) ks = 2;
+            if (B >= 2 && M <= 64) {                      // pair tiles (variants 16 / 17) split by their own rule
+                int kp = pair_splitk_dims(B, N, K);
+                if (kp < 2 && g_forced_variant == 17) kp = 2;
+                if (kp > ks) ks = kp;
+            }
             if (ks < 2) return 0;
             const int64_t need = (int64_t)B * ks * M * N * 4;
             return need <= SPLITK_WS_CAP * 2 ? GEMV_TICKET_BYTES + need : 0;
@@ -1045,7 +1140,7 @@ static int binary_linear_impl(const void* X, const void* W, const int32_t* P, co
         const int cb = GEMV_MAX_R / M, bc = B < cb ? B : cb;
         if (!stream_ok(q, bc * M, sPb == 0 ? 1 : bc)) return BD_E_BAD_SHAPE;
         if (q.mask_tiled == 2) {      // interleaved tenants: the whole batch is one chunk, one dword slot per tenant
-            const bool tp_ok = t_pad == 1 || t_pad == 2 || t_pad == 4 || t_pad == 6 || t_pad == 8;
+            const bool tp_ok = t_pad == 1 || t_pad == 2 || t_pad == 4 || t_pad == 6 || t_pad == 8 || t_pad == 12 || t_pad == 16;
             if (!tp_ok || B > t_pad || B > cb || (sPb == 0 && B > 1 && t_pad != 1)) return BD_E_BAD_SHAPE;
             q.sPb = t_pad == 1 ? 0 : 1;             // only "broadcast or not" matters to the kernel in this layout
             if (t_pad == 1 && B > 1) q.sPb = 0;

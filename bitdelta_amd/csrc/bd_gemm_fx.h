@@ -20,11 +20,21 @@
 
 namespace bd {
 
-template <int DT_, int BM_, int BN_, int NS_, bool OUT_F32_, int OPT_ = 1>
+// PAIR = 1 (multi-tenant prefill of short prompts, demo/demo_backend.py:297-299: T tenants x <= 64 rows): a 128-row tile holds TWO batch
+// entries -- rows 0..63 = entry 2y, rows 64..127 = entry 2y + 1 of the launch (blockIdx.y = pair index), each with its own sign words
+// and scales.  The two waves rows of the 2 x 4 wave layout coincide with the two entries, so every wave still expands ONE mask; what
+// the pair shares is the W panel (one W stream per CU serves two tenants: these shapes are bound by how fast a CU can pull W through
+// L2) and the LDS-DMA / barrier schedule of a full 128-row tile.  The ring slot carries both entries' [2 x BN] sign words.
+template <int DT_, int BM_, int BN_, int NS_, bool OUT_F32_, int OPT_ = 1, int PAIR_ = 0>
 struct FxCfg : GemmCfg<DT_, BM_, BN_, 2, 4, NS_, true, OUT_F32_, OPT_> {
     using Base = GemmCfg<DT_, BM_, BN_, 2, 4, NS_, true, OUT_F32_, OPT_>;
-    static constexpr int STAGE_X = Base::A_BYTES + Base::W_BYTES + Base::BW_BYTES;
-    static constexpr int DPW_X = Base::A_PW + Base::W_PW + Base::BW_PW;
+    static constexpr int PAIR = PAIR_;
+    static constexpr int PB_BYTES = Base::BW_BYTES * (PAIR ? 2 : 1);                     // sign words of a k-tile: one mask, or the pair's two
+    static constexpr int PB_PIECES = Base::BW_PIECES * (PAIR ? 2 : 1);
+    static constexpr int PB_PW = PB_PIECES >= Base::NW ? PB_PIECES / Base::NW : 1;
+    static constexpr int STAGE_X = Base::A_BYTES + Base::W_BYTES + PB_BYTES;
+    static constexpr int DPW_X = Base::A_PW + Base::W_PW + PB_PW;
+    static_assert(!PAIR || (BM_ == 128 && (PB_PIECES % Base::NW == 0 || Base::NW % PB_PIECES == 0)), "pair mode: 128-row tile = 2 x 64 rows");
     static constexpr int LUT_OFF = NS_ * STAGE_X;
     static constexpr int LDS_BYTES = NS_ * STAGE_X + 4096;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
@@ -37,8 +47,9 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_fx_kernel(const GemmParams
     constexpr int DT = Cfg::DT, BM = Cfg::BM, BN = Cfg::BN, NS = Cfg::NS;
     constexpr int WM = Cfg::WM, WN = Cfg::WN, TM = Cfg::TM, TN = Cfg::TN;
     constexpr int A_BYTES = Cfg::A_BYTES, W_BYTES = Cfg::W_BYTES, STAGE = Cfg::STAGE_X;
-    constexpr int A_PW = Cfg::A_PW, BW_PW = Cfg::BW_PW, W_PW = Cfg::W_PW;
+    constexpr int A_PW = Cfg::A_PW, BW_PW = Cfg::PB_PW, W_PW = Cfg::W_PW;
     constexpr int BW_OFF = A_BYTES + W_BYTES, LUT_OFF = Cfg::LUT_OFF;
+    constexpr bool PAIR = Cfg::PAIR != 0;
     constexpr bool USE_LUT = (Cfg::OPT & 1) != 0;
     static_assert(Cfg::NW == 8 && Cfg::WAVES_M == 2, "full-tile ping-pong: 8 waves, two groups");
 
@@ -58,8 +69,12 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_fx_kernel(const GemmParams
     // split-k (mid-size M: too few tiles to fill the chip): y = b * ksplit + ks; partials go to an fp32 workspace indexed by y
     const int by = blockIdx.y;
     const int ksp = max(p.ksplit, 1);
-    const int b = by / ksp;
-    const int ksi = by - b * ksp;
+    const int bq = by / ksp;                   // batch entry, or pair of entries
+    const int ksi = by - bq * ksp;
+    const int b = PAIR ? 2 * bq : bq;          // (first) batch entry of the tile
+    // pair mode: entry of a tile half (the second entry of the last pair of an odd batch does not exist: its half re-reads the first
+    // entry's operands and is not stored)
+    const bool has2 = !PAIR || b + 1 < p.nbatch;
     const int nk_all = p.K >> 6;
     const int kt_lo = (int)((long long)ksi * nk_all / ksp), kt_hi = (int)((long long)(ksi + 1) * nk_all / ksp);
     const int nk = kt_hi - kt_lo;
@@ -77,8 +92,13 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_fx_kernel(const GemmParams
         const int rg = wave * A_PW + i;
         const int r = rg * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
-        const int rr = min(m0 + r, p.M - 1) - m0;
-        a_voff[i] = (uint32_t)rr * (uint32_t)p.sAm * 2u + (uint32_t)c * 16u;
+        if constexpr (PAIR) {
+            const int half = (r >> 6) && has2, rr = min(r & 63, p.M - 1);
+            a_voff[i] = (uint32_t)(((long long)half * p.sAb + (long long)rr * p.sAm) * 2) + (uint32_t)c * 16u;
+        } else {
+            const int rr = min(m0 + r, p.M - 1) - m0;
+            a_voff[i] = (uint32_t)rr * (uint32_t)p.sAm * 2u + (uint32_t)c * 16u;
+        }
         a_lds[i] = rg * 1024;
     }
 #pragma unroll
@@ -92,11 +112,12 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_fx_kernel(const GemmParams
     }
 #pragma unroll
     for (int i = 0; i < BW_PW; ++i) {
-        const int idx = (wave * BW_PW + i) % Cfg::BW_PIECES;
+        const int idx2 = (wave * BW_PW + i) % Cfg::PB_PIECES;
+        const int half = idx2 / Cfg::BW_PIECES, idx = idx2 % Cfg::BW_PIECES;            // (half = 0 without PAIR)
         const int hh = idx / (BN / 64), seg = idx % (BN / 64);
         const int nn = min(n0 + seg * 64 + lane, p.N - 1) - n0;
-        bw_voff[i] = (uint32_t)hh * (uint32_t)p.N * 4u + (uint32_t)nn * 4u;
-        bw_lds[i] = BW_OFF + hh * BN * 4 + seg * 256;
+        bw_voff[i] = (uint32_t)hh * (uint32_t)p.N * 4u + (uint32_t)nn * 4u + (uint32_t)((half && has2) ? p.sPb * 4 : 0);
+        bw_lds[i] = BW_OFF + half * Cfg::BW_BYTES + hh * BN * 4 + seg * 256;
     }
     const int swz = (l31 >> 1) & 7;
     uint32_t a_rd[4], w_rd[4];
@@ -105,7 +126,7 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_fx_kernel(const GemmParams
         a_rd[s] = (uint32_t)(wm * WM + l31) * 128u + (uint32_t)(((4 * h + s) ^ swz) * 16);
         w_rd[s] = A_BYTES + (uint32_t)(wn * WN + l31) * 128u + (uint32_t)(((4 * h + s) ^ swz) * 16);
     }
-    const uint32_t bw_rd = BW_OFF + h * BN * 4 + (wn * WN + l31) * 4;
+    const uint32_t bw_rd = BW_OFF + (PAIR ? wm * Cfg::BW_BYTES : 0) + h * BN * 4 + (wn * WN + l31) * 4;
 
     f32x16_t accS[TM][TN], accW[TM][TN];
 #pragma unroll
@@ -235,7 +256,8 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_fx_kernel(const GemmParams
     wait_vmcnt<0>();
 
     // ---- out = accW + alpha[n] * accS  (fp32), then the shared staged epilogue
-    const float* al = p.alpha + (long long)b * p.sAlb;
+    const int b_w = PAIR ? (has2 ? b + wm : b) : b;      // this wave's batch entry
+    const float* al = p.alpha + (long long)b_w * p.sAlb;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -248,7 +270,12 @@ __global__ void __launch_bounds__(Cfg::NT) delta_gemm_fx_kernel(const GemmParams
                 for (int i = 0; i < TM; ++i) accW[i][j][q * 4 + e] = __builtin_fmaf(a, accS[i][j][q * 4 + e], accW[i][j][q * 4 + e]);
             }
     __builtin_amdgcn_s_barrier();
-    gemm_epilogue<Cfg>(p, accW, smem, m0, n0, wm, wn, by, lane, wave);
+    if constexpr (PAIR) {
+        // rows of this wave = rows 0..63 of ITS entry; output slab = the entry's own (split-k: slab entry * ksplit + ks of the workspace)
+        if (wm == 0 || has2) gemm_epilogue<Cfg>(p, accW, smem, m0 - wm * WM, n0, wm, wn, (b + wm) * ksp + ksi, lane, wave);
+    } else {
+        gemm_epilogue<Cfg>(p, accW, smem, m0, n0, wm, wn, by, lane, wave);
+    }
 }
 
 }  // namespace bd

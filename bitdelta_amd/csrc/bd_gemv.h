@@ -588,7 +588,7 @@ __global__ void __launch_bounds__(256) gemv_reduce_kernel(const GemvParams p) {
 // One thread per 4 consecutive columns; partials are read as float4 (N % 4 == 0 is guaranteed by the fast-path checks).
 template <int DT>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, void* C, int B, int KS, int M, int N,
-                                                             long long sCb, int sCm, int out_f32) {
+                                                             long long sCb, int sCm, int out_f32, int accumulate = 0) {
     const long long q4 = (long long)blockIdx.x * 256 + threadIdx.x;        // index of a float4 inside one [M][N] slab
     const int b = blockIdx.y;
     const long long per = (long long)M * N / 4;
@@ -605,11 +605,21 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
             if (k0 + j < KS) s += v[j];
     }
     const long long off = (long long)b * sCb + (long long)m * sCm + n;
+    // accumulate: C holds the residual (`hidden = residual + proj(x)`): the Linear's output is rounded to the output type first and the
+    // sum is rounded again -- the same two roundings as the tile kernels' residual epilogue (gemm_epilogue, res_mode)
     if (out_f32) {
+        if (accumulate) s += *(const f32x4_t*)((const float*)C + off);
         *(f32x4_t*)((float*)C + off) = s;
     } else {
-        const uint32_t h0 = f32_to_half_bits<DT>(s[0]), h1 = f32_to_half_bits<DT>(s[1]);
-        const uint32_t h2 = f32_to_half_bits<DT>(s[2]), h3 = f32_to_half_bits<DT>(s[3]);
+        uint32_t h0 = f32_to_half_bits<DT>(s[0]), h1 = f32_to_half_bits<DT>(s[1]);
+        uint32_t h2 = f32_to_half_bits<DT>(s[2]), h3 = f32_to_half_bits<DT>(s[3]);
+        if (accumulate) {
+            const u32x2_t r = *(const u32x2_t*)((const unsigned short*)C + off);
+            h0 = f32_to_half_bits<DT>(half_bits_to_f32<DT>(h0) + half_bits_to_f32<DT>(r[0] & 0xffffu));
+            h1 = f32_to_half_bits<DT>(half_bits_to_f32<DT>(h1) + half_bits_to_f32<DT>(r[0] >> 16));
+            h2 = f32_to_half_bits<DT>(half_bits_to_f32<DT>(h2) + half_bits_to_f32<DT>(r[1] & 0xffffu));
+            h3 = f32_to_half_bits<DT>(half_bits_to_f32<DT>(h3) + half_bits_to_f32<DT>(r[1] >> 16));
+        }
         *(u32x2_t*)((unsigned short*)C + off) = u32x2_t{h0 | (h1 << 16), h2 | (h3 << 16)};
     }
 }

@@ -239,16 +239,17 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
                 const u32x2_t v = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rp, (int)po, 0, AUXP));
                 st.wd[0] = v[0]; st.wd[1] = v[1];
             } else {
-                const u32x4_t v = buf_load16<AUXP>(rp, po);
+                // NM / 4 full 16-byte loads of the lane's adjacent tenant dwords (+ one 8-byte load when NM % 4 == 2: t_pad = 6)
 #pragma unroll
-                for (int t = 0; t < 4 && t < NM; ++t) st.wd[t] = v[t];
-                if constexpr (NM == 6) {
-                    const u32x2_t v2 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rp, (int)(po == STREAM_OOB ? STREAM_OOB : po + 16u), 0, AUXP));
-                    st.wd[4] = v2[0]; st.wd[5] = v2[1];
-                } else if constexpr (NM == 8) {
-                    const u32x4_t v2 = buf_load16<AUXP>(rp, po == STREAM_OOB ? STREAM_OOB : po + 16u);
+                for (int q4 = 0; q4 < NM / 4; ++q4) {
+                    const u32x4_t v = buf_load16<AUXP>(rp, po == STREAM_OOB ? STREAM_OOB : po + 16u * q4);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) st.wd[4 + t] = v2[t];
+                    for (int t = 0; t < 4; ++t) st.wd[4 * q4 + t] = v[t];
+                }
+                if constexpr (NM % 4 == 2) {
+                    const u32x2_t v2 = __builtin_bit_cast(
+                        u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rp, (int)(po == STREAM_OOB ? STREAM_OOB : po + 16u * (NM / 4)), 0, AUXP));
+                    st.wd[NM - 2] = v2[0]; st.wd[NM - 1] = v2[1];
                 }
             }
         } else {

@@ -87,7 +87,7 @@ class FusedDeltaLinear(nn.Module):
         self.groups = alpha.shape[1]
         # decode copy of the sign words in the streaming kernel's packed order (tenants interleaved, natural k order); prefill keeps
         # the reference layout
-        self.register_buffer("mask_packed", pack_decode_masks(self.mask) if (decode_copies and self.mask.shape[0] <= 8) else None)
+        self.register_buffer("mask_packed", pack_decode_masks(self.mask) if (decode_copies and self.mask.shape[0] <= 16) else None)
         # ... and of the base weight in the kernel's tile-major order (one contiguous 4-KiB block per stage; +2 bytes per weight of HBM)
         N, K = self.weight.shape
         tiled = self.mask_packed is not None and self.tile_decode_weight and N % 16 == 0 and K % 128 == 0

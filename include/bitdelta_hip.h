@@ -246,12 +246,12 @@ int bd_set_decode_small_lut(int mode);
 /* A/B hook: 1 = the no-split-k decode kernel always runs its generic one-iteration-ahead loop (default 0: delta-only K = 4096
  * launches use the straight-line instantiation: iterations 0-1 in flight during activation staging, 2-3 issued after the barrier) */
 int bd_set_decode_generic_loop(int on);
-/* Which kernel serves the packed-layout decode launches (bd_binary_linear_decode[_fused] with mask_layout 2) of the calling thread:
- * -1 = the library default, 0 = streaming register-load kernel (gemv_stream_kernel, variant 600), 1 = LDS-DMA loader / consumer
- * kernel (gemv_ring_kernel, variant 700; launches outside its envelope -- K % 128 != 0, K < 512, no base weight -- stay on 600).
- * bd_set_gemm_variant(700) forces the same kernel and answers BD_E_BAD_SHAPE outside the envelope. */
+/* A/B hook, effective only in -DBD_AB_VARIANTS builds (the native harness; the shipped library ignores it and answers BD_E_BAD_SHAPE
+ * to bd_set_gemm_variant(700)): which kernel serves the packed-layout decode launches (mask_layout 2) of the calling thread:
+ * -1 / 0 = streaming register-load kernel (gemv_stream_kernel, variant 600), 1 = LDS-DMA loader / consumer kernel (gemv_ring_kernel,
+ * variant 700, tests/native/ab/bd_gemv_ring.h -- measured 26-45 % slower in round 4, profiles/r04_decode_ring_ab.txt). */
 int bd_set_decode_engine(int engine);
-/* Knobs of variant 700 (-1 = defaults): bit 0 = non-temporal policy on the weight / sign streams, bit 1 = the activation rows ride the
+/* Knobs of variant 700 (harness builds only; -1 = defaults): bit 0 = non-temporal policy on the weight / sign streams, bit 1 = the activation rows ride the
  * ring even when a resident LDS copy would fit, bit 2 = one loader wave instead of two, bit 3 = 4-copy LDS sign table instead of VALU expansion, bit 4 = per-block
  * rotation of the k walk, bits 8..13 = cap on the number of ring slots
  * (0 = as many as fit). */

@@ -37,7 +37,7 @@
 // of the ring holds landed, unconsumed stages.  Every spin is bounded (RING_SPIN_LIMIT polls, then s_trap): a protocol bug aborts
 // the launch instead of hanging the GPU.
 #pragma once
-#include "bd_gemv_stream.h"
+#include "../../../bitdelta_amd/csrc/bd_gemv_stream.h"
 
 namespace bd {
 

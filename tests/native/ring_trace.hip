@@ -2,7 +2,7 @@
 // Development probe: compiles bd_gemv_ring.h directly with -DBD_RING_TRACE (the shipped library carries no trace code).
 //   ring_trace T N K [tune]         fp16, M = 1, tile-major W, random operands (timing only, no checker); tune = bd_set_ring_tuning flags
 #define BD_RING_TRACE
-#include "../../bitdelta_amd/csrc/bd_gemv_ring.h"
+#include "ab/bd_gemv_ring.h"
 
 #include <stdio.h>
 #include <stdlib.h>

@@ -87,6 +87,91 @@ def test_partition_helpers_single_process():
     assert torch.equal(torch.cat([bdd.shard_mask_columns(m, r, 2) for r in range(2)], 1), m)
 
 
+# ------------------------------------------------------------------------------------------------ PartialSumReducer: the transport decision is collective
+def _reducer_worker(rank, world, port, q):
+    """The one-shot (symmetric-memory) path of tp.PartialSumReducer may only be taken when EVERY rank could set it up: a rank that fell
+    back to the ring while its peers sat in the rendezvous would hang the job.  Driven over gloo with the symmetric-memory
+    primitives replaced by stand-ins, so that each failure mode can be injected on ONE rank: (a) nothing fails -> one-shot on all ranks;
+    (b) enable fails on rank 1 -> ring on all ranks; (c) buffer allocation fails on rank 0 -> ring on all ranks for that shape, and the
+    decision is cached; (d) the real class on a gloo group -> ring, no vote needed.  Every call must still return the correct sum."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from bitdelta_amd import dist as bdd
+    from bitdelta_amd import tp
+    bdd.init_from_env(backend="gloo")
+
+    class Fake(tp.PartialSumReducer):
+        fail_enable_on = fail_alloc_on = None
+        rendezvous_calls = 0
+
+        def _capable(self, device):
+            return True
+
+        def _local_enable(self):
+            if self.fail_enable_on == dist.get_rank():
+                raise RuntimeError("no peer access (injected)")
+            self._gname = "fake"
+
+        def _local_alloc(self, y):
+            if self.fail_alloc_on == dist.get_rank():
+                raise RuntimeError("symmetric allocation failed (injected)")
+            return torch.empty_like(y)
+
+        def _rendezvous(self, buf):
+            self.rendezvous_calls += 1
+            dist.barrier()                       # collective, like the real one: would hang if only some ranks got here
+
+        def _one_shot(self, buf):
+            out = buf.clone()
+            dist.all_reduce(out)
+            return out
+
+    want = float(sum(range(1, world + 1)))
+    res = {}
+    y = lambda n=8: torch.full((2, n), float(rank + 1))
+    a = Fake()
+    out = a(y())
+    res["all_ok"] = (bool((out == want).all()), a.calls["one_shot"], a.calls["ring"], a.report()["one_shot_available"])
+    b = Fake()
+    b.fail_enable_on = 1
+    out = b(y())
+    res["enable_fails_on_rank1"] = (bool((out == want).all()), b.calls["one_shot"], b.calls["ring"], b.rendezvous_calls,
+                                    b.report()["ring_reason"] is not None)
+    c = Fake()
+    c.fail_alloc_on = 0
+    o1, o2, o3 = c(y()), c(y()), c(y(16))       # the failed shape stays on the ring (cached); another shape fails the same way
+    res["alloc_fails_on_rank0"] = (bool((o1 == want).all() and (o2 == want).all() and (o3 == want).all()), c.calls["one_shot"], c.calls["ring"],
+                                   c.rendezvous_calls)
+    d = tp.PartialSumReducer()
+    out = d(y())
+    res["real_class_on_gloo"] = (bool((out == want).all()), d.calls["one_shot"], d.calls["ring"], "gloo" in (d.report()["ring_reason"] or ""))
+    big = torch.full((1024, 128), float(rank + 1))                     # > ONE_SHOT_MAX_BYTES: ring whatever the setup says
+    e = Fake()
+    res["large_message"] = (bool((e(big) == want).all()), e.calls["one_shot"], e.calls["ring"])
+    q.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_partial_sum_reducer_transport_decision_is_collective():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, r in res:
+        assert r["all_ok"] == (True, 1, 0, True), (rank, r)
+        assert r["enable_fails_on_rank1"] == (True, 0, 1, 0, True), (rank, r)          # BOTH ranks on the ring, nobody in a rendezvous
+        assert r["alloc_fails_on_rank0"] == (True, 0, 3, 0), (rank, r)
+        assert r["real_class_on_gloo"] == (True, 0, 1, True), (rank, r)
+        assert r["large_message"] == (True, 0, 1), (rank, r)
+
+
 # ------------------------------------------------------------------------------------------------ tensor-parallel Linears through the HIP path
 def _tp_worker(rank, world, port, q):
     """Two ranks share cuda:0 (the GPU box has one device); partial sums come from the HIP kernel (bd_binary_linear on the rank's

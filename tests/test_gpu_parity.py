@@ -230,7 +230,12 @@ LINEAR_SHAPES = [sh for sh in SHAPES if not (sh[5] in (0, 5, 13))] + [(3, 130, 1
                           # 11 = 64x128 tile (up to 64 rows per mask: multi-tenant prefill of short prompts; also under split-k)
                           (6, 64, 512, 640, 6, None), (6, 64, 512, 640, 6, 11), (3, 33, 256, 264, 3, 11), (2, 200, 256, 520, 2, 11),
                           (1, 64, 1024, 384, 1, 10), (4, 17, 192, 136, 4, 11), (6, 64, 4096, 512, 6, None),
-                          (6, 64, 512, 640, 6, 12), (3, 33, 256, 264, 3, 12), (2, 200, 256, 520, 2, 12), (4, 64, 256, 8200, 4, None)]
+                          (6, 64, 512, 640, 6, 12), (3, 33, 256, 264, 3, 12), (2, 200, 256, 520, 2, 12), (4, 64, 256, 8200, 4, None),
+                          # 16 / 17 = pair tiles (two batch entries of <= 64 rows per 128x128 tile; 17 adds split-k): even and odd batches, ragged
+                          # rows per entry, a broadcast mask shared by the pair, a single k-tile per slice, wide N, and the automatic choice
+                          (6, 64, 512, 640, 6, 16), (3, 33, 256, 264, 3, 16), (5, 64, 1024, 384, 5, 16), (2, 17, 192, 136, 2, 16),
+                          (4, 64, 512, 640, 1, 16), (4, 64, 256, 8200, 4, 16), (6, 64, 4096, 512, 6, 17), (3, 33, 2048, 264, 3, 17),
+                          (5, 40, 1024, 1032, 5, 17), (2, 64, 128, 136, 2, 17), (6, 48, 2048, 1024, 6, None), (2, 64, 4096, 256, 2, None)]
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -274,6 +279,24 @@ def test_pruned_ab_variants_are_refused_not_silently_replaced(bd):
                     bd.delta_bmm(dev(a), dev(p))
         finally:
             L.bd_set_gemm_variant(-1)
+    # ... and the round-4 loader / consumer decode kernel (variant 700, tests/native/ab/bd_gemv_ring.h: lost its A/B by 26-45 %) is a
+    # harness-only kernel too: forcing it on a packed decode launch is refused, and bd_set_decode_engine(1) changes nothing
+    from bitdelta_amd.binary_gemm_kernel import binary_linear_decode, pack_decode_masks
+    a, p, w, alpha = rand_problem(6, 1, 1024, 1024, torch.float16, 6, seed=4)
+    pk = pack_decode_masks(dev(p))
+    ref = binary_linear_decode(dev(a), dev(w), pk, dev(alpha), layout="packed")
+    L.bd_set_gemm_variant(700)
+    try:
+        with pytest.raises(_lib.BitDeltaHipError):
+            binary_linear_decode(dev(a), dev(w), pk, dev(alpha), layout="packed")
+    finally:
+        L.bd_set_gemm_variant(-1)
+    L.bd_set_decode_engine(1)
+    try:
+        got = binary_linear_decode(dev(a), dev(w), pk, dev(alpha), layout="packed")
+        assert L.bd_last_gemm_variant() == 600 and torch.equal(got, ref)
+    finally:
+        L.bd_set_decode_engine(-1)
 
 
 def test_decode_in_launch_reduction_matches_two_launch_form(bd):
@@ -623,6 +646,9 @@ DECODE_LAYOUT_SHAPES = [
     # B (tenants), M, K, N, per-tenant masks?
     (6, 1, 1024, 1000, True), (1, 1, 4096, 4096, True), (3, 2, 512, 520, True), (5, 1, 1184, 777, True), (8, 2, 288, 640, True),
     (2, 4, 160, 520, True), (1, 16, 512, 600, True), (4, 1, 2048, 1040, True), (6, 1, 4096, 6144, True), (7, 1, 384, 512, True),
+    # 9 .. 16 tenants in ONE launch (packed layout only, t_pad 12 / 16): the reference's batched benchmark runs B = 16
+    # (notebooks/binary_gemm_kernel_triton.ipynb:759)
+    (12, 1, 1024, 1000, True), (16, 1, 4096, 4096, True), (16, 1, 1184, 520, True), (9, 1, 2048, 1040, True), (11, 1, 512, 640, True),
 ]
 
 
@@ -637,6 +663,7 @@ def test_binary_linear_decode_layouts_vs_oracle(bd, oracle, dtype, shape):
     pd = dev(p)
     tiled = bd.tile_masks(pd)
     packed = bd.pack_decode_masks(pd)
+    assert packed.shape[4] == next(v for v in (1, 2, 4, 6, 8, 12, 16) if v >= B)
     # definition of the tile-major repack
     n = torch.arange(N)
     assert torch.equal(tiled[:, n // 16, :, n % 16].permute(1, 2, 0).cpu(), p)
@@ -647,8 +674,10 @@ def test_binary_linear_decode_layouts_vs_oracle(bd, oracle, dtype, shape):
         for g in range(4):
             assert pk[nn_ // 16, i // 4, g, nn_ % 16, t, i % 4] == pb[t, i, nn_, g]
     base = bd.binary_linear(dev(a), dev(w), pd, dev(alpha), out_dtype=torch.float32)
-    for layout, m in (("tile", tiled), ("packed", packed)):
+    from bitdelta_amd import _lib
+    for layout, m in ((("tile", tiled), ("packed", packed)) if B <= 8 else (("packed", packed),)):
         y32 = bd.binary_linear_decode(dev(a), dev(w), m, dev(alpha), layout=layout, out_dtype=torch.float32)
+        assert _lib.lib().bd_last_gemm_variant() == 600                # one launch of the streaming kernel, also for 9 .. 16 tenants
         fro, mrel = relerr(y32.cpu(), ref32)
         assert fro <= 1e-5 and mrel <= 2e-5, (layout, fro, mrel)
         assert relerr(y32.cpu(), base.cpu())[0] <= 2e-6

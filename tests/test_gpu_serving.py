@@ -139,8 +139,9 @@ def test_binary_linear_residual_epilogue(bd, oracle):
     g = torch.Generator().manual_seed(7)
     # M <= 16: decode kernels; M > 16 with K % 64 == 0: the one-pass fused GEMM's epilogue (64-row, 128-row and 256-row tiles,
     # ragged M / N, bf16-free fp16 here; bf16 below); K % 64 != 0: caller-side add
+    # (6, 64, 4096, 512) and (5, 33, 2048, 264): pair tiles + split-k, the residual is added by the reduce launch
     for B, M, K, N, T in ((6, 1, 1024, 1000, 6), (2, 3, 512, 520, 1), (2, 40, 256, 520, 2), (6, 64, 512, 640, 6), (1, 300, 256, 264, 1),
-                          (1, 130, 128, 136, 1), (1, 600, 1024, 384, 1), (1, 40, 96, 136, 1)):
+                          (1, 130, 128, 136, 1), (1, 600, 1024, 384, 1), (1, 40, 96, 136, 1), (6, 64, 4096, 512, 6), (5, 33, 2048, 264, 5)):
         a = torch.randn(B, M, K, generator=g).half()
         p = torch.randint(-2 ** 31, 2 ** 31 - 1, (T, K // 32, N), generator=g, dtype=torch.int64).to(torch.int32)
         w = (torch.randn(N, K, generator=g) * 0.02).half()
@@ -224,7 +225,10 @@ def test_differentiable_delta_term(bd):
         yq = mod(xq2)
     if kernels:
         assert len(kernels) == 1 and "bd::" in kernels[0], kernels   # one launch, and it is this library's kernel
-    assert type(yq.grad_fn).__name__ == "_RefLinearFnBackward"
+    fn = yq.grad_fn                                  # (the module reshapes the kernel output back to x's leading dims)
+    while fn is not None and "View" in type(fn).__name__:
+        fn = fn.next_functions[0][0]
+    assert type(fn).__name__ == "_RefLinearFnBackward", type(fn).__name__
     # forward values: single rounding of the fused kernel vs the composition's four -- both within bf16 rounding of the fp32 truth
     assert torch.allclose(yq.float(), yr.detach(), rtol=2 ** -7, atol=2e-3) and torch.allclose(yc.float(), yr.detach(), rtol=2 ** -6, atol=4e-3)
 
@@ -617,6 +621,30 @@ def test_serving_loop_single_tenant(bd):
     a, n1 = dec.generate(prompts, max_new_tokens=6, use_graph=True)
     b, n2 = dec.generate(prompts, max_new_tokens=6, use_graph=False)
     assert n1 == n2 == 6 and torch.equal(a, b)
+
+
+def test_serving_loop_twelve_tenants_decode_in_one_launch(bd):
+    """More than 8 tenants per GPU (the reference's batched benchmark runs B = 16): the packed decode layout takes t_pad 12 / 16, so a
+    decode Linear over 12 tenants is ONE launch of the streaming kernel (round 3: chunks through the generic path).  Graph decode, eager
+    decode and the stock-torch glue agree token for token; the Linear itself agrees with per-tenant launches."""
+    from bitdelta_amd import _lib
+    from bitdelta_amd.serving_loop import TenantDecoder
+    T = 12
+    dec = TenantDecoder.synthetic("tiny128", T, "cuda", dtype=torch.float16, seed=11, max_len=160)
+    lay = dec.layers[0]
+    assert lay.qkv.mask_packed is not None and lay.qkv.mask_packed.shape[4] == 12
+    x = torch.randn(T, 1, 512, device="cuda", dtype=torch.float16)
+    y = lay.qkv(x)
+    assert _lib.lib().bd_last_gemm_variant() == 600
+    for t in (0, 7, 11):                                   # tenant t alone: its own mask and scales through the reference-layout path
+        yt = bd.binary_linear(x[t:t + 1], lay.qkv.weight, lay.qkv.mask[t:t + 1], lay.qkv.alpha[t:t + 1], groups=lay.qkv.groups)
+        assert relerr(y[t:t + 1].float(), yt.float()) <= 2e-3
+    prompts = [list(range(1 + t, 30 + 2 * t)) for t in range(T)]
+    a, n1 = dec.generate(prompts, max_new_tokens=5, use_graph=True)
+    b, n2 = dec.generate(prompts, max_new_tokens=5, use_graph=False)
+    dec.fast_glue = False
+    c, _ = dec.generate(prompts, max_new_tokens=5, use_graph=False)
+    assert n1 == n2 == 5 and torch.equal(a, b) and (a == c).float().mean().item() >= 0.9      # (stock glue rounds differently: near-ties may flip)
 
 
 def test_serving_loop_static_state_is_bounded(bd):

@@ -32,14 +32,15 @@ def test_tile_major_layout(T, K, N):
         assert int(t[:, -1, :, N % 16:].abs().sum()) == 0            # padding columns are zero words
 
 
-@pytest.mark.parametrize("T,K,N", [(1, 128, 16), (3, 256, 40), (6, 384, 100), (5, 96, 33), (8, 160, 16), (2, 1024, 64)])
+@pytest.mark.parametrize("T,K,N", [(1, 128, 16), (3, 256, 40), (6, 384, 100), (5, 96, 33), (8, 160, 16), (2, 1024, 64), (9, 160, 33), (12, 256, 40),
+                                   (16, 128, 16)])
 def test_packed_decode_layout(T, K, N):
     """element [tile][it][g][c][t], byte s, bit e  ==  sign bit of k = 128 it + 32 s + 8 g + e of column 16 tile + c, tenant t;
     k past K, columns past N and tenants past T are zero"""
     m = rand_masks(T, K, N, seed=K * 3 + N)
     bits = bits_of(m)                                                # [T, K, N]
     p = pack_decode_masks(m)
-    tp = next(v for v in (1, 2, 4, 6, 8) if v >= T)
+    tp = next(v for v in (1, 2, 4, 6, 8, 12, 16) if v >= T)
     ntile, nit = (N + 15) // 16, (K + 127) // 128
     assert p.shape == (ntile, nit, 4, 16, tp) and p.dtype == torch.int32 and p.is_contiguous()
     by = p.view(torch.uint8).view(ntile, nit, 4, 16, tp, 4)          # little-endian: byte s of the dword

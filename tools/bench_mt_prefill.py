@@ -14,15 +14,15 @@ L = _lib.lib()
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(0)
 shapes = [("q+k+v", 6144, 4096), ("o", 4096, 4096), ("gate+up", 28672, 4096), ("down", 4096, 14336)]
-for M in (32, 64, 128):
+for M in (32, 64, 128) if len(sys.argv) <= 2 else [int(a) for a in sys.argv[2:]]:
     for name, N, K in shapes:
         x = torch.randn(T, M, K, device=dev, generator=g).to(torch.float16)
         w = (torch.randn(N, K, device=dev, generator=g) * 0.02).to(torch.float16)
         mask = torch.randint(-2**31, 2**31 - 1, (T, K // 32, N), device=dev, generator=g, dtype=torch.int64).to(torch.int32)
         alpha = torch.full((T, 1), 4e-4, device=dev)
         row = []
-        for v in (-1, 9, 11, 12, 8):
-            if v in (11, 12) and M > 64:
+        for v in (-1, 9, 11, 12, 16, 17, 10):
+            if v in (11, 12, 16, 17) and M > 64:
                 continue
             L.bd_set_gemm_variant(v)
             try:
