@@ -489,7 +489,7 @@ int launch_gemv_stream_chunk(const Problem& q) {
                 case 1: BD_XR(1, 8); break;
                 case 2: BD_XR(2, 8); break;
                 case 4: BD_XR(4, 8); break;
-                case 6: BD_XR(6, 6); break;
+                case 6: BD_XR(6, 6); break;      // (NS 8 measured equal: 53.2 vs 53.8 us on gate|up, tools/ab_decode_depth.py)
                 case 8: BD_XR(8, 6); break;
                 default: return BD_E_BAD_SHAPE;
             }
@@ -512,7 +512,7 @@ int launch_gemv_stream_chunk(const Problem& q) {
             case 1: BD_PK(1, 8); break;
             case 2: BD_PK(2, 6); break;
             case 4: BD_PK(4, 4); break;
-            case 6: BD_PK(6, 4); break;
+            case 6: BD_PK(6, 4); break;      // (NS 6 with nt weight loads measured 5-14 % slower: tools/ab_decode_depth.py)
             case 8: BD_PK(8, 4); break;
             // 9 .. 16 tenants in ONE launch (the reference publishes B = 16: notebooks/binary_gemm_kernel_triton.ipynb:759): plain and SwiGLU
             // launches; the fused-norm / resident-row forms end at 8 rows of K = 4096 anyway

@@ -198,15 +198,19 @@ class TenantDecoder(nn.Module):
         self.swiglu_epilogue = False  # prefill: SwiGLU inside the gate|up GEMM (256-row tiles only; measured slower than GEMM + one pass)
         self.hip_prefill_attention = True      # prefill: RoPE + flash-style attention kernels instead of torch SDPA over a [L, Lc] mask
         self.fuse_glue = True       # ... and fold RMSNorm / SwiGLU into the Linear launches where the shapes allow (bit-identical)
-        # Which glue is folded where, by same-process A/B of the whole step (profiles/r02_decode_step.txt; ms per step, Mistral-7B x 6,
-        # tile-major weights): separate launches 5.35 | SwiGLU in gate|up's epilogue 5.11 | + RMSNorm in gate|up's prologue 5.17 |
-        # + RMSNorm in q|k|v's prologue 5.28.  The epilogue is free; a norm prologue makes 256 blocks each re-read and re-normalise
-        # all rows (~6 us in front of the launch) to save a 4.4 us kernel -- at best a wash on the long launch, a loss on the short one.
+        # Which glue is folded where, by same-process A/B of the whole step (ms per step, Mistral-7B x 6, tile-major weights).  Round 2
+        # (profiles/r02_decode_step.txt): separate launches 5.35 | SwiGLU in gate|up's epilogue 5.11 | + RMSNorm in gate|up's prologue
+        # 5.17 | + RMSNorm in q|k|v's prologue 5.28.  Round 4, nt weight loads (profiles/r04_decode_step_ab.txt): 5.28 | 5.02 | 4.94 | 5.05.
+        # The epilogue is free; a norm prologue makes 256 blocks each re-read and re-normalise all rows (~6 us in front of the launch)
+        # to save a 4.4 us kernel: it pays on the long gate|up launch, not on the short q|k|v one.
         self._static = {}               # (stop-table width, glue switches) -> static request state + captured decode-step graph (LRU)
         self._kv_cache = None           # ONE KV cache per decoder, shared by every slot
         self._capture_stream = None
         self.fuse_qkv_norm = False      # RMSNorm folded into the q|k|v launch
-        self.fuse_gateup_norm = False   # RMSNorm folded into the gate|up launch (SwiGLU stays in its epilogue either way)
+        # RMSNorm folded into the gate|up launch (SwiGLU stays in its epilogue either way).  Round 2 measured this a small loss (5.17 vs
+        # 5.11 ms); with the non-temporal weight loads of round 4 the norm form -- whose activation rows are resident in LDS, i.e. no
+        # per-stage activation loads -- wins: 4.94 vs 5.02 ms per step, same process (profiles/r04_decode_step_ab.txt)
+        self.fuse_gateup_norm = True
         # (round 2 also shipped a persistent per-layer chain launch, bd_decode_chain: bit-identical but 5.91 vs 5.33 ms per step in every
         # same-process A/B, so it was removed from the library in round 3 -- profiles/r02_decode_chain_*.txt keep the measurements)
 
