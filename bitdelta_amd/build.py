@@ -47,13 +47,14 @@ def build(force=False, verbose=True):
             print(f"bitdelta_amd.build: {OUT} is up to date (source hash matches)", file=sys.stderr)
         return OUT, False
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    stamp = source_hash()                # of what the compiler is about to read (an edit during the build must not be stamped as built)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc] + FLAGS + ["-o", OUT, SRC]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
     with open(STAMP, "w") as fh:
-        fh.write(source_hash() + "\n")
+        fh.write(stamp + "\n")
     if verbose:
         print(f"bitdelta_amd.build: compiled {OUT}", file=sys.stderr)
     return OUT, True

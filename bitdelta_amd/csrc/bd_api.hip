@@ -465,8 +465,7 @@ int launch_gemv_stream_chunk(const Problem& q) {
             }
             if (g_forced_variant == 700) return BD_E_BAD_SHAPE;
         }
-        // kernel kinds: plain | RMSNorm prologue (XL) | XL + SwiGLU epilogue | SwiGLU epilogue only; tile-major W (WT) for the three
-        // the serving loop uses (a norm prologue without SwiGLU on tile-major W answers BD_E_BAD_SHAPE)
+        // kernel kinds: plain | RMSNorm prologue (XL) | XL + SwiGLU epilogue | SwiGLU epilogue only; each with row-major or tile-major W (WT)
 #else
         if (g_forced_variant == 700) return BD_E_BAD_SHAPE;      // harness-only kernel (round 4 A/B loser): never silently replaced
 #endif
@@ -498,7 +497,7 @@ int launch_gemv_stream_chunk(const Problem& q) {
             return launch_status();
         }
 #define BD_PKW(NM, NS4, AX) (q.norm_w ? (q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS4, 4, 1, AX, 1, 1, 1, 1>(sp, dim3(grid), q.st)   \
-                                                         : BD_E_BAD_SHAPE)                                                                \
+                                                         : launch_stream_inst<DT, NM, true, NS4, 4, 1, AX, 1, 1, 0, 1>(sp, dim3(grid), q.st)) \
                                       : q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS4, 4, 1, AX, 1, 0, 1, 1>(sp, dim3(grid), q.st)   \
                                                         : launch_stream_inst<DT, NM, true, NS4, 4, 1, AX, 1, 0, 0, 1>(sp, dim3(grid), q.st))
 #define BD_PK(NM, NS4) rc = q.w_tiled                                                                                                   \

@@ -127,8 +127,9 @@ class FusedDeltaLinear(nn.Module):
             w, wt = self._dec_weight(x)
             return binary_linear_decode(x, w, self.mask_packed, self.alpha_pair, layout="packed", groups=2,
                                         norm_weight=norm_weight, eps=eps, swiglu=True, weight_tiled=wt)
-        return binary_linear_decode(x, self.weight, self.mask_packed, self.alpha, layout="packed", groups=self.groups,
-                                    norm_weight=norm_weight, eps=eps)
+        w, wt = self._dec_weight(x)
+        return binary_linear_decode(x, w, self.mask_packed, self.alpha, layout="packed", groups=self.groups,
+                                    norm_weight=norm_weight, eps=eps, weight_tiled=wt)
 
     def swiglu_ok(self, x):
         """True when forward_swiglu can take this input: an interleaved gate|up pair at prefill size on the fused GEMM's fast path"""

@@ -675,7 +675,7 @@ def test_serving_loop_static_state_is_bounded(bd):
 @pytest.mark.parametrize("T,K,N", [(6, 4096, 6144), (1, 4096, 4096), (2, 1024, 1024), (4, 14336, 4096), (8, 2048, 512), (3, 128, 528)])
 def test_tile_major_weight_is_bit_identical(bd, dtype, T, K, N):
     """the tile-major decode copy of the base weight (ldw = 0 at the C ABI) gives the same bits as the row-major operand: plain,
-    with the residual epilogue, with the SwiGLU epilogue and with RMSNorm + SwiGLU"""
+    with the residual epilogue, with the SwiGLU epilogue, with RMSNorm + SwiGLU and with the RMSNorm prologue alone"""
     from bitdelta_amd import serving_ops as ops
     from bitdelta_amd.binary_gemm_kernel import binary_linear_decode, fused_norm_ok, pack_decode_masks, tile_weight
     g = torch.Generator(device="cuda").manual_seed(K + N + T)
@@ -697,6 +697,10 @@ def test_tile_major_weight_is_bit_identical(bd, dtype, T, K, N):
         nw = (1 + 0.1 * torch.randn(T, K, device="cuda", generator=g)).to(dtype)
         assert torch.equal(binary_linear_decode(x, wt, pk, alpha, layout="packed", groups=2, swiglu=True, norm_weight=nw, weight_tiled=True),
                            binary_linear_decode(x, w, pk, alpha, layout="packed", groups=2, swiglu=True, norm_weight=nw))
+        # RMSNorm prologue alone (the q|k|v launch of a decoder layer): tile-major == row-major == separate norm launch + Linear
+        y_t = binary_linear_decode(x, wt, pk, a1, layout="packed", norm_weight=nw, weight_tiled=True)
+        assert torch.equal(y_t, binary_linear_decode(x, w, pk, a1, layout="packed", norm_weight=nw))
+        assert torch.equal(y_t, binary_linear_decode(ops.rmsnorm_tenant(x, nw, 1e-5), wt, pk, a1, layout="packed", weight_tiled=True))
 
 
 # ---------------------------------------------------------------------------------------------------- prefill attention (caller glue)
