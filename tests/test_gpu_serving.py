@@ -500,6 +500,29 @@ def test_decode_glue_kernels_vs_torch_ops(bd):
             assert torch.equal(kc, kr) and torch.equal(vc, vr) and torch.equal(valid, vm)     # cache append is bit-exact
 
 
+def test_decode_attention_split_merge_is_deterministic(bd):
+    """The in-launch merge of the key-range splits hands partial (acc, max, sum) triples from four blocks to the block that arrives last,
+    through agent-scope stores / a ticket / agent-scope loads (csrc/bd_serving.h).  A visibility race in that hand-over would show up as
+    run-to-run differences: 3000 launches on the decode step's geometry (6 tenants, 32 / 8 heads, 512 keys) must all be bit-identical."""
+    from bitdelta_amd import serving_ops as ops
+    from bitdelta_amd.serving_loop import _rope_tables
+    torch.manual_seed(5)
+    dev, dtype, T, heads, kvh, hd, Lc, pos = "cuda", torch.float16, 6, 32, 8, 128, 576, 512
+    cos, sin = _rope_tables(Lc, hd, dev, dtype)
+    kc = torch.randn(T, kvh, Lc, hd, device=dev).to(dtype)
+    vc = torch.randn(T, kvh, Lc, hd, device=dev).to(dtype)
+    valid = torch.zeros(T, Lc, dtype=torch.bool, device=dev)
+    valid[:, :pos] = True
+    qkv = torch.randn(T, 1, (heads + 2 * kvh) * hd, device=dev).to(dtype)
+    pidx = torch.tensor([pos], device=dev)
+    first = ops.decode_attention(qkv, cos, sin, kc, vc, valid, pidx, heads, kvh).clone()
+    bad = torch.zeros((), dtype=torch.int64, device=dev)
+    for _ in range(3000):
+        got = ops.decode_attention(qkv, cos, sin, kc, vc, valid, pidx, heads, kvh)
+        bad += (got != first).sum()
+    assert int(bad) == 0
+
+
 def test_serving_loop_fast_glue_matches_torch_glue(bd):
     """head_dim-128 decoder: greedy decode with the HIP glue kernels (and graph replay) == the same loop on stock torch ops"""
     from bitdelta_amd.serving_loop import TenantDecoder
