@@ -445,7 +445,8 @@ def run_mt_decode(dev, timer, model_name, tenants, kv_len, steps, warmup, layers
         from bitdelta_amd import _lib as _bl
         L = _bl.lib()
         nt_runs = {}
-        for name, flag in (("weight_nt_on_ms", 16), ("weight_nt_off_ms", 32)):
+        # ... and the residual of the o / down launches fetched at kernel start (default) vs in the epilogue (1024)
+        for name, flag in (("weight_nt_on_ms", 16), ("weight_nt_off_ms", 32), ("residual_prefetch_on_ms", 0), ("residual_prefetch_off_ms", 1024)):
             L.bd_set_stream_tuning(flag)
             restore()
             nt_runs[name] = dec._graph_runner(st)

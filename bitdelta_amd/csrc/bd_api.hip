@@ -406,7 +406,7 @@ int launch_ring_inst(const RingParams& rp, unsigned grid, hipStream_t st) {
 
 template <int DT>
 int launch_gemv_stream_chunk(const Problem& q) {
-    StreamParams sp;
+    StreamParams sp{};
     GemvParams& gp = sp.g;
     gp.X = (const unsigned short*)q.A;
     gp.P = (const uint32_t*)q.P;
@@ -432,6 +432,7 @@ int launch_gemv_stream_chunk(const Problem& q) {
     sp.prs = q.mask_tiled == 1 ? 16u : (uint32_t)q.N;
     sp.tp = (uint32_t)q.t_pad;
     sp.nw = (const unsigned short*)q.norm_w; sp.sNw = q.sNw; sp.eps = q.eps;
+    sp.no_res_prefetch = (g_stream_tune & 1024) ? 1 : 0;
     sp.n_bytes = q.norm_w ? (uint32_t)(((int64_t)(q.B - 1) * q.sNw + q.K) * 2) : 0u;
     sp.xs_off = (uint32_t)STREAM_XS_OFF; sp.xrow = (uint32_t)q.K * 2u + 16u;
     sp.jsh = 0;

@@ -61,6 +61,16 @@ template <int DT> __device__ __forceinline__ void store_out(const GemvParams& p,
     else ((unsigned short*)p.C)[off] = (unsigned short)f32_to_half_bits<DT>(v);
 }
 
+// the same store with the residual value (what `accumulate` would read from C) already in a register: the streaming kernel fetches it at
+// kernel start -- a load issued in the epilogue is a full memory round trip with nothing left to hide it
+template <int DT> __device__ __forceinline__ void store_out_residual(const GemvParams& p, int r, int n, float v, float cin) {
+    const int b = r / p.M, m = r - b * p.M;
+    const long long off = (long long)b * p.sCb + (long long)m * p.sCm + n;
+    v += cin;
+    if (p.out_f32) ((float*)p.C)[off] = v;
+    else ((unsigned short*)p.C)[off] = (unsigned short)f32_to_half_bits<DT>(v);
+}
+
 // In-launch split-k reduction.  Every block has stored its fp32 partial tile to ws[ks][r][n]; the block that arrives LAST at the
 // tile's ticket sums the KS partials in k-slice order (so the result does not depend on which block that is), rounds once, stores,
 // and puts the ticket back to 0 for the next launch.

@@ -85,6 +85,7 @@ struct StreamParams {
     uint32_t n_bytes, xs_off, xrow;
     int jsh;                 // K = 2048 << jsh
     float eps;
+    int no_res_prefetch;     // A/B switch (bd_set_stream_tuning bit 10): 1 = the residual is read in the epilogue, as before round 4
 };
 
 // NW = waves per block (8: two per SIMD, 256 VGPRs each; 4: one per SIMD, the whole register file, deeper prefetch).
@@ -175,6 +176,25 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
     if (al_lds) {
         const int idx = min((int)threadIdx.x, p.R * ng - 1), r = idx / ng, j = idx - r * ng;
         a_pre = p.alpha[(long long)(r / p.M) * p.sAlb + g0 + j];
+    }
+
+    // Residual epilogue (`accumulate`: o / down of a decoder layer add onto the residual stream): the values this lane will add in the
+    // FIRST tile its wave reduces (tile = wave index) are fetched now, for the same reason -- in the epilogue the load would be a full,
+    // exposed memory round trip (the residual was written by the previous launch, usually from another XCD) and the youngest entry of
+    // the queue.  Later tiles of the same wave (wide residual launches) fall back to the load in store_out.
+    // (Not in the norm-prologue form: no caller adds a residual there, and that form's instantiations stay the code the round-3/4 test
+    // matrix has run against.)
+    constexpr bool CPRE = EPI == 0 && XL != 1;
+    [[maybe_unused]] uint32_t c_pre[4] = {0u, 0u, 0u, 0u};               // raw bits: converted where they are used, so nothing waits here
+    const bool c_pre_ok = CPRE && p.accumulate && wave < ntile && !sp.no_res_prefetch;
+    if (CPRE && c_pre_ok && li < p.R) {
+        const int b = li / p.M, m = li - b * p.M;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = min(c_lo + wave * 16 + 4 * g + e, p.N - 1);
+            const long long off = (long long)b * p.sCb + (long long)m * p.sCm + n;
+            c_pre[e] = p.out_f32 ? ((const uint32_t*)p.C)[off] : (uint32_t)((const unsigned short*)p.C)[off];
+        }
     }
 
     // XL: the R raw rows (and their norm weights) are the OLDEST loads of the wave -- like the scales above, consuming them never
@@ -430,7 +450,14 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
                         float a = 1.f;
                         if (al_lds) a = a_lds[li * ng + (n / p.gsz - g0)];
                         else if (p.alpha) a = p.alpha[(long long)b * p.sAlb + n / p.gsz];
-                        store_out<DT>(p, li, n, scale_then_add(sd[e], a, HASW ? sb[e] : 0.f));
+                        const float val = scale_then_add(sd[e], a, HASW ? sb[e] : 0.f);
+                        if constexpr (CPRE) {
+                            if (c_pre_ok && tile == wave)
+                                store_out_residual<DT>(p, li, n, val, p.out_f32 ? __builtin_bit_cast(float, c_pre[e]) : half_bits_to_f32<DT>(c_pre[e]));
+                            else store_out<DT>(p, li, n, val);
+                        } else {
+                            store_out<DT>(p, li, n, val);
+                        }
                     }
                 }
             }
