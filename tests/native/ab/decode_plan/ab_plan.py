@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--rotate", action="store_true", help="plan leg: one buffer per (layer, phase output) instead of in-place reuse")
     ap.add_argument("--plain", action="store_true", help="plan leg: plain (L2-cached) reads of earlier phases' outputs; implies --rotate")
     ap.add_argument("--barriers", type=int, default=0, help="also time a plan of N empty phases (the device-wide barrier alone)")
+    ap.add_argument("--pair", action="store_true", help="third leg: only [attention -> o] of every layer as a 2-phase plan, the rest as launches")
     ap.add_argument("--dtype", default="float16")
     a = ap.parse_args()
     a.rotate = a.rotate or a.plain
@@ -200,6 +201,59 @@ def main():
     plan.check_status()
     print(json.dumps({"check": "launch after the replays, new input", "x": torch.equal(x_sep_c, x_out),
                       "x_mismatches": int((x_sep_c != x_out).sum())}), flush=True)
+    if a.pair and not a.linear_only:
+        # [attention -> o + residual] as a 2-phase plan per layer (the o projection's weight prologue lands while the attention phase runs);
+        # q|k|v, gate|up, down stay launches, written into static buffers through the C ABI
+        from bitdelta_amd._lib import DTYPE_CODE, check, ptr, stream_ptr
+        L = lib()
+        dt = DTYPE_CODE[dtype]
+
+        def launch_into(x, fl, y, alpha, groups, accumulate=False, norm=None, swiglu=False):
+            N, K = fl.weight.shape
+            if norm is not None or swiglu:
+                check(L.bd_binary_linear_decode_fused(ptr(x), ptr(fl.weight_tiled), ptr(fl.mask_packed), fl.mask_packed.shape[4], ptr(alpha), ptr(y),
+                                                      T, 1, N, K, x.stride(0), x.stride(1), 0, 1, groups, groups, y.stride(0), y.stride(1), dt, dt,
+                                                      1 if accumulate else 0, ptr(norm), norm.stride(0) if norm is not None else 0, float(eps),
+                                                      1 if swiglu else 0, stream_ptr()), "decode_fused")
+            else:
+                check(L.bd_binary_linear_decode(ptr(x), ptr(fl.weight_tiled), ptr(fl.mask_packed), 2, fl.mask_packed.shape[4], ptr(alpha), ptr(y),
+                                                T, 1, N, K, x.stride(0), x.stride(1), 0, 1, groups, groups, y.stride(0), y.stride(1), dt, dt,
+                                                1 if accumulate else 0, stream_ptr()), "decode")
+
+        s4 = fresh_state()
+        mk = lambda n: torch.empty(T, 1, n, device=dev, dtype=dtype)
+        qkv_b, att_b, act_b = mk((heads + 2 * kvh) * hd), mk(heads * hd), mk(inter)
+        need = lib().bd_srv_decode_attention_workspace_bytes(T, heads, kvh, hd, Lc)
+        ws4 = torch.zeros(max(int(need), 16), dtype=torch.uint8, device=dev)
+        t_pad = dec.layers[0].qkv.mask_packed.shape[4]
+        pair_plans = []
+        for li, layer in enumerate(dec.layers):
+            pp = DecodePlan(dev, dtype, t_pad)
+            pp.attention(qkv_b, dec.cos, dec.sin, s4["k"][li], s4["v"][li], s4["valid"], pos, att_b, heads, kvh, ws4)
+            pp.linear(att_b, layer.o.weight_tiled, layer.o.mask_packed, layer.o.alpha, s4["x"], groups=layer.o.groups, accumulate=True)
+            pair_plans.append(pp.finalize())
+
+        def pair_fn():
+            x = s4["x"]
+            for li, layer in enumerate(dec.layers):
+                launch_into(x, layer.qkv, qkv_b, layer.qkv.alpha, layer.qkv.groups, norm=layer.norm1)
+                pair_plans[li].launch()
+                launch_into(x, layer.gate_up, act_b, layer.gate_up.alpha_pair, 2, norm=layer.norm2, swiglu=True)
+                launch_into(act_b, layer.down, x, layer.down.alpha, layer.down.groups, accumulate=True)
+
+        pair_fn()
+        torch.cuda.synchronize()
+        for pp in pair_plans:
+            pp.check_status()
+        s1p = fresh_state(); s1p["att"] = att_fixed
+        x_ref = step_sep(s1p).clone()
+        print(json.dumps({"check": "pair plans == separate launches", "x": torch.equal(x_ref, s4["x"]),
+                          "x_mismatches": int((x_ref != s4["x"]).sum())}), flush=True)
+        us_pair = bench(pair_fn, a.iters)
+        for pp in pair_plans:
+            pp.check_status()
+        print(json.dumps({"leg": "[attention -> o] as a 2-phase plan per layer, other launches separate", "us_per_step": round(us_pair, 2),
+                          "us_per_layer": round(us_pair / a.layers, 2), "vs_separate": round(us_pair / us_sep, 4)}), flush=True)
     if a.barriers > 0:
         bp = DecodePlan(dev, dtype, dec.layers[0].qkv.mask_packed.shape[4])
         for _ in range(a.barriers):
