@@ -476,10 +476,11 @@ int launch_gemv_stream_chunk(const Problem& q) {
         // bit 7 = off): plain and SwiGLU launches inside the fused-norm envelope (M = 1, K = 2048 * 2^s, R * K <= 32768)
         const bool xres_ok = q.w_tiled && !q.norm_w && q.M == 1 && q.K >= 2048 && !(q.K & (q.K - 1)) && (int64_t)q.B * q.K <= 16 * 2048 &&
                              (int64_t)STREAM_XS_OFF + (int64_t)q.B * (2 * (int64_t)q.K + 16) <= STREAM_LDS_MAX;
-        // Default rule from the same-process A/B (profiles/r04_decode_ring_ab.txt): the copy costs ~3 us in front of the launch, so it pays
-        // where the per-stage activation loads are a large share of the load instructions (one or two rows: -7..-10 % on every K = 4096
-        // launch of the single-delta Llama-2-7B decode) or the launch is long (6 tenants: gate|up -3.5 %, but o +25 %, q|k|v +4 %)
-        const bool xres_auto = STREAM_XRES_DEFAULT != 0 && (q.B * q.M <= 2 || (int64_t)q.N * q.K >= (64ll << 20));
+        // Default rule from the same-process A/Bs (profiles/r04_decode_ring_ab.txt, r04_decode_step_ab.txt): it pays where the per-stage
+        // activation loads are a large share of the load instructions (one or two rows: -7..-10 % on every K = 4096 launch of the
+        // single-delta Llama-2-7B decode) or the launch is not short (6 tenants at 4 stages: q|k|v 20.3 -> 19.0 us, gate|up 52.1 -> 51.1;
+        // the 4096 x 4096 o projection stays on the plain form)
+        const bool xres_auto = STREAM_XRES_DEFAULT != 0 && (q.B * q.M <= 2 || (int64_t)q.N * q.K >= (20ll << 20));
         const bool xres = xres_ok && ((g_stream_tune & 64) ? true : (g_stream_tune & 128) ? false : xres_auto);
         if (xres) {
 #define BD_XR(NM, NS8) rc = q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS8, 4, 1, 2, 1, 2, 1, 1>(sp, dim3(grid), q.st)   \
@@ -489,8 +490,10 @@ int launch_gemv_stream_chunk(const Problem& q) {
                 case 1: BD_XR(1, 8); break;
                 case 2: BD_XR(2, 8); break;
                 case 4: BD_XR(4, 8); break;
-                case 6: BD_XR(6, 6); break;      // (NS 8 measured equal: 53.2 vs 53.8 us on gate|up, tools/ab_decode_depth.py)
-                case 8: BD_XR(8, 6); break;
+                // 6 / 8 tenants: 4 stages, like the plain form -- NS 6 measured 3-12 % slower per launch (gate|up 54.2 vs 51.1 us, q|k|v 21.5 vs
+                // 19.0) and +2 % on the step; the win of this form is the shorter load queue (6 instead of 10 loads per stage), not depth
+                case 6: BD_XR(6, 4); break;
+                case 8: BD_XR(8, 4); break;
                 default: return BD_E_BAD_SHAPE;
             }
 #undef BD_XR
