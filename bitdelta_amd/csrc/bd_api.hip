@@ -486,34 +486,40 @@ int launch_gemv_stream_chunk(const Problem& q) {
 #define BD_XR(NM, NS8) rc = q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS8, 4, 1, 2, 1, 2, 1, 1>(sp, dim3(grid), q.st)   \
                                             : launch_stream_inst<DT, NM, true, NS8, 4, 1, 2, 1, 2, 0, 1>(sp, dim3(grid), q.st)
             switch (q.t_pad) {
-                // prefetch depth: the 16 activation-row loads of the prologue + NS stages of (4 W + sign) loads stay under the 63-entry vmcnt
-                case 1: BD_XR(1, 8); break;
-                case 2: BD_XR(2, 8); break;
-                case 4: BD_XR(4, 8); break;
-                // 6 / 8 tenants: 4 stages, like the plain form -- NS 6 measured 3-12 % slower per launch (gate|up 54.2 vs 51.1 us, q|k|v 21.5 vs
-                // 19.0) and +2 % on the step; the win of this form is the shorter load queue (6 instead of 10 loads per stage), not depth
-                case 6: BD_XR(6, 4); break;
-                case 8: BD_XR(8, 4); break;
+                // Prefetch depth: TWO stages.  Same-process A/Bs of the whole step late in round 4 (profiles/r04_decode_step_ab.txt): 8 -> 6 -> 4
+                // -> 2 stages each made the step faster (1 tenant: 3.57 -> 3.32 ms over the whole sequence of changes; 6 tenants: -0.3 %
+                // for this form alone) -- the memory system is saturated by far fewer loads in flight than the register file can hold, and
+                // beyond that point a deeper queue only adds latency (returns are in issue order).  (The parity of NS selects the
+                // activation fragment set, so 2 is the minimum.)
+                case 1: BD_XR(1, 2); break;
+                case 2: BD_XR(2, 2); break;
+                case 4: BD_XR(4, 2); break;
+                case 6: BD_XR(6, 2); break;
+                case 8: BD_XR(8, 2); break;
                 default: return BD_E_BAD_SHAPE;
             }
 #undef BD_XR
             if (rc != BD_OK) return rc;
             return launch_status();
         }
-#define BD_PKW(NM, NS4, AX) (q.norm_w ? (q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS4, 4, 1, AX, 1, 1, 1, 1>(sp, dim3(grid), q.st)   \
-                                                         : launch_stream_inst<DT, NM, true, NS4, 4, 1, AX, 1, 1, 0, 1>(sp, dim3(grid), q.st)) \
+// (tile-major weight: the norm-prologue forms run 2 stages deep -- 6 tenants: gate|up with its norm at 2 instead of 4 stages is -1 % on
+//  the whole step; the plain / SwiGLU-only forms NS4 stages)
+#define BD_PKW(NM, NS4, AX) (q.norm_w ? (q.epilogue == 1 ? launch_stream_inst<DT, NM, true, 2, 4, 1, AX, 1, 1, 1, 1>(sp, dim3(grid), q.st)   \
+                                                         : launch_stream_inst<DT, NM, true, 2, 4, 1, AX, 1, 1, 0, 1>(sp, dim3(grid), q.st)) \
                                       : q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS4, 4, 1, AX, 1, 0, 1, 1>(sp, dim3(grid), q.st)   \
                                                         : launch_stream_inst<DT, NM, true, NS4, 4, 1, AX, 1, 0, 0, 1>(sp, dim3(grid), q.st))
 #define BD_PK(NM, NS4) rc = q.w_tiled                                                                                                   \
                      ? (wnt ? BD_PKW(NM, NS4, 2) : BD_PKW(NM, NS4, 0))                                                                  \
-                     : q.norm_w ? (q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1, 1, 1>(sp, dim3(grid), q.st)   \
-                                                        : launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1, 1, 0>(sp, dim3(grid), q.st))  \
+                     : q.norm_w ? (q.epilogue == 1 ? launch_stream_inst<DT, NM, true, 2, 4, 1, 0, 1, 1, 1>(sp, dim3(grid), q.st)   \
+                                                        : launch_stream_inst<DT, NM, true, 2, 4, 1, 0, 1, 1, 0>(sp, dim3(grid), q.st))  \
                      : q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1, 0, 1>(sp, dim3(grid), q.st)            \
                      : q.W ? launch_stream_inst<DT, NM, true, NS4, 4, 1, 0, 1>(sp, dim3(grid), q.st)                              \
                            : launch_stream_inst<DT, NM, false, NS4, 4, 1, 0, 1>(sp, dim3(grid), q.st)
         switch (q.t_pad) {
-            case 1: BD_PK(1, 8); break;
-            case 2: BD_PK(2, 6); break;
+            // depth of the plain / SwiGLU-only forms: 1 tenant 3 stages (8 until late in round 4: -6 % on the single-delta step over 8 -> 6 -> 4
+            // -> 3), 2 tenants 4 (6: +3 %), 4 and more 4 (3 measured +0.6 % at 6 tenants)
+            case 1: BD_PK(1, 3); break;
+            case 2: BD_PK(2, 4); break;
             case 4: BD_PK(4, 4); break;
             case 6: BD_PK(6, 4); break;      // (NS 6 with nt weight loads measured 5-14 % slower: tools/ab_decode_depth.py)
             case 8: BD_PK(8, 4); break;
