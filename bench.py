@@ -446,11 +446,21 @@ def run_mt_decode(dev, timer, model_name, tenants, kv_len, steps, warmup, layers
         L = _bl.lib()
         nt_runs = {}
         # ... and the residual of the o / down launches fetched at kernel start (default) vs in the epilogue (1024)
-        for name, flag in (("weight_nt_on_ms", 16), ("weight_nt_off_ms", 32), ("residual_prefetch_on_ms", 0), ("residual_prefetch_off_ms", 1024)):
+        for name, flag in (("weight_nt_on_ms", 16), ("weight_nt_off_ms", 32), ("residual_prefetch_on_ms", 0), ("residual_prefetch_off_ms", 1024),
+                           ("resident_rows_everywhere_ms", 64), ("resident_rows_nowhere_ms", 128)):
             L.bd_set_stream_tuning(flag)
             restore()
             nt_runs[name] = dec._graph_runner(st)
             ab[name] = []
+        # ... and the two together: resident rows on every eligible launch with gate|up's norm fused / as its own launch
+        keep2 = (dec.fuse_glue, dec.fuse_qkv_norm, dec.fuse_gateup_norm)
+        for name, gn in (("resident_everywhere_gateup_norm_fused_ms", True), ("resident_everywhere_gateup_norm_separate_ms", False)):
+            dec.fuse_glue, dec.fuse_qkv_norm, dec.fuse_gateup_norm = True, False, gn
+            L.bd_set_stream_tuning(64)
+            restore()
+            nt_runs[name] = dec._graph_runner(st)
+            ab[name] = []
+        dec.fuse_glue, dec.fuse_qkv_norm, dec.fuse_gateup_norm = keep2
         L.bd_set_stream_tuning(0)
         for _ in range(3):
             for name, run in nt_runs.items():

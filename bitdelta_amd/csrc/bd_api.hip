@@ -476,11 +476,10 @@ int launch_gemv_stream_chunk(const Problem& q) {
         // bit 7 = off): plain and SwiGLU launches inside the fused-norm envelope (M = 1, K = 2048 * 2^s, R * K <= 32768)
         const bool xres_ok = q.w_tiled && !q.norm_w && q.M == 1 && q.K >= 2048 && !(q.K & (q.K - 1)) && (int64_t)q.B * q.K <= 16 * 2048 &&
                              (int64_t)STREAM_XS_OFF + (int64_t)q.B * (2 * (int64_t)q.K + 16) <= STREAM_LDS_MAX;
-        // Default rule from the same-process A/Bs (profiles/r04_decode_ring_ab.txt, r04_decode_step_ab.txt): it pays where the per-stage
-        // activation loads are a large share of the load instructions (one or two rows: -7..-10 % on every K = 4096 launch of the
-        // single-delta Llama-2-7B decode) or the launch is not short (6 tenants at 4 stages: q|k|v 20.3 -> 19.0 us, gate|up 52.1 -> 51.1;
-        // the 4096 x 4096 o projection stays on the plain form)
-        const bool xres_auto = STREAM_XRES_DEFAULT != 0 && (q.B * q.M <= 2 || (int64_t)q.N * q.K >= (20ll << 20));
+        // Default: wherever it applies.  (Until the prefetch depths came down to 2 stages this form lost on short launches -- at 6 stages the
+        // 4096 x 4096 o projection of a 6-tenant step was +25 % -- and was dispatched by size; at 2 stages it wins on every eligible launch:
+        // 6 tenants 4.805 -> 4.770 ms per step with o included, profiles/r04_decode_step_ab.txt.)
+        const bool xres_auto = STREAM_XRES_DEFAULT != 0;
         const bool xres = xres_ok && ((g_stream_tune & 64) ? true : (g_stream_tune & 128) ? false : xres_auto);
         if (xres) {
 #define BD_XR(NM, NS8) rc = q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS8, 4, 1, 2, 1, 2, 1, 1>(sp, dim3(grid), q.st)   \

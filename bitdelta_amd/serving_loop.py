@@ -208,10 +208,12 @@ class TenantDecoder(nn.Module):
         self._kv_cache = None           # ONE KV cache per decoder, shared by every slot
         self._capture_stream = None
         self.fuse_qkv_norm = False      # RMSNorm folded into the q|k|v launch
-        # RMSNorm folded into the gate|up launch (SwiGLU stays in its epilogue either way).  Round 2 measured this a small loss (5.17 vs
-        # 5.11 ms); with the non-temporal weight loads of round 4 the norm form -- whose activation rows are resident in LDS, i.e. no
-        # per-stage activation loads -- wins: 4.94 vs 5.02 ms per step, same process (profiles/r04_decode_step_ab.txt)
-        self.fuse_gateup_norm = True
+        # RMSNorm folded into the gate|up launch (SwiGLU stays in its epilogue either way): every block re-normalises all rows (rows + norm
+        # weights from L2) to save one ~4.5 us launch.  Same-process A/Bs at the end of round 4, with the resident-row form (which needs no
+        # norm) at 2 stages on every eligible launch: 1 tenant 3.353 fused vs 3.386 ms separate, 2 tenants 3.790 vs 3.823, 4 tenants 4.244
+        # vs 4.226, 6 tenants 4.771 vs 4.700 -- the prologue's cost grows with the rows, the saved launch does not
+        # (profiles/r04_decode_step_ab.txt).
+        self.fuse_gateup_norm = tenants <= 3
         # (round 2 also shipped a persistent per-layer chain launch, bd_decode_chain: bit-identical but 5.91 vs 5.33 ms per step in every
         # same-process A/B, so it was removed from the library in round 3 -- profiles/r02_decode_chain_*.txt keep the measurements)
 

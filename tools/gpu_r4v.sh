@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4: residual prefetch A/B on the decode step (T = 6 and T = 1), same process
+# same-process A/Bs of the decode step (bench.py --workload mt-decode --ab-glue) at 6 tenants (Mistral-7B) and 1 (Llama-2-7B)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; O=gpurun_out/r4v; mkdir -p $O
 export TMPDIR=/tmp
@@ -10,6 +10,6 @@ for T in 6 1; do
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 ab = d['mt_decode']['glue_ab']
-print({k: [round(x, 3) for x in v] for k, v in ab.items() if 'residual' in k or 'weight_nt_on' in k}, d['mt_decode']['hipgraph_ms_per_step'])
+print({k: [round(x, 3) for x in v] for k, v in ab.items()}, d['mt_decode']['hipgraph_ms_per_step'])
 P
 done
