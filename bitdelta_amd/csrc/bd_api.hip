@@ -1248,7 +1248,7 @@ extern "C" int bd_tenant_linear(const void* X, const void* W, void* Y, int T, in
     dim3 grid((unsigned)((N + cpb - 1) / cpb), (unsigned)T);
     hipStream_t st = (hipStream_t)stream;
     const int rc = dtype == BD_BF16 ? launch_stream_tuned<DT_BF16, 0, true, 8>(sp, grid, st)
-                                    : launch_stream_tuned<DT_F16, 0, true, 8>(sp, grid, st);
+                                    : launch_stream_tuned<DT_F16, 0, true, 8>(sp, grid, st);      // (NS 6 / 4 measured equal or slower here)
     if (rc != BD_OK) return rc;
     return launch_status();
 }
@@ -1342,9 +1342,12 @@ extern "C" int bd_srv_decode_attention(const void* QKV, const void* cos_t, const
     dim3 grid((unsigned)(T * KVH), (unsigned)p.nsplit);
 #define BD_ATT(DT, GG)                                                                                      \
     do {                                                                                                    \
-        hipLaunchKernelGGL((decode_attn_kernel<DT, GG>), grid, dim3(512), 0, st, p);                        \
+        if (Lc <= 2048) hipLaunchKernelGGL((decode_attn_kernel<DT, GG, 2>), grid, dim3(512), 0, st, p);    \
+        else hipLaunchKernelGGL((decode_attn_kernel<DT, GG, 4>), grid, dim3(512), 0, st, p);                \
     } while (0)
-    // G = query heads per kv head: 1 (Llama-2-7B), 4 (Mistral-7B), 8 (Llama-2-70B -- also per rank under tensor parallelism)
+    // G = query heads per kv head: 1 (Llama-2-7B), 4 (Mistral-7B), 8 (Llama-2-70B -- also per rank under tensor parallelism).
+    // Depth of the K / V row ring: 2 iterations for caches of up to 2048 positions (a split is then <= 16 iterations; 4.698 -> 4.661 ms on the
+    // 6-tenant step at 512 keys, one iteration: 4.649 but exposed to the full load latency on long splits), 4 beyond
     if (dtype == BD_BF16) { if (G == 1) BD_ATT(DT_BF16, 1); else if (G == 4) BD_ATT(DT_BF16, 4); else BD_ATT(DT_BF16, 8); }
     else { if (G == 1) BD_ATT(DT_F16, 1); else if (G == 4) BD_ATT(DT_F16, 4); else BD_ATT(DT_F16, 8); }
 #undef BD_ATT

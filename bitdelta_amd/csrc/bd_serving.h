@@ -166,8 +166,9 @@ struct AttnParams {
 
 // One block of 8 waves per (tenant, kv head): its G = H / KVH query heads share the K / V stream.  Lane (kq = l >> 4, d8 = l & 15)
 // reads 16 bytes (dims 8*d8 .. +7) of key / value row l0 + kq, so a wave instruction covers 4 whole 256-byte rows and the block 32
-// rows per iteration; a 4-deep register ring keeps the rows of the next 4 iterations in flight (8 KB per wave), so the loop runs at
-// its issue rate instead of one HBM round trip per iteration.  Online softmax per head in fp32; the 4 row slots of a wave are merged
+// rows per iteration; a DEPTH-deep register ring keeps the rows of the next DEPTH iterations in flight, so the loop does not pay one
+// memory round trip per iteration (DEPTH is picked by the launch code: 2 for short caches, 4 for long ones -- deeper measured slower
+// on the decode step at 512 keys, like every other prefetch depth of the step: profiles/r04_decode_step_ab.txt).  Online softmax per head in fp32; the 4 row slots of a wave are merged
 // with lane shuffles, the 8 waves through LDS.  head_dim = 128, G in {1, 4, 8}.
 // (History, profiles/r02_decode_step.txt: 4 waves, no prefetch -> 16 waves, one iteration ahead: 21 us per layer -> this form.)
 __device__ __forceinline__ void attn_ws_store(float* dst, float v) { __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -175,9 +176,9 @@ __device__ __forceinline__ float attn_ws_load(const float* src) {
     return __hip_atomic_load(const_cast<float*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int DT, int G>
+template <int DT, int G, int DEPTH = 4>
 __global__ void __launch_bounds__(512) decode_attn_kernel(const AttnParams p) {
-    constexpr int HD = 128, NWV = 8, RPI = 4 * NWV, DEPTH = 4;
+    constexpr int HD = 128, NWV = 8, RPI = 4 * NWV;
     __shared__ float q_lds[G][HD];              // rotated, pre-scaled queries
     __shared__ float kn_lds[HD], vn_lds[HD];    // the new token's rotated key / value (also written to the cache)
     __shared__ float m_lds[NWV][G], s_lds[NWV][G];
