@@ -473,8 +473,14 @@ int launch_gemv_stream_chunk(const Problem& q) {
         // tile-major W: optional nt policy on the weight loads (STREAM_WT_NT_DEFAULT, or bd_set_stream_tuning bit 4 = on / bit 5 = off)
         const bool wnt = (g_stream_tune & 16) ? true : (g_stream_tune & 32) ? false : (STREAM_WT_NT_DEFAULT != 0);
         // ... and optionally the activation rows resident in LDS with a deeper weight prefetch (XL = 2; bd_set_stream_tuning bit 6 = on,
-        // bit 7 = off): plain and SwiGLU launches inside the fused-norm envelope (M = 1, K = 2048 * 2^s, R * K <= 32768)
-        const bool xres_ok = q.w_tiled && !q.norm_w && q.M == 1 && q.K >= 2048 && !(q.K & (q.K - 1)) && (int64_t)q.B * q.K <= 16 * 2048 &&
+        // bit 7 = off): plain and SwiGLU launches with M = 1 and R * K <= 32768
+        // (any K: tile-major W already needs K % 128 == 0; the norm prologue keeps its power-of-two rule, this form does not need it)
+        // Every wave must own at least one 128-k iteration: a wave with an empty k range still walks one padded stage per tile, whose
+        // zero sign words expand to -1 fragments -- harmless against the zero activation fragments of the per-stage form, NOT against
+        // fragments read from the resident rows (K = 1152: 9 iterations over 4 waves leave the last wave empty).
+        const int nit_x = (q.K + 127) / 128;
+        const bool xres_ok = q.w_tiled && !q.norm_w && q.M == 1 && q.t_pad <= 8 && q.K >= 1024 && 3 * ((nit_x + 3) / 4) < nit_x &&
+                             (int64_t)q.B * q.K <= 16 * 2048 &&
                              (int64_t)STREAM_XS_OFF + (int64_t)q.B * (2 * (int64_t)q.K + 16) <= STREAM_LDS_MAX;
         // Default: wherever it applies.  (Until the prefetch depths came down to 2 stages this form lost on short launches -- at 6 stages the
         // 4096 x 4096 o projection of a 6-tenant step was +25 % -- and was dispatched by size; at 2 stages it wins on every eligible launch:

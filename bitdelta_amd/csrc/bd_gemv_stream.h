@@ -206,7 +206,11 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
         const __amdgpu_buffer_rsrc_t rn = make_rsrc(sp.nw, sp.n_bytes);
 #pragma unroll
         for (int j = 0; j < XCH; ++j) {
-            const int r = j >> jsh, c = ((int)threadIdx.x + 256 * (j - (r << jsh))) * 8;      // M == 1 (host-checked): row = tenant
+            // XL = 1: K = 2048 << jsh, a thread's chunks of one row are consecutive j (the row sums need that).  XL = 2: any K % 8 == 0 --
+            // chunk q = thread + 256 j of the flat [R][K / 8] array (the same chunks as the line above when K is a power of two)
+            int r, c;
+            if constexpr (XL == 2) { const int q = (int)threadIdx.x + 256 * j, kc = p.K >> 3; r = q / kc; c = (q - r * kc) * 8; }
+            else { r = j >> jsh; c = ((int)threadIdx.x + 256 * (j - (r << jsh))) * 8; }      // M == 1 (host-checked): row = tenant
             const bool ok = r < p.R;
             xraw[j] = buf_load16<0>(rx, ok ? (uint32_t)(((long long)r * p.sXb + c) * 2) : STREAM_OOB);
             if constexpr (XL == 1) graw[j] = buf_load16<0>(rn, ok ? (uint32_t)(((long long)r * sp.sNw + c) * 2) : STREAM_OOB);
@@ -310,7 +314,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
     if constexpr (XL == 2) {                      // raw rows -> LDS (same thread mapping as the norm form)
 #pragma unroll
         for (int j = 0; j < XCH; ++j) {
-            const int r = j >> jsh, c = ((int)threadIdx.x + 256 * (j - (r << jsh))) * 8;
+            const int q = (int)threadIdx.x + 256 * j, kc = p.K >> 3, r = q / kc, c = (q - r * kc) * 8;
             if (r < p.R) *(u32x4_t*)(dyn_lds + sp.xs_off + (uint32_t)r * sp.xrow + (uint32_t)c * 2u) = xraw[j];
         }
     }

@@ -238,7 +238,7 @@ int bd_set_decode_wave_spec(int on);
  * bit 0 = natural-order base-weight loads, bit 1 = nt cache policy, bit 2 = 8-wave blocks, bit 3 = deeper prefetch.
  * Bits 4 / 5 work in the shipped library: 16 = non-temporal policy ON for the tile-major base-weight loads of the packed-layout kernels,
  * 32 = OFF (neither: the library default); 64 = activation rows resident in LDS + deeper weight prefetch (tile-major weight, M = 1,
- * K = 2048 * 2^s, B * K <= 32768) ON wherever it applies, 128 = OFF (neither: the library's shape rule); 1024 = the residual of an
+ * K >= 1024, B * K <= 32768) ON wherever it applies, 128 = OFF (neither: the library's shape rule); 1024 = the residual of an
  * `accumulate` launch is read in the epilogue (as before round 4) instead of at kernel start. */
 int bd_set_stream_tuning(int flags);
 /* A/B hook, sign LUT of the no-split-k decode kernel: -1 (default) automatic, 1 = single 4-KiB table, 0 = 16-copy conflict-free

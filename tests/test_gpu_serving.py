@@ -695,7 +695,9 @@ def test_serving_loop_static_state_is_bounded(bd):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("T,K,N", [(6, 4096, 6144), (1, 4096, 4096), (2, 1024, 1024), (4, 14336, 4096), (8, 2048, 512), (3, 128, 528)])
+@pytest.mark.parametrize("T,K,N", [(6, 4096, 6144), (1, 4096, 4096), (2, 1024, 1024), (4, 14336, 4096), (8, 2048, 512), (3, 128, 528),
+                                   (1, 11008, 4096), (2, 14336, 4096), (3, 5120, 1024), (1, 1152, 528), (2, 1280, 512),
+                                   (1, 2304, 528)])     # resident rows at any K (1152 = 9 iterations: a wave would be empty -> plain form)
 def test_tile_major_weight_is_bit_identical(bd, dtype, T, K, N):
     """the tile-major decode copy of the base weight (ldw = 0 at the C ABI) gives the same bits as the row-major operand: plain,
     with the residual epilogue, with the SwiGLU epilogue, with RMSNorm + SwiGLU and with the RMSNorm prologue alone"""
