@@ -490,6 +490,9 @@ int launch_gemv_stream_chunk(const Problem& q) {
         if (xres) {
 #define BD_XR(NM, NS8) rc = q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS8, 4, 1, 2, 1, 2, 1, 1>(sp, dim3(grid), q.st)   \
                                             : launch_stream_inst<DT, NM, true, NS8, 4, 1, 2, 1, 2, 0, 1>(sp, dim3(grid), q.st)
+            // (A/B, not shipped: the short 6-tenant launches -- q|k|v, o -- on 8-wave blocks, half the stages per wave, are 1 % faster on the
+            //  step, 4.688 -> 4.639 ms, but 8 partial sums in another order are no longer bit-identical to every other form of the Linear:
+            //  profiles/r04_decode_step_ab.txt.  The kernel template still takes NW = 8 with XL = 2.)
             switch (q.t_pad) {
                 // Prefetch depth: TWO stages.  Same-process A/Bs of the whole step late in round 4 (profiles/r04_decode_step_ab.txt): 8 -> 6 -> 4
                 // -> 2 stages each made the step faster (1 tenant: 3.57 -> 3.32 ms over the whole sequence of changes; 6 tenants: -0.3 %

@@ -128,7 +128,7 @@ template <int DT, int NM, bool HASW, int NS, int NW = 4, int WNAT = 0, int AUX =
 __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams sp) {
     static_assert(!WT || (PK && HASW), "tile-major W: packed layout");
     static_assert(!PK || (WNAT == 1 && NM > 0), "packed layout = natural order, with a sign operand");
-    static_assert(!(XL || EPI) || (PK && NW == 4), "fused prologue / epilogue: packed layout, 256-thread blocks");
+    static_assert(!(XL || EPI) || (PK && (NW == 4 || (XL == 2 && NW == 8))), "fused prologue / epilogue: packed layout, 256-thread blocks (resident rows: 512 too)");
     static_assert(!XL || NS % 2 == 0, "stage parity selects the activation fragment set");
     constexpr int AUXW = AUX & 2, AUXP = (AUX & 4) ? 2 : 0;
     GemvParams p = sp.g;
@@ -199,7 +199,8 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
 
     // XL: the R raw rows (and their norm weights) are the OLDEST loads of the wave -- like the scales above, consuming them never
     // waits for a weight stage.  Thread t owns the 16-byte chunks c = 8 t + 2048 i of every row: rmsnorm_tenant_kernel's mapping.
-    constexpr int XCH = 16;                                              // chunks per thread: R * K <= 16 * 2048 (host-checked)
+    constexpr int XCH = NW == 8 ? 8 : 16;                                // chunks per thread: R * K <= 16 * 2048 (host-checked)
+    constexpr int XNT = 64 * NW;                                         // threads that share the copy
     [[maybe_unused]] u32x4_t xraw[XL ? XCH : 1], graw[XL == 1 ? XCH : 1];
     [[maybe_unused]] const int jsh = sp.jsh;                             // log2(chunks per row per thread): K = 2048 << jsh (host-checked)
     if constexpr (XL) {
@@ -209,7 +210,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
             // XL = 1: K = 2048 << jsh, a thread's chunks of one row are consecutive j (the row sums need that).  XL = 2: any K % 8 == 0 --
             // chunk q = thread + 256 j of the flat [R][K / 8] array (the same chunks as the line above when K is a power of two)
             int r, c;
-            if constexpr (XL == 2) { const int q = (int)threadIdx.x + 256 * j, kc = p.K >> 3; r = q / kc; c = (q - r * kc) * 8; }
+            if constexpr (XL == 2) { const int q = (int)threadIdx.x + XNT * j, kc = p.K >> 3; r = q / kc; c = (q - r * kc) * 8; }
             else { r = j >> jsh; c = ((int)threadIdx.x + 256 * (j - (r << jsh))) * 8; }      // M == 1 (host-checked): row = tenant
             const bool ok = r < p.R;
             xraw[j] = buf_load16<0>(rx, ok ? (uint32_t)(((long long)r * p.sXb + c) * 2) : STREAM_OOB);
@@ -314,7 +315,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
     if constexpr (XL == 2) {                      // raw rows -> LDS (same thread mapping as the norm form)
 #pragma unroll
         for (int j = 0; j < XCH; ++j) {
-            const int q = (int)threadIdx.x + 256 * j, kc = p.K >> 3, r = q / kc, c = (q - r * kc) * 8;
+            const int q = (int)threadIdx.x + XNT * j, kc = p.K >> 3, r = q / kc, c = (q - r * kc) * 8;
             if (r < p.R) *(u32x4_t*)(dyn_lds + sp.xs_off + (uint32_t)r * sp.xrow + (uint32_t)c * 2u) = xraw[j];
         }
     }
