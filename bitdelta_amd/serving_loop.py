@@ -211,9 +211,9 @@ class TenantDecoder(nn.Module):
         # RMSNorm folded into the gate|up launch (SwiGLU stays in its epilogue either way): every block re-normalises all rows (rows + norm
         # weights from L2) to save one ~4.5 us launch.  Same-process A/Bs at the end of round 4, with the resident-row form (which needs no
         # norm) at 2 stages on every eligible launch: 1 tenant 3.353 fused vs 3.386 ms separate, 2 tenants 3.790 vs 3.823, 4 tenants 4.244
-        # vs 4.226, 6 tenants 4.771 vs 4.700 -- the prologue's cost grows with the rows, the saved launch does not
-        # (profiles/r04_decode_step_ab.txt).
-        self.fuse_gateup_norm = tenants <= 3
+        # vs 4.226 (and 4.218 vs 4.243 in a later session: a wash), 6 tenants 4.771 vs 4.700 -- the prologue's cost grows with the rows,
+        # the saved launch does not (profiles/r04_decode_step_ab.txt).
+        self.fuse_gateup_norm = tenants <= 4
         # (round 2 also shipped a persistent per-layer chain launch, bd_decode_chain: bit-identical but 5.91 vs 5.33 ms per step in every
         # same-process A/B, so it was removed from the library in round 3 -- profiles/r02_decode_chain_*.txt keep the measurements)
 
