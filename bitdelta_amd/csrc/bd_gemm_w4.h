@@ -525,7 +525,11 @@ __global__ void __launch_bounds__(256) delta_gemm_w4_kernel(const GemmParams p) 
     };
 
     if constexpr (USE_LUT) {
-        constexpr uint32_t POS = One2<DT>::v & 0xffffu, NEG = POS | 0x8000u;
+        // OPT & 128 / 256 / 512 (operand-value energy A/B, harness only; results need the row-sum correction x.S = x.(2B) - sum x):
+        //   128: bit -> {0x0000, 2.0 = 0x4000}   256: bit -> {0x0000, 1.0}   512: all zero
+        constexpr uint32_t ONE = One2<DT>::v & 0xffffu;
+        constexpr uint32_t POS = (Cfg::OPT & 512) ? 0u : (Cfg::OPT & 128) ? 0x4000u : ONE;
+        constexpr uint32_t NEG = (Cfg::OPT & (128 | 256 | 512)) ? 0u : (ONE | 0x8000u);
         const int e = threadIdx.x;
         u32x4_t v;
 #pragma unroll
@@ -628,6 +632,10 @@ __global__ void __launch_bounds__(256) delta_gemm_w4_kernel(const GemmParams p) 
                 // OPT & 4 (energy A/B only, results transposed inside each 32 x 32 block): the 8-wave kernels' order, sign fragment first
                 if constexpr (Cfg::OPT & 4) acc[bb][i] = mfma32<DT>(bf[bb], xf[s & 1][i], acc[bb][i]);
                 else if constexpr (Cfg::OPT & 2) acc[bb][i & 2] = mfma32<DT>(xf[s & 1][i], bf[bb], acc[bb][i & 2]);   // energy A/B: dependent pairs
+                else if constexpr (Cfg::OPT & 1024) {      // energy A/B (results wrong): X-stationary order -- 4 consecutive MFMAs share the X fragment
+                    const int bi = (bb + (i == 3 ? 0 : i)) & 3;
+                    acc[i][bb] = mfma32<DT>(xf[s & 1][bb], bf[bi], acc[i][bb]);
+                }
                 else if constexpr (Cfg::OPT & 16) acc[bb][0] = mfma32<DT>(xf[s & 1][i], bf[bb], acc[bb][0]);          // energy A/B: chains of 4
                 else acc[bb][i] = mfma32<DT>(xf[s & 1][i], bf[bb], acc[bb][i]);
             }

@@ -184,7 +184,7 @@ int main(int argc, char** argv) {
     if (what.rfind("soak", 0) == 0) {      // soak<variant>: run one kernel back to back for `reps` x 0.1 s (power / clock sampling from outside)
         const int M = Ms[0];
         const int v = atoi(what.c_str() + (what.rfind("soakn", 0) == 0 ? 5 : 4));
-        GemmParams p0 = params(M, N, v >= 10 && v < 20, C0);   // (fused variants: 10, 11, 12)
+        GemmParams p0 = params(M, N, v >= 10 && v < 20, C0);   // (fused variants: 10, 11, 12, 13)
         using OldD = GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 1>;
         using OldF = FxCfg<DT_BF16, 256, 128, 3, false, 1>;
         auto one = [&] {
@@ -196,6 +196,11 @@ int main(int argc, char** argv) {
             else if (v == 7) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 8>>(p0, 1, 0);     // ablation: no LDS-DMA in the loop
             else if (v == 8) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 32>>(p0, 1, 0);    // ablation: no X-fragment reads in the loop
             else if (v == 9) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 8 | 32>>(p0, 1, 0);  // ablation: neither
+            else if (v == 20) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 128>>(p0, 1, 0);   // operand-value A/B: sign LUT {0, 2.0}
+            else if (v == 21) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 256>>(p0, 1, 0);   // operand-value A/B: sign LUT {0, 1.0}
+            else if (v == 22) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 512>>(p0, 1, 0);   // operand-value A/B: sign LUT all zero
+            else if (v == 13) launch_w4<W4Cfg<DT_BF16, 256, 128, true, false, 1 | 128>>(p0, 1, 0);    // fused, sign LUT {0, 2.0}
+            else if (v == 23) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 1024>>(p0, 1, 0);  // MFMA-order A/B: X-stationary (results wrong)
             else if (v == 3) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 64>>(p0, 1, 0);    // split-form DMA
             else if (v == 12) launch_w4<W4Cfg<DT_BF16, 256, 128, true, false, 0>>(p0, 1, 0);         // fused, VALU sign expansion (A/B)
             else if (v == 4) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 4>>(p0, 1, 0);     // energy A/B: sign fragment in the first MFMA slot (results wrong)
@@ -216,7 +221,7 @@ int main(int argc, char** argv) {
             n += 50;
             CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&total, e0, e1));
         }
-        const double fl = (v >= 10 ? 4.0 : 2.0) * M * N * K;
+        const double fl = (v >= 10 && v < 20 ? 4.0 : 2.0) * M * N * K;
         printf("soak variant %d M=%d: %lld launches in %.1f ms -> %.2f us each, %.1f TF\n", v, M, n, total, total * 1e3 / n, fl * n / (total * 1e-3) / 1e12);
         return 0;
     }
