@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the 1-bit-delta Linear hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W          (N > 1: one rank per GPU under torch.distributed.run -- either the caller
+                                                            launches it that way, or bench.py re-execs itself under the launcher)
 
 Workload of `value` (BASELINE.json configs[1]): Llama-2-7B base + one 1-bit delta (Vicuna-7B-v1.5 shapes), prefill of one
 2048-token sequence per GPU, synthetic weights/activations (SURVEY.md 8d recipe).  A "step" is one full prefill forward:
@@ -527,10 +528,30 @@ def main():
     ap.add_argument("--no-mt-decode", action="store_true", help="skip the configs[2] leg of the default run")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU (the driver's command line
+    # may or may not carry the launcher; either way N ranks run, or the run fails -- it never silently measures one rank).
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
+
     from bitdelta_amd import dist as bdd
-    rank, world, local = bdd.init_from_env()
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:          # checked BEFORE the rendezvous (a short job would hang in it)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')} rank(s)")
     assert torch.cuda.is_available(), "bench.py needs a ROCm device (there is no CPU path)"
+    rank, world, local = bdd.init_from_env()
+    import torch.distributed as tdist
+    n_seen = tdist.get_world_size() if tdist.is_initialized() else 1
+    if n_seen != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but torch.distributed sees {n_seen} rank(s)")
+    shared_gpu_ok = os.environ.get("BD_DIST_BACKEND") == "gloo"      # control-flow test of the N-rank path on a box with fewer GPUs
+    if torch.cuda.device_count() < args.gpus and not shared_gpu_ok:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} device(s) are visible")
     local = local % torch.cuda.device_count()        # one rank per GPU on a full node; wraps only in the gloo smoke test of this path
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -582,8 +603,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    timer.enabled = True
+    # `value`: the K timed steps run CLEAN (no per-launch events inside the region).  The roofline of the dominant kernel is measured
+    # right after, over the same K steps again with every fused launch bracketed by a HIP event pair on the launch stream.
+    timer.enabled = False
     dt = bdd.timed_region(step, args.steps, device_sync=torch.cuda.synchronize)
+    timer.enabled = True
+    dt_events = bdd.timed_region(step, args.steps, device_sync=torch.cuda.synchronize)
     timer.enabled = False
     torch.cuda.synchronize()
     n_launch, k_ms, k_flops, k_bytes = timer.summary()
@@ -622,7 +647,10 @@ def main():
                                "x.W^T + alpha*(x.S), 4*M*N*K flop/launch; a tail split hands the last partial round's columns to "
                                "bd::delta_gemm_fx_kernel<128x128>)",
                      "launches": n_launch, "kernel_ms_total": k_ms, "algorithmic_flops_total": k_flops,
-                     "share_of_step_time": (k_ms / 1e3) / dt if dt > 0 else None},
+                     "measured_in": "a second pass of the same K steps with one HIP event pair per fused launch (the timed region of `value` "
+                                    "carries no events)",
+                     "ms_per_step_with_events": dt_events / args.steps * 1e3,
+                     "share_of_step_time": (k_ms / 1e3) / dt_events if dt_events > 0 else None},
         **bdd.runtime_info(),
         "delta_gemm": mb,
         "vendor_gemm": vendor_gemm_microbench(dev),

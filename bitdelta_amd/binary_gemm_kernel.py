@@ -113,7 +113,7 @@ def delta_bmm(a, b, *, out=None, out_dtype=None, round_mode=1, alpha=None, accum
     return out
 
 
-def binary_linear(x, weight, mask, alpha, *, out_dtype=None, groups=1, residual=None):
+def binary_linear(x, weight, mask, alpha, *, out_dtype=None, groups=1, residual=None, out=None):
     """Fused 16-bit base + 1-bit delta Linear:  y[i] = x[i] . weight^T + alpha[i] * (x[i] . S[i])  in ONE launch.
 
     x: (B, M, K); weight: (N, K) rows k-contiguous; mask: (B or 1, K/32, N) int32; alpha: fp32 (B or 1, groups).
@@ -122,8 +122,10 @@ def binary_linear(x, weight, mask, alpha, *, out_dtype=None, groups=1, residual=
     residual: optional (B, M, N) tensor of out_dtype that is updated IN PLACE to residual + y and returned (the decoder layer's
     `hidden = residual + proj(...)`): folded into the kernel epilogue at decode shapes (fp32 sum, one rounding) and on the fast
     path of the fused GEMM at M > 16 (output rounded, then the sum: the two roundings of the separate ops); a separate add otherwise.
+    out: optional (B, M, N) destination of out_dtype with unit column stride (e.g. a peer-mapped all-reduce buffer: the row-parallel
+    Linear of tp.py writes its fp32 partial sums straight into it); not combined with `residual`.
     """
-    require_gpu(x, weight, mask, alpha, residual)
+    require_gpu(x, weight, mask, alpha, residual, out)
     assert x.dim() == 3 and mask.dim() == 3 and weight.dim() == 2
     B, M, K = x.shape
     N = weight.shape[0]
@@ -144,7 +146,12 @@ def binary_linear(x, weight, mask, alpha, *, out_dtype=None, groups=1, residual=
     fused_residual = residual is not None and aligned and ((M <= 16 and B * M <= 64 and K % 32 == 0) or (M > 16 and K % 64 == 0))
     if residual is not None:
         assert residual.shape == (B, M, N) and residual.dtype == out_dtype and residual.stride(2) == 1
-    y = residual if fused_residual else torch.empty((B, M, N), device=x.device, dtype=out_dtype)
+    if out is not None:
+        assert residual is None, "out= and residual= are exclusive"
+        assert out.shape == (B, M, N) and out.dtype == out_dtype and out.stride(2) == 1 and out.device == x.device
+        y = out
+    else:
+        y = residual if fused_residual else torch.empty((B, M, N), device=x.device, dtype=out_dtype)
     fn = L.bd_binary_linear_residual if fused_residual else L.bd_binary_linear
     ws, ws_bytes = workspace(L.bd_gemm_workspace_bytes(B, M, N, K), x.device, zeroed=True)
     with torch.cuda.device(x.device):

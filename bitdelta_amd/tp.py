@@ -79,24 +79,40 @@ class RowParallelBinaryDiff(nn.Module):
         assert weight.shape[1] % world == 0 and k % 32 == 0, "K / world must be a multiple of 32"
         return cls(weight[:, rank * k:(rank + 1) * k], shard_mask_rows(mask, rank, world), coeff, group)
 
-    def partial(self, x, out_dtype=torch.float32):
+    def partial(self, x, out_dtype=torch.float32, out=None):
         shape = x.shape
-        y = binary_linear(x.reshape(1, -1, shape[-1]), self.weight, self.mask.unsqueeze(0), self.coeff, out_dtype=out_dtype)
+        if out is not None:
+            out = out.view(1, -1, out.shape[-1])
+        y = binary_linear(x.reshape(1, -1, shape[-1]), self.weight, self.mask.unsqueeze(0), self.coeff, out_dtype=out_dtype, out=out)
         return y.reshape(*shape[:-1], y.shape[-1])
 
     def forward(self, x, reduce_dtype=None):
         rows = x.numel() // x.shape[-1]
         if reduce_dtype is None:
             reduce_dtype = torch.float32 if rows <= 64 else x.dtype
+        if self._reduce is None:
+            self._reduce = PartialSumReducer(self.group)       # one-shot exchange for decode-sized messages, ring otherwise
+        if reduce_dtype == torch.float32:
+            # decode-sized messages: the Linear writes its fp32 partial sums STRAIGHT into the reducer's peer-mapped buffer (no staging
+            # copy, one launch less per all-reduce); None when this message shape rides the ring
+            buf = self._reduce.buffer((*x.shape[:-1], self.weight.shape[0]), torch.float32, x.device)
+            if buf is not None:
+                self.partial(x, out_dtype=torch.float32, out=buf)
+                return self._reduce.reduce_buffer(buf).to(x.dtype)
         y = self.partial(x, out_dtype=torch.float32)
         if reduce_dtype != torch.float32:
             y = y.to(reduce_dtype)
-        if self._reduce is None:
-            self._reduce = PartialSumReducer(self.group)       # one-shot exchange for decode-sized messages, ring otherwise
         return self._reduce(y).to(x.dtype)
 
 
 # ------------------------------------------------------------------------------------------------ small-message all-reduce
+class _ShapeLike:
+    """(shape, dtype, device) of a message, for allocating its symmetric buffer before any tensor of that shape exists"""
+
+    def __init__(self, shape, dtype, device):
+        self.shape, self.dtype, self.device = tuple(shape), dtype, device
+
+
 class PartialSumReducer:
     """All-reduce of the row-parallel Linears' fp32 partial sums.
 
@@ -136,7 +152,7 @@ class PartialSumReducer:
         self._sm, self._gname = sm, g.group_name
 
     def _local_alloc(self, y):
-        return self._sm.empty(y.shape, dtype=y.dtype, device=y.device)
+        return self._sm.empty(tuple(y.shape), dtype=y.dtype, device=y.device)
 
     def _rendezvous(self, buf):
         self._sm.rendezvous(buf, self._gname)
@@ -164,21 +180,21 @@ class PartialSumReducer:
                 self.why_ring = err or "symmetric-memory setup failed on another rank"
         return self._symm
 
-    def _buffer_for(self, y):
-        key = (tuple(y.shape), y.dtype)
+    def _buffer_for(self, shape, dtype, device):
+        key = (tuple(shape), dtype)
         if key in self._bufs:
             return self._bufs[key]
         buf, ok, err = None, True, None
         try:
-            buf = self._local_alloc(y)               # local; the collective rendezvous comes only after everybody has a buffer
+            buf = self._local_alloc(_ShapeLike(shape, dtype, device))     # local; the collective rendezvous comes only after everybody has one
         except Exception as e:
             ok, err = False, f"{type(e).__name__}: {e}"
-        if self._all_agree(ok, y.device):
+        if self._all_agree(ok, device):
             try:
                 self._rendezvous(buf)
             except Exception as e:
                 ok, err = False, f"{type(e).__name__}: {e}"
-            ok = self._all_agree(ok, y.device)
+            ok = self._all_agree(ok, device)
         else:
             ok = False
         if not ok:
@@ -187,16 +203,32 @@ class PartialSumReducer:
         self._bufs[key] = buf
         return buf
 
+    def _active(self):
+        return not (self.world == 1 or not dist.is_initialized() or dist.get_world_size(self.group) == 1)
+
+    def buffer(self, shape, dtype, device):
+        """The peer-mapped buffer a producer may write its partial sums INTO (then `reduce_buffer`), or None when a message of this shape
+        goes over the ring / nothing is reduced.  The decision is collective and cached per (shape, dtype): every rank gets the same answer."""
+        nbytes = torch.empty((), dtype=dtype).element_size()
+        for d in shape:
+            nbytes *= int(d)
+        if self._active() and nbytes <= self.ONE_SHOT_MAX_BYTES and self._symm_ok(device):
+            return self._buffer_for(shape, dtype, device)
+        return None
+
+    def reduce_buffer(self, buf):
+        """sum over ranks of a buffer handed out by `buffer` and filled by the producing kernel (stream order: same stream)"""
+        self.calls["one_shot"] += 1
+        return self._one_shot(buf)
+
     def __call__(self, y):
         """y: fp32 (or 16-bit) partial sums, identical shape on every rank; returns the sum (may alias y)"""
-        if self.world == 1 or not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+        if not self._active():
             return y
-        if y.numel() * y.element_size() <= self.ONE_SHOT_MAX_BYTES and self._symm_ok(y.device):
-            buf = self._buffer_for(y)
-            if buf is not None:
-                buf.copy_(y)
-                self.calls["one_shot"] += 1
-                return self._one_shot(buf)
+        buf = self.buffer(y.shape, y.dtype, y.device)
+        if buf is not None:              # a producer that could not write into the buffer itself (16-bit partials, non-Linear callers)
+            buf.copy_(y)
+            return self.reduce_buffer(buf)
         dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
         self.calls["ring"] += 1
         return y
@@ -438,8 +470,10 @@ def bench_tp70b(args, dev, rank, world, timer):
     for _ in range(args.warmup):
         step()
     timer.reset()
+    timer.enabled = False
+    dt = timed_region(step, args.steps, device_sync=torch.cuda.synchronize)          # `value`: no per-launch events inside the region
     timer.enabled = True
-    dt = timed_region(step, args.steps, device_sync=torch.cuda.synchronize)
+    dt_ev = timed_region(step, args.steps, device_sync=torch.cuda.synchronize)       # roofline pass: one HIP event pair per fused launch
     timer.enabled = False
     n_launch, k_ms, k_flops, _ = timer.summary()
     # decode: one token per step on a KV cache of args.kv_len, the per-rank step (kernels + collectives) replayed as a hipGraph
@@ -471,7 +505,7 @@ def bench_tp70b(args, dev, rank, world, timer):
                    "measured_on_hardware": "never on > 1 GPU by the builder (no multi-GPU box); world = 1 / 2-rank gloo runs only"},
         "roofline": {"bound": "mfma", "achieved": k_flops / k_ms * 1e-9 if k_ms > 0 else None, "peak": 2500.0, "unit": "TFLOP/s",
                      "frac": (k_flops / k_ms * 1e-9 / 2500.0) if k_ms > 0 else None, "traffic": None, "launches": n_launch,
-                     "share_of_step_time": (k_ms / 1e3) / dt if dt > 0 else None},
+                     "share_of_step_time": (k_ms / 1e3) / dt_ev if dt_ev > 0 else None},
         "decode": {"ms_per_step": ddt / 20 * 1e3, "kv_len": args.kv_len, "linear_bytes_per_rank": dec.linear_bytes_per_rank(),
                    "linear_gbs_per_rank_if_only_linears": dec.linear_bytes_per_rank() / (ddt / 20) * 1e-9},
         # which transport the partial-sum exchange actually took on this run (prefill messages: ring; decode messages: one-shot when

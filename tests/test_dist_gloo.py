@@ -116,7 +116,7 @@ def _reducer_worker(rank, world, port, q):
         def _local_alloc(self, y):
             if self.fail_alloc_on == dist.get_rank():
                 raise RuntimeError("symmetric allocation failed (injected)")
-            return torch.empty_like(y)
+            return torch.empty(y.shape, dtype=y.dtype, device=y.device)      # y: (shape, dtype, device) of the message
 
         def _rendezvous(self, buf):
             self.rendezvous_calls += 1
@@ -133,6 +133,11 @@ def _reducer_worker(rank, world, port, q):
     a = Fake()
     out = a(y())
     res["all_ok"] = (bool((out == want).all()), a.calls["one_shot"], a.calls["ring"], a.report()["one_shot_available"])
+    # producer-side use (RowParallelBinaryDiff): the Linear writes into the handed-out buffer, no staging copy; same cached buffer as above
+    pbuf = a.buffer((2, 8), torch.float32, torch.device("cpu"))
+    pbuf.fill_(float(rank + 1))
+    res["producer_buffer"] = (pbuf is not None and bool((a.reduce_buffer(pbuf) == want).all()), a.calls["one_shot"], a.rendezvous_calls,
+                              a.buffer((1024, 128), torch.float32, torch.device("cpu")) is None)
     b = Fake()
     b.fail_enable_on = 1
     out = b(y())
@@ -166,6 +171,7 @@ def test_partial_sum_reducer_transport_decision_is_collective():
         assert p.exitcode == 0
     for rank, r in res:
         assert r["all_ok"] == (True, 1, 0, True), (rank, r)
+        assert r["producer_buffer"] == (True, 2, 1, True), (rank, r)
         assert r["enable_fails_on_rank1"] == (True, 0, 1, 0, True), (rank, r)          # BOTH ranks on the ring, nobody in a rendezvous
         assert r["alloc_fails_on_rank0"] == (True, 0, 3, 0), (rank, r)
         assert r["real_class_on_gloo"] == (True, 0, 1, True), (rank, r)
@@ -336,3 +342,54 @@ def test_tp_decoder_chunked_prefill_is_causal():
     run()
     torch.cuda.synchronize()
     assert ((eager.float() - buf.float()).norm() / eager.float().norm()).item() <= 3e-3 and int(pos2) == 49
+
+
+# ------------------------------------------------------------------------------------------------ bench.py --gpus N launches N ranks itself
+def _run_bench(argv, env_extra, timeout):
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=timeout,
+                          env=env, cwd=ROOT)
+
+
+def test_bench_gpus_n_reexecs_under_the_launcher_cpu():
+    """`python bench.py --gpus 2` with no launcher in front (the driver's command line) must start TWO ranks under
+    torch.distributed.run -- never silently measure one.  On this GPU-less box each rank then fails loudly (no CPU path): the failure
+    report must come from the elastic launcher and name both the missing device and two local ranks."""
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--layers", "1"], {"BD_DIST_BACKEND": "gloo"}, 300)
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU box: covered by test_bench_gpus_2_runs_two_ranks_on_one_gpu")
+    assert r.returncode != 0
+    assert "needs a ROCm device" in r.stderr
+    assert "torch.distributed" in r.stderr or "ChildFailedError" in r.stderr, r.stderr[-2000:]
+    assert "local_rank: 1" in r.stderr or "rank      : 1" in r.stderr or "[rank1]" in r.stderr or "rank: 1" in r.stderr, r.stderr[-3000:]
+
+
+def test_bench_world_size_mismatch_fails_loudly_cpu():
+    """A launcher that started a different number of ranks than --gpus asks for is an error, not a one-rank measurement."""
+    r = _run_bench(["--gpus", "1", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "2", "RANK": "0", "BD_DIST_BACKEND": "gloo",
+                                                                   "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())}, 120)
+    assert r.returncode != 0
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_runs_two_ranks_on_one_gpu():
+    """bench.py --gpus 2 as the driver invokes it (no launcher): two ranks (gloo control plane, both on the box's one GPU), and the JSON
+    line says so: n_gpus == n_ranks_seen == 2."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--layers", "1", "--no-mt-decode", "--no-cpu-baseline"],
+                   {"BD_DIST_BACKEND": "gloo"}, 900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["backend"] == "gloo"
+    assert d["config"]["valid"] is False          # --layers 1 is a debug run and says so
+    assert d["roofline"]["launches"] == 2 * 4 and d["roofline"]["ms_per_step_with_events"] > 0
