@@ -222,8 +222,13 @@ def parity_block(dev):
         fixed = [0, 1, 127, 128, 255, 256, N // 2, N - 257, N - 129, N - 2, N - 1]
         return torch.tensor(sorted(set([c for c in fixed if 0 <= c < N] + torch.randint(0, N, (n,), generator=g).tolist())))
 
-    out = {"oracle": "oracle/bd_oracle.c on sampled output columns, all rows, all of k", "gates": "16-bit outputs: <= 1 ulp of the rounded "
-           "fp32 oracle (or inside the cancellation floor 2^-22 sqrt(K) max|ref|), >= 99 % bit-equal; fp32 outputs: rel-Frobenius <= 1e-5"}
+    out = {"oracle": "oracle/bd_oracle.c on sampled output columns, all rows, all of k",
+           "gates": "bf16 / fp16 OUTPUTS: every element <= 1 ulp of the fp32 oracle rounded to the output type, or inside the cancellation "
+                    "floor 2^-22 sqrt(K) max|ref| taken PER ROW (activation row x sampled columns), >= 99 % bit-equal.  The north star's "
+                    "'1e-3 relative' holds in fp32-output mode (rel-Frobenius <= 1e-5 below) and on fp16 outputs; a bf16 OUTPUT cannot "
+                    "meet it by construction -- one bf16 rounding is 2^-9 = 1.95e-3 relative worst case, ~1.7e-3 rel-Frobenius against "
+                    "the unrounded fp32 oracle (rel_frobenius_16bit_vs_fp32_oracle below; the reference's own bf16 path has the same "
+                    "floor plus its fp16 intermediate, SURVEY.md 7b)"}
     g = torch.Generator().manual_seed(5)
     # (1) the delta GEMM row at M = 4096 (bf16, round_mode 0 as timed; fp32-output mode as the exactness check)
     M, N, K = 4096, 4096, 4096
@@ -250,7 +255,7 @@ def parity_block(dev):
     ref32 = o.binary_linear(x, w[cols].contiguous(), p[:, :, cols].contiguous(), al, out_dtype=torch.float32, round_mode=0)
     got = y16[:, :, cols.to(dev)].cpu().contiguous()
     d = ulp(got, ref32.bfloat16())
-    floor = 2.0 ** -22 * (K ** 0.5) * float(ref32.abs().max())
+    floor = 2.0 ** -22 * (K ** 0.5) * ref32.abs().amax(dim=-1, keepdim=True)      # per activation row
     ok = (d <= 1) | ((got.float() - ref32.bfloat16().float()).abs() <= floor)
     out["fused_linear_2048x4096_to_11008"] = {
         "kernel_variant": v, "sampled_columns": len(cols), "max_ulp": int(d.max()), "all_within_gate": bool(ok.all()),
@@ -282,7 +287,7 @@ def parity_block(dev):
                                 G=len(cols), out_dtype=torch.float32, round_mode=0)
         got = y16[:, :, cols.to(dev)].cpu().contiguous()
         d = ulp(got, ref32.bfloat16())
-        floor = 2.0 ** -22 * (K ** 0.5) * float(ref32.abs().max())
+        floor = 2.0 ** -22 * (K ** 0.5) * ref32.abs().amax(dim=-1, keepdim=True)      # per activation row
         ok = (d <= 1) | ((got.float() - ref32.bfloat16().float()).abs() <= floor)
         out[name] = {"kernel_variant": v, "scale_groups": lin.groups, "sampled_columns": len(cols), "max_ulp": int(d.max()),
                      "all_within_gate": bool(ok.all()), "bit_equal": float((d == 0).float().mean()),

@@ -85,8 +85,8 @@ def check_linear(bd, oracle, x, w, p, alpha, cols=None, groups=1):
 
 def cancel_floor(ref, K):
     """absolute floor for outputs that cancel to ~0 (ulp distance is meaningless there): fp32 rounding of partial sums as large as
-    the largest output, random-walked over K terms -- scales with the problem, not a flat constant"""
-    return 2.0 ** -22 * (K ** 0.5) * max(ref.float().abs().max().item(), 1e-30)
+    the largest output OF THE SAME ROW, random-walked over K terms -- scales with the problem, not a flat constant"""
+    return 2.0 ** -22 * (K ** 0.5) * ref.float().abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)       # per output row
 
 
 def check_delta(bd, oracle, x, p, cols=None):
