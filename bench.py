@@ -122,12 +122,37 @@ def physical_cores():
                 sib = fh.read().strip().replace("-", ",").split(",")
             first = min(int(t) for t in sib if t != "")
             firsts.add(first if first in allowed else c)
-    except OSError:
+    except (OSError, AttributeError):
         return sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
     return sorted(firsts)
 
 
 def cpu_baseline(seq=2048, reps=5):
+    """The CPU baseline runs in a FRESH process started under the affinity mask (one hardware thread per physical core): an in-process
+    os.sched_setaffinity only moves the calling thread, and OpenMP / MKL pool threads torch created earlier would keep their old mask
+    (ADVICE r04).  The child reports the affinity it actually observes; that is what the bench line states."""
+    import subprocess
+    cores = physical_cores()
+
+    def pin():
+        if hasattr(os, "sched_setaffinity"):
+            try:
+                os.sched_setaffinity(0, cores)
+            except OSError:
+                pass
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    env.update(OMP_NUM_THREADS=str(len(cores)), MKL_NUM_THREADS=str(len(cores)))
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--seq", str(seq), "--steps", str(reps)],
+                       capture_output=True, text=True, preexec_fn=pin, env=env, cwd=ROOT, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError(f"cpu_baseline child failed (rc {r.returncode}): {r.stderr[-1500:]}")
+    return json.loads(lines[-1])
+
+
+def cpu_baseline_measure(seq=2048, reps=5):
     """Reference-equivalent CPU path (oracle/torch_port.py) on the SAME unit of work as the GPU step: one 2048-token sequence through
     a decoder layer's 7 BinaryDiff projections (Llama-2-7B shapes).  BASELINE.md 3 hygiene: the process is pinned to ONE hardware
     thread per PHYSICAL core and torch runs that many threads (SMT siblings and over-subscription made round 3's figure swing 14x
@@ -136,14 +161,11 @@ def cpu_baseline(seq=2048, reps=5):
     (what a CPU run of the reference does); variant 2 is the pure torch.matmul baseline with pre-unpacked signs.  Attention / norms
     are excluded (GPU side: about 10 % of the step)."""
     from oracle import torch_port as tp
-    cores = physical_cores()
-    old_aff = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    # this process was STARTED under the mask (cpu_baseline): every thread pool inherits it.  Report what is observed, not what was asked.
+    observed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    cores = observed
+    old_aff = None
     old_threads = torch.get_num_threads()
-    try:
-        if old_aff is not None:
-            os.sched_setaffinity(0, cores)
-    except OSError:
-        pass
     torch.set_num_threads(len(cores))
     torch.manual_seed(0)
     hid, inter = 4096, 11008
@@ -197,8 +219,9 @@ def cpu_baseline(seq=2048, reps=5):
             "sample": f"same unit as the GPU step (one {seq}-token sequence, Llama-2-7B projections): per DISTINCT projection shape one "
                       f"warm-up + the median of {reps} timed calls at seq {seq} (variant 1 / variant 2: " + ", ".join(detail) +
                       f"), layer = 4+2+1 of them = {t1:.1f} s, x32 layers; value = variant 1 (unpack inside the timed region, the "
-                      f"reference's CPU-executable path); host: {cpu}, os.cpu_count()={os.cpu_count()}, pinned to {len(cores)} physical "
-                      f"cores, torch threads={len(cores)}, torch {torch.__version__}"}
+                      f"reference's CPU-executable path); host: {cpu}, os.cpu_count()={os.cpu_count()}, fresh process whose OBSERVED affinity "
+                      f"is {len(cores)} hardware threads (one per physical core when the sysfs topology is readable), torch threads="
+                      f"{torch.get_num_threads()}, torch {torch.__version__}"}
 
 
 def parity_block(dev):
@@ -531,7 +554,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ab-glue", action="store_true", help="mt-decode: also time the step with separate RMSNorm / SwiGLU launches")
     ap.add_argument("--no-mt-decode", action="store_true", help="skip the configs[2] leg of the default run")
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_child:                  # the pinned child of cpu_baseline(): CPU only, prints its JSON object and exits
+        print(json.dumps(cpu_baseline_measure(seq=args.seq, reps=args.steps)), flush=True)
+        return
 
     # `python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU (the driver's command line
     # may or may not carry the launcher; either way N ranks run, or the run fails -- it never silently measures one rank).

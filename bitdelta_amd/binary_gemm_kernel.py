@@ -247,8 +247,9 @@ def decode_shape_ok(B, M, N, K, n_masks, layout="packed"):
 
 
 def fused_norm_ok(B, M, K):
-    """envelope of the fused RMSNorm prologue of bd_binary_linear_decode_fused (include/bitdelta_hip.h)"""
-    return M == 1 and K >= 2048 and K & (K - 1) == 0 and B * K <= 16 * 2048 and 83968 + B * (2 * K + 16) <= 160 * 1024
+    """envelope of the fused RMSNorm prologue of bd_binary_linear_decode_fused (include/bitdelta_hip.h): at most 8 tenants -- the kernel
+    side (BD_PKL in csrc/bd_api.hip) answers BD_E_BAD_SHAPE for a norm_w launch on the 12 / 16-tenant packed layouts"""
+    return M == 1 and B <= 8 and K >= 2048 and K & (K - 1) == 0 and B * K <= 16 * 2048 and 83968 + B * (2 * K + 16) <= 160 * 1024
 
 
 def binary_linear_decode(x, weight, mask, alpha, *, layout="tile", out_dtype=None, groups=1, residual=None,

@@ -975,7 +975,7 @@ int dispatch3(const Problem& q) {
                 if (!pair_ok(q) || q.N % 8 || q.sCm % 4 || q.sCb % 4) return BD_E_BAD_SHAPE;
                 int ks = pair_splitk(q);
                 if (ks < 2) ks = (q.K / 64 >= 2) ? 2 : 1;
-                if (ks < 2) return BD_E_BAD_SHAPE;
+                if (ks < 2 || ks > q.K / 64) return BD_E_BAD_SHAPE;       // every k slice holds at least one 64-k tile (no empty slices)
                 return launch_pair_splitk<DT>(q, ks);
             } else return BD_E_BAD_SHAPE;
         }

@@ -17,6 +17,7 @@ Reduction precision: partial sums leave the kernel in fp32 and are all-reduced i
 (16-64 KB: latency-bound, precision is free), the activation dtype for prefill-sized ones (2048 x 8192: 32 MB instead of 64 MB per
 all-reduce; one extra rounding of each of the 8 partials, <= 2^-9 relative each).  Messages per step: 2 per layer x 80 layers.
 """
+import os
 import time
 
 import torch
@@ -307,6 +308,18 @@ class TPDecoderLayer(nn.Module):
         y = self.reduce(y)
         return residual + y.to(residual.dtype)
 
+    def prefill_kernel_ok(self, B, S, dtype, device):
+        """True when `forward(..., from_zero=True)` will take the flash-style prefill attention kernel for a [B, S] prompt: the gate of
+        that branch evaluated on an (uninitialised) tensor of the fused projection's output shape.  TPDecoder.forward asks ONCE per call,
+        so the dense [S, Lc] mask is either built once or not at all."""
+        hd = self.hd
+        nq, nk = self.h_loc * hd, self.kv_loc * hd
+        if not (S > 1 and hd == 128 and S % 64 == 0 and not self.qkv.interleave8):
+            return False
+        qkv = torch.empty(B, S, nq + 2 * nk, device=device, dtype=dtype)
+        return bool(ops.prefill_attention_supported(qkv[..., :nq].view(B, S, self.h_loc, hd), qkv[..., nq:nq + nk].view(B, S, self.kv_loc, hd),
+                                                    qkv[..., nq + nk:].view(B, S, self.kv_loc, hd)))
+
     def forward(self, x, cos, sin, cache, pos_idx, attn_mask, from_zero=False):
         """x [1, S, hidden] (replicated); cache = (k [1, kv_loc, L, hd], v, valid [1, L]); pos_idx [S] device positions;
         from_zero: the caller knows pos_idx == arange(S) (a prompt prefilled from position 0 into an empty cache)"""
@@ -406,9 +419,15 @@ class TPDecoder(nn.Module):
         Returns the logits of the last position [1, 1, vocab] (replicated on every rank)."""
         B, S = ids.shape
         Lc = cache["valid"].shape[1]
+        if from_zero and os.environ.get("BD_DEBUG_CHECKS"):
+            # from_zero is a caller assertion; with it wrong, attention would silently see only keys [:S].  Debug builds check it (a sync).
+            assert int(pos_idx[0]) == 0 and int(pos_idx[-1]) == S - 1 and not bool(cache["valid"].any()), \
+                "from_zero=True needs pos_idx == arange(S) on an EMPTY cache"
         cache["valid"].index_fill_(1, pos_idx, True)
         mask = None
-        if not (from_zero and S > 1 and S % 64 == 0 and self.hd == 128):
+        # the attention path is decided ONCE here (layer 0's gate: every layer has the same shapes), not re-derived per layer
+        from_zero = bool(from_zero and self.layers[0].prefill_kernel_ok(B, S, self.dtype, self.dev))
+        if not from_zero:
             # query i (at position pos_idx[i]) sees the valid keys at positions <= pos_idx[i]: correct for a chunk that starts at pos > 0 too
             keypos = torch.arange(Lc, device=self.dev)
             mask = (keypos[None, :] <= pos_idx[:, None])[None, None] & cache["valid"][:, None, None, :]

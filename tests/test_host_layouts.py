@@ -102,3 +102,13 @@ def test_tile_major_weight_layout(N, K):
                     k0 = 128 * it + 32 * s_ + 8 * g
                     assert torch.equal(v[tile, it, s_, :, g, :], w[16 * tile:16 * tile + 16, k0:k0 + 8])
     assert torch.equal(torch.sort(t.flatten())[0], torch.sort(w.flatten())[0])
+
+
+def test_fused_norm_envelope_matches_the_kernel_side():
+    """the Python envelope of the fused RMSNorm prologue must not admit what the kernel rejects -- packed layouts of 12 / 16
+    tenants have no norm_w form (BD_PKL in csrc/bd_api.hip returns BD_E_BAD_SHAPE), so 9..16 tenants are outside it even at K = 2048."""
+    from bitdelta_amd.binary_gemm_kernel import fused_norm_ok
+    assert fused_norm_ok(8, 1, 2048) and fused_norm_ok(6, 1, 4096) and fused_norm_ok(1, 1, 8192)
+    for B in range(9, 17):
+        assert not fused_norm_ok(B, 1, 2048)
+    assert not fused_norm_ok(6, 2, 4096) and not fused_norm_ok(6, 1, 6144) and not fused_norm_ok(8, 1, 8192)
