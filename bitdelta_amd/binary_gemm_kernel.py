@@ -253,7 +253,7 @@ def fused_norm_ok(B, M, K):
 
 
 def binary_linear_decode(x, weight, mask, alpha, *, layout="tile", out_dtype=None, groups=1, residual=None,
-                         norm_weight=None, eps=1e-5, swiglu=False, weight_tiled=False):
+                         norm_weight=None, eps=1e-5, swiglu=False, weight_tiled=False, out=None):
     """binary_linear for decode shapes with repacked masks: one launch of the streaming kernel.
     x: (B, M, K), M <= 16; weight (N, K); alpha fp32 (B or 1, groups);
     layout "tile":   mask = tile_masks(...)        (B or 1, ceil(N/16), K/32, 16)
@@ -297,8 +297,12 @@ def binary_linear_decode(x, weight, mask, alpha, *, layout="tile", out_dtype=Non
             s_norm = 0 if (norm_weight.shape[0] == 1 and B > 1) else norm_weight.stride(0)
         assert not swiglu or (groups == 2 and N % 16 == 0 and residual is None and out_dtype == x.dtype)
     if residual is not None:
-        assert residual.shape == (B, M, N) and residual.dtype == out_dtype and residual.stride(2) == 1
+        assert out is None and residual.shape == (B, M, N) and residual.dtype == out_dtype and residual.stride(2) == 1
         y = residual
+    elif out is not None:                # caller-provided destination (any row / batch stride, unit column stride)
+        require_gpu(out)
+        assert out.shape == (B, M, N // 2 if swiglu else N) and out.dtype == out_dtype and out.stride(2) == 1
+        y = out
     else:
         y = torch.empty((B, M, N // 2 if swiglu else N), device=x.device, dtype=out_dtype)
     if norm_weight is not None or swiglu:

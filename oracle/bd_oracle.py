@@ -12,13 +12,16 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libbd_oracle.so")
+# BD_ORACLE_SO: an alternative build of the same source (tests/test_oracle_sanitized.py loads the ASan + UBSan build this way)
+_SO = os.environ.get("BD_ORACLE_SO") or os.path.join(_HERE, "libbd_oracle.so")
 _DT = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
 _WORD_DT = {8: torch.uint8, 16: torch.int16, 32: torch.int32, 64: torch.int64}
 
 
 def build(force=False):
     src = os.path.join(_HERE, "bd_oracle.c")
+    if os.environ.get("BD_ORACLE_SO"):
+        return _SO                      # built by whoever set the override
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return _SO

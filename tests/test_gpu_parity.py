@@ -11,8 +11,13 @@ Tolerances (BASELINE.json north star: 1e-3 relative on 16-bit, bit-exact on the 
 """
 import os
 
+import sys
+
 import pytest
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from canary import CanaryOut, canary_workspace  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -218,6 +223,20 @@ def test_delta_bmm_vs_oracle(bd, oracle, dtype, shape):
         assert ok and same >= 0.99, (ok, same)
         if dtype == torch.float16:
             assert relerr(got.cpu(), ref32)[0] <= 1e-3
+    # canaries: the same three launches into an output surrounded by >= one tile of poisoned margin on every side, with exactly the
+    # scratch bytes bd_gemm_workspace_bytes() names: nothing outside the output / the request may change, and the values are the same
+    import bitdelta_amd.binary_gemm_kernel as bgk
+    L.bd_set_gemm_variant(-1 if variant is None else variant)
+    try:
+        with canary_workspace(bgk) as (ws_ok, _):
+            for plain, od, rm in ((c32, torch.float32, 0), (c16, dtype, 0), (c16r, dtype, 1)):
+                cn = CanaryOut(B, M, N, od)
+                bd.delta_bmm(dev(a), dev(p), out=cn.view, out_dtype=od, round_mode=rm)
+                assert torch.equal(cn.result(), plain), (od, rm)
+                assert cn.untouched_outside(), ("output margin overwritten", od, rm)
+            assert ws_ok(), "wrote past bd_gemm_workspace_bytes()"
+    finally:
+        L.bd_set_gemm_variant(-1)
 
 
 # the one-pass fused kernel (variant 8, bd_binary_linear only): multi-tenant, ragged M/N, k shorter than its 3-slot ring
@@ -262,6 +281,28 @@ def test_binary_linear_vs_oracle(bd, oracle, dtype, shape):
     # not worse than the reference's own multi-rounding chain (SURVEY.md 7b iv)
     ref_chain = oracle.binary_linear(a, w, p, alpha, round_mode=1)
     assert fro16 <= relerr(ref_chain, ref32)[0] * 1.05 + 1e-7
+    # canaries (tests/canary.py): output inside poisoned margins, scratch of exactly bd_gemm_workspace_bytes(); same values, nothing else touched.
+    # Covers the ragged-M / ragged-N guarded epilogues of every tile family in LINEAR_SHAPES, the pair tiles' absent partner, the
+    # split-k slabs and the fused-residual epilogue (in place on the canary view).
+    import bitdelta_amd.binary_gemm_kernel as bgk
+    L.bd_set_gemm_variant(-1 if variant is None else variant)
+    try:
+        with canary_workspace(bgk) as (ws_ok, _):
+            for plain, od in ((y32, torch.float32), (y16, dtype)):
+                cn = CanaryOut(B, M, N, od)
+                bd.binary_linear(dev(a), dev(w), dev(p), dev(alpha), out_dtype=od, out=cn.view)
+                assert torch.equal(cn.result(), plain), od
+                assert cn.untouched_outside(), ("output margin overwritten", od)
+            cn = CanaryOut(B, M, N, dtype)
+            r = torch.randn(B, M, N).to(dtype)
+            cn.view.copy_(dev(r))
+            bd.binary_linear(dev(a), dev(w), dev(p), dev(alpha), residual=cn.view)
+            got = cn.result().cpu().float()
+            assert ((got - (r.float() + ref32)).abs() <= (r.float().abs() + ref32.abs()) * (2 ** -7 if dtype == torch.bfloat16 else 2 ** -10) + 1e-4).all()
+            assert cn.untouched_outside(), "residual epilogue wrote outside the output"
+            assert ws_ok(), "wrote past bd_gemm_workspace_bytes()"
+    finally:
+        L.bd_set_gemm_variant(-1)
 
 
 def test_pruned_ab_variants_are_refused_not_silently_replaced(bd):
@@ -689,6 +730,16 @@ def test_binary_linear_decode_layouts_vs_oracle(bd, oracle, dtype, shape):
         want = (r.float() + ref32).to(dtype)
         d = (out.cpu().float() - want.float()).abs()
         assert (d <= (r.float().abs() + ref32.abs()) * (2 ** -7 if dtype == torch.bfloat16 else 2 ** -10) + 1e-4).all()
+        # canaries: ragged N / several tenants / 16-row chunks of the streaming kernel into poisoned margins -- same bits, nothing else touched
+        for plain, od in ((y32, torch.float32), (y16, dtype)):
+            cn = CanaryOut(B, M, N, od)
+            bd.binary_linear_decode(dev(a), dev(w), m, dev(alpha), layout=layout, out_dtype=od, out=cn.view)
+            assert torch.equal(cn.result(), plain), (layout, od)
+            assert cn.untouched_outside(), ("output margin overwritten", layout, od)
+        cn = CanaryOut(B, M, N, dtype)
+        cn.view.copy_(dev(r))
+        bd.binary_linear_decode(dev(a), dev(w), m, dev(alpha), layout=layout, residual=cn.view)
+        assert torch.equal(cn.result(), out) and cn.untouched_outside(), ("residual form", layout)
 
 
 @pytest.mark.gpu

@@ -112,3 +112,33 @@ def test_fused_norm_envelope_matches_the_kernel_side():
     for B in range(9, 17):
         assert not fused_norm_ok(B, 1, 2048)
     assert not fused_norm_ok(6, 2, 4096) and not fused_norm_ok(6, 1, 6144) and not fused_norm_ok(8, 1, 8192)
+
+
+def test_canary_helper_detects_writes_outside_the_output():
+    """tests/canary.py on CPU tensors: a write one row past M, one column past N, into the next batch entry's margin or into the poisoned
+    tail of a workspace must be reported; writes inside the output must not."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from canary import CanaryOut, canary_workspace
+    for dt in (torch.bfloat16, torch.float16, torch.float32):
+        c = CanaryOut(2, 5, 7, dt, device="cpu", row_margin=3, col_margin=8)
+        c.view.copy_(torch.randn(2, 5, 7).to(dt))
+        assert c.untouched_outside() and c.result().shape == (2, 5, 7)
+        for where in ((1, 3 + 5, 8), (1, 3, 8 + 7), (1, 2, 8), (0, 4, 9), (3, 3, 8)):       # below, right, above, previous / next batch entry
+            c2 = CanaryOut(2, 5, 7, dt, device="cpu", row_margin=3, col_margin=8)
+            c2.buf[where] = 0.5
+            assert not c2.untouched_outside(), (dt, where)
+
+    class Target:
+        @staticmethod
+        def workspace(nbytes, device, zeroed=False):
+            raise AssertionError("the original allocator must not be called inside the block")
+    with canary_workspace(Target) as (ok, made):
+        buf, n = Target.workspace(1000, "cpu", zeroed=True)
+        assert n == 1000 and bool((buf[:1000] == 0).all())
+        buf[999] = 3
+        assert ok()
+        buf[1000] = 3
+        assert not ok()
+    assert Target.workspace.__qualname__.startswith("test_canary_helper")         # restored
