@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbitdelta_hip.so")
+# BD_HIP_LIB: another BUILD of the same library (same-box A/Bs of compile-time kernel switches, tools/ab_lib.sh); never a fallback
+LIB_PATH = os.environ.get("BD_HIP_LIB") or os.path.join(_HERE, "lib", "libbitdelta_hip.so")
 
 BD_F16, BD_BF16, BD_F32 = 0, 1, 2
 DTYPE_CODE = {torch.float16: BD_F16, torch.bfloat16: BD_BF16, torch.float32: BD_F32}

@@ -71,6 +71,18 @@ struct W4Cfg {
     static constexpr int STG_ROWB = JC * 32 * ESZ + 16, STG_PW = FAST_EPI ? stg_pw(JC) : 2048;
     static constexpr int LDS_BYTES = STG_OFF + NW * STG_PW;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    // OPT & 2048: TRICKLED epilogue (16-bit fast form, no residual).  The finished tile is converted to packed 16-bit values in spare VGPRs
+    // (NCH chunks of JC * 4 register pairs: 128 registers delta-only, 64 fused) and its staging writes / transpose reads / global stores are
+    // issued one small burst per k-tile INSIDE the next tile's k loop (4 k-tiles per chunk), instead of as one 10-k-cycle burst in which
+    // every CU of the chip stores its 128 KB at the same moment (32 MB at HBM write speed, MFMA pipes idle).
+    static constexpr bool TRICKLE = (OPT & 2048) != 0 && !OUT_F32 && EPI == 0 && FAST_EPI;
+    static constexpr int NCH = TM * (TN / JC);          // epilogue chunks per wave tile (32 rows x JC 32-column blocks each)
+    // trickle schedule: a group = 4 k-tiles = 8 SLOTS (two per k-tile); a slot carries ONE 1-KiB global store per wave (the CU's store path
+    // takes ~16 B/clk: stores issued back to back block the issuing wave ~260 cycles each), plus the staging traffic of the chunk(s) of
+    // the current group.  A chunk has UPC = 2 * JC store units (16-row half x 32-column block).
+    static constexpr int UPC = 2 * JC, CPG = 8 / UPC, NGRP = (NCH + CPG - 1) / CPG;
+    static_assert(UPC <= 8 && 8 % UPC == 0, "store units per chunk vs slots per group");
+    static constexpr int TRICKLE_KT = 4 * (NGRP + 1);   // k-tiles the trickle of one tile takes (stores lag the staging by one group)
     static_assert(DPW <= 24, "piece placement");
 };
 
@@ -400,6 +412,120 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, f32x16_t (&acc)
     });
 }
 
+// ---- trickled epilogue, part 1 (at the end of a tile's k loop): accumulators -> output type, packed in VGPRs.  Same value transforms, same
+//      rounding and the same (chunk, column block, quad) order as w4_epilogue's 16-bit fast form: pk[cc][jj * 4 + q] is exactly the register
+//      pair that form stages with one ds_write_b64.
+template <class Cfg>
+__device__ __forceinline__ void w4_convert(const GemmParams& p, f32x16_t (&acc)[4][Cfg::TM], u32x2_t (&pk)[Cfg::NCH][Cfg::JC * 4], char* stg,
+                                           int n0, int wn, int b, int lane, int wave) {
+    constexpr int DT = Cfg::DT, WN = Cfg::WN, TN = Cfg::TN, JC = Cfg::JC;
+    constexpr bool FUSED = Cfg::FUSED;
+    asm volatile("" : "+v"(lane));
+    const int l31 = lane & 31, h = lane >> 5;
+    char* const wr = stg + wave * Cfg::STG_PW + l31 * 64;      // chunk 0 goes straight into the (idle) staging image: 2 * JC * 4 fewer live registers
+    const int swz = (l31 >> 1) & 7;
+    const bool rm16 = !FUSED && p.round_mode == 1;
+    const float* al = FUSED ? p.alpha + (long long)b * p.sAlb : nullptr;
+    float a_col[TN];
+    if (p.gsz >= p.N) {
+        const float a0 = al ? al[0] : 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) a_col[j] = a0;
+    } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) a_col[j] = al ? al[min(n0 + wn * WN + j * 32 + l31, p.N - 1) / p.gsz] : 0.f;
+        __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0): see w4_epilogue
+    }
+    auto pack2 = [&](float lo, float hi) -> uint32_t {
+        if constexpr (DT == DT_BF16) {
+            uint32_t r;
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+            return r;
+        } else {
+            return f32_to_f16_bits(lo) | (f32_to_f16_bits(hi) << 16);
+        }
+    };
+    auto rd = [](float x) -> float {
+        float r;
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(x));
+        return r;
+    };
+    auto value = [&](auto ic, auto jc, auto rc) -> float {
+        constexpr int i = decltype(ic)::value, j = decltype(jc)::value, r = decltype(rc)::value;
+        if constexpr (FUSED) return __builtin_fmaf(a_col[j], rd(acc[2 * j + 1][i][r]), rd(acc[2 * j][i][r]));
+        else return rd(acc[j][i][r]);
+    };
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");    // MFMA result -> accvgpr_read distance for the last MFMAs of the k loop
+    static_for<0, Cfg::NCH>([&](auto cc) {
+        constexpr int i = decltype(cc)::value / (TN / JC), j0 = (decltype(cc)::value % (TN / JC)) * JC;
+        static_for<0, JC * 4>([&](auto tc) {
+            constexpr int jj = decltype(tc)::value / 4, q = decltype(tc)::value % 4, j = j0 + jj;
+            __builtin_amdgcn_sched_barrier(0);
+            float v[4];
+            v[0] = value(IC<i>{}, IC<j>{}, IC<4 * q + 0>{}); v[1] = value(IC<i>{}, IC<j>{}, IC<4 * q + 1>{});
+            v[2] = value(IC<i>{}, IC<j>{}, IC<4 * q + 2>{}); v[3] = value(IC<i>{}, IC<j>{}, IC<4 * q + 3>{});
+            if constexpr (!FUSED) { if (rm16) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = round_through_f16(v[e]);
+            } }
+            const u32x2_t pr = u32x2_t{pack2(v[0], v[1]), pack2(v[2], v[3])};
+            if constexpr (decltype(cc)::value == 0) *(u32x2_t*)(wr + (((2 * q + h) ^ swz) * 8) + jj * 2048) = pr;
+            else pk[decltype(cc)::value][decltype(tc)::value] = pr;
+        });
+    });
+}
+
+// ---- trickled epilogue, part 2: slot S (0..7) of group G of the NEXT tile's k loop (two slots per k-tile, inside the k-tile: see ktile).
+//      In group G the chunks [G * CPG, (G + 1) * CPG) are staged (transposed image, as w4_epilogue) and read back with the hardware
+//      transpose read, one 16-row x 32-column store unit per slot into rbuf[S]; the unit read in slot S of group G - 1 is stored in slot S
+//      of group G, just before rbuf[S] is re-read.  So every slot issues at most ONE global store per wave and a store unit waits a whole
+//      group (4 k-tiles) for its LDS reads.  LDS operations of one wave execute in issue order: a chunk's writes, its reads and the next
+//      chunk's writes need no waits between them.  The stores are ordinary VMEM operations retired IN ORDER with the LDS-DMA pieces: issued
+//      in the middle of a k-tile's pieces they are among the last DPW operations at that k-tile's vmcnt(DPW) (which then covers the first
+//      pieces of the look-ahead instead) and must have completed only by the NEXT k-tile's wait, ~1.4 k-tiles later.
+template <class Cfg, int S, int G>
+__device__ __forceinline__ void w4_slot(const GemmParams& p, const u32x2_t (&pk)[Cfg::NCH][Cfg::JC * 4], u32x4_t (&rbuf)[8], char* stg, int m0,
+                                        int n0, int wm, int wn, int b, bool inside, int lane, int wave) {
+    constexpr int WM = Cfg::WM, WN = Cfg::WN, TN = Cfg::TN, JC = Cfg::JC, UPC = Cfg::UPC, CPG = Cfg::CPG, NGRP = Cfg::NGRP, NCH = Cfg::NCH;
+    constexpr int ci = S / UPC, ui = S % UPC, mh = ui / JC, u = ui % JC;
+    typedef short v4s_t __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4s_t* lds_v4s_p;
+    // The (slot, group) blocks differ only in WHICH registers they touch; SimplifyCFG would sink their common tails into one block fed by
+    // phis of the pk element addresses, which turns pk into an indexed array in scratch.  An asm statement with a distinct immediate at
+    // both ends of every block cannot be merged, and nothing is sunk or hoisted across it.
+    asm volatile("; trickle slot %0 begin" ::"n"(G * 8 + S) : "memory");
+    asm volatile("" : "+v"(lane));                         // lane-derived addresses are recomputed here, never hoisted + spilled
+    char* buf = stg + wave * Cfg::STG_PW;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int Gq = lane >> 4, t = lane & 15, js = t >> 2, cs = t & 3;
+    // ---- store of the unit read one group ago
+    constexpr int cst = (G - 1) * CPG + ci;                // its chunk
+    if constexpr (G >= 1 && cst < NCH && !(Cfg::OPT & 4096)) {
+        constexpr int i = cst / (TN / JC), j0 = (cst % (TN / JC)) * JC;
+        const int mm = m0 + wm * WM + i * 32 + 16 * mh + t;
+        const int n = n0 + wn * WN + (j0 + u) * 32 + 8 * Gq;
+        if (inside || (mm < p.M && n < p.N)) *(u32x4_t*)(p.C + ((long long)b * p.sCb + (long long)mm * p.sCm + n) * 2) = rbuf[S];
+    }
+    // ---- staging of this group's chunk: writes when its first unit comes up, then this slot's transpose reads
+    constexpr int cw = G * CPG + ci;
+    if constexpr (G < NGRP && cw < NCH) {
+        if constexpr (ui == 0 && cw > 0) {                 // (chunk 0 was staged by w4_convert)
+            const int swz = (l31 >> 1) & 7;
+            static_for<0, JC * 4>([&](auto tcc) {          // (compile-time indices: pk must stay a set of registers, never an array in scratch)
+                constexpr int tc = decltype(tcc)::value, jj = tc / 4, q = tc % 4;
+                *(u32x2_t*)(buf + l31 * 64 + (((2 * q + h) ^ swz) * 8) + jj * 2048) = pk[cw][tc];
+            });
+        }
+        const uint32_t o0 = (8 * Gq + js) * 64 + (((4 * mh + cs) ^ ((4 * Gq + (js >> 1)) & 7)) * 8);
+        const uint32_t o1 = (8 * Gq + 4 + js) * 64 + (((4 * mh + cs) ^ ((4 * Gq + 2 + (js >> 1)) & 7)) * 8);
+        const v4s_t ra = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(buf + o0 + u * 2048));
+        const v4s_t rb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_p)(buf + o1 + u * 2048));
+        const u32x2_t a2 = __builtin_bit_cast(u32x2_t, ra), b2 = __builtin_bit_cast(u32x2_t, rb);
+        rbuf[S] = u32x4_t{a2.x, a2.y, b2.x, b2.y};
+    }
+    asm volatile("; trickle slot %0 end" ::"n"(G * 8 + S) : "memory");
+}
+
 template <class Cfg>
 __global__ void __launch_bounds__(256) delta_gemm_w4_kernel(const GemmParams p) {
     constexpr int DT = Cfg::DT, BM = Cfg::BM, BN = Cfg::BN, NS = Cfg::NS;
@@ -727,31 +853,88 @@ __global__ void __launch_bounds__(256) delta_gemm_w4_kernel(const GemmParams p) 
 
     // ================================================================ tile loop
     int c_slot = 0;                                   // ring slot of the k-tile being multiplied
+    // ---- trickled epilogue state: the PREVIOUS tile's outputs, packed, waiting to be staged + stored inside this tile's k loop
+    constexpr bool TRICKLE = Cfg::TRICKLE;
+    [[maybe_unused]] u32x2_t pk[Cfg::NCH][Cfg::JC * 4];
+    [[maybe_unused]] u32x4_t rbuf[8];
+    [[maybe_unused]] bool pk_live = false, pk_inside = false;
+    [[maybe_unused]] int pk_m0 = 0, pk_n0 = 0, pk_b = 0;
+    [[maybe_unused]] const bool trickle_able = TRICKLE && !p.accumulate && (p.N % 8 == 0) && (p.sCm % 8 == 0) && (p.sCb % 8 == 0) &&
+                                               (((uintptr_t)p.C & 15) == 0) && nk >= Cfg::TRICKLE_KT;
+    // slot SL (0..7) of group kq of the pending tile; wave-uniform branches only
+    auto site = [&](auto slc, int kq) __attribute__((always_inline)) {
+        if constexpr (TRICKLE) {
+            constexpr int SL = decltype(slc)::value;
+            if (pk_live && kq <= Cfg::NGRP) {
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, Cfg::NGRP + 1>([&](auto gc) {
+                    if (kq == decltype(gc)::value)
+                        w4_slot<Cfg, SL, decltype(gc)::value>(p, pk, rbuf, smem + Cfg::STG_OFF, pk_m0, pk_n0, wm, wn, pk_b, pk_inside, lane, wave);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+                if (SL == 7 && kq == Cfg::NGRP) pk_live = false;
+            }
+        }
+    };
+    // one k-tile of the multiply stream (16 regions) + the loader's step.  U = its index inside a group of four (trickle slots 2U, 2U + 1,
+    // placed after regions 2 and 8: inside the window in which the k-tile's LDS-DMA pieces are issued, see w4_slot); U < 0: no slots
+    auto ktile = [&](auto uc, int kq) __attribute__((always_inline)) {
+        constexpr int U = decltype(uc)::value;
+        const int n_slot = c_slot + 1 == NS ? 0 : c_slot + 1;
+        const uint32_t l_slot = (n_slot + 1 == NS ? 0 : n_slot + 1) * STAGE;      // k-tile c+2 goes where k-tile c-1 was
+        const char* st_cur = smem + c_slot * STAGE;
+        const char* st_nxt = smem + n_slot * STAGE;
+        BD_W4_R(0, 1); BD_W4_R(1, 1); BD_W4_R(2, 1);
+        if constexpr (U >= 0) site(IC<(U >= 0 ? 2 * U : 0)>{}, kq);
+        BD_W4_R(3, 1);
+        BD_W4_R(4, 1); BD_W4_R(5, 1); BD_W4_R(6, 1); BD_W4_R(7, 1);
+        BD_W4_R(8, 1);
+        if constexpr (U >= 0) site(IC<(U >= 0 ? 2 * U + 1 : 0)>{}, kq);
+        BD_W4_R(9, 1); BD_W4_R(10, 1); BD_W4_R(11, 1);
+        BD_W4_R(12, 1); BD_W4_R(13, 1); BD_W4_R(14, 1); BD_W4_R(15, 1);
+        loader_advance();
+        c_slot = n_slot;
+    };
     for (int r = 0;; ++r) {
         const int m0 = tm_c * BM, n0 = tn_c * BN;
         zero_acc();
         BD_W4_STAMP(r, 0);
-        for (int kt = 0; kt < nk; ++kt) {
-            const int n_slot = c_slot + 1 == NS ? 0 : c_slot + 1;
-            const uint32_t l_slot = (n_slot + 1 == NS ? 0 : n_slot + 1) * STAGE;      // k-tile c+2 goes where k-tile c-1 was
-            const char* st_cur = smem + c_slot * STAGE;
-            const char* st_nxt = smem + n_slot * STAGE;
-            BD_W4_R(0, 1); BD_W4_R(1, 1); BD_W4_R(2, 1); BD_W4_R(3, 1);
-            BD_W4_R(4, 1); BD_W4_R(5, 1); BD_W4_R(6, 1); BD_W4_R(7, 1);
-            BD_W4_R(8, 1); BD_W4_R(9, 1); BD_W4_R(10, 1); BD_W4_R(11, 1);
-            BD_W4_R(12, 1); BD_W4_R(13, 1); BD_W4_R(14, 1); BD_W4_R(15, 1);
-            loader_advance();
-            c_slot = n_slot;
+        if constexpr (TRICKLE || (Cfg::OPT & 8192)) {      // (OPT & 8192: the k loop unrolled by four on its own, no trickle -- A/B of the loop form)
+            // groups of four k-tiles, one trickle phase behind each; then the k-tiles left over (nk % 4).  Both loops have ONE exit: with
+            // an exit test after every k-tile the 256 accumulators flow out through four edges and the allocator routes them through scratch.
+            const int nk4 = nk >> 2;
+            for (int kq = 0; kq < nk4; ++kq) {
+                ktile(IC<0>{}, kq); ktile(IC<1>{}, kq); ktile(IC<2>{}, kq); ktile(IC<3>{}, kq);
 #ifdef BD_TRACE
-            if (kt == 7) BD_W4_STAMP(r, 1);
-            if (kt == 39) BD_W4_STAMP(r, 2);
+                if (kq == 1) BD_W4_STAMP(r, 1);
+                if (kq == 9) BD_W4_STAMP(r, 2);
 #endif
+            }
+            for (int kt = nk4 * 4; kt < nk; ++kt) ktile(IC<-1>{}, 0);
+        } else {
+            for (int kt = 0; kt < nk; ++kt) {
+                ktile(IC<-1>{}, 0);
+#ifdef BD_TRACE
+                if (kt == 7) BD_W4_STAMP(r, 1);
+                if (kt == 39) BD_W4_STAMP(r, 2);
+#endif
+            }
         }
         BD_W4_STAMP(r, 3);
         // ---- epilogue of tile r (the DMA of the next tile's first two k-tiles is already in flight / landed)
         int tm_n = 0, tn_n = 0, b_n = 0;
         const bool more = tile_of(r + 1, tm_n, tn_n, b_n);
-        w4_epilogue<Cfg>(p, acc, smem + Cfg::STG_OFF, m0, n0, wm, wn, b_c, lane, wave);
+        bool deferred = false;
+        if constexpr (TRICKLE) {
+            if (trickle_able && more) {
+                // another tile follows: convert now (the accumulators are about to be reused), stage + store inside its k loop
+                w4_convert<Cfg>(p, acc, pk, smem + Cfg::STG_OFF, n0, wn, b_c, lane, wave);
+                pk_live = true; pk_m0 = m0; pk_n0 = n0; pk_b = b_c;
+                pk_inside = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+                deferred = true;
+            }
+        }
+        if (!deferred) w4_epilogue<Cfg>(p, acc, smem + Cfg::STG_OFF, m0, n0, wm, wn, b_c, lane, wave);
         BD_W4_STAMP(r, 4);
         if (!more) break;
         tm_c = tm_n; tn_c = tn_n; b_c = b_n;

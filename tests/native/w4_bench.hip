@@ -146,12 +146,12 @@ int main(int argc, char** argv) {
     printf("device %s, %d CUs\n", prop.name, g_cus);
     const int N = 4096, K = 4096, Mmax = *std::max_element(Ms.begin(), Ms.end());
     unsigned short *X, *W, *C0, *C1; uint32_t* P; float* alpha; unsigned long long* dcount; float* derr; int* drows;
-    CK(hipMalloc(&X, (size_t)Mmax * K * 2)); CK(hipMalloc(&W, (size_t)11008 * K * 2)); CK(hipMalloc(&P, (size_t)(K / 32) * 11008 * 4));
-    CK(hipMalloc(&C0, (size_t)Mmax * 11008 * 2)); CK(hipMalloc(&C1, (size_t)Mmax * 11008 * 2));
+    CK(hipMalloc(&X, (size_t)Mmax * K * 2)); CK(hipMalloc(&W, (size_t)12288 * K * 2)); CK(hipMalloc(&P, (size_t)(K / 32) * 12288 * 4));
+    CK(hipMalloc(&C0, (size_t)Mmax * 12288 * 2)); CK(hipMalloc(&C1, (size_t)Mmax * 12288 * 2));
     CK(hipMalloc(&alpha, 4)); CK(hipMalloc(&dcount, 8)); CK(hipMalloc(&derr, 4)); CK(hipMalloc(&drows, 64 * 4));
     fill_bf16<<<2048, 256>>>(X, (size_t)Mmax * K, 1u, 1.0f);
-    fill_bf16<<<2048, 256>>>(W, (size_t)11008 * K, 2u, 0.02f);
-    fill_u32<<<2048, 256>>>(P, (size_t)(K / 32) * 11008, 3u);
+    fill_bf16<<<2048, 256>>>(W, (size_t)12288 * K, 2u, 0.02f);
+    fill_u32<<<2048, 256>>>(P, (size_t)(K / 32) * 12288, 3u);
     const float a_h = 4.2e-4f; CK(hipMemcpy(alpha, &a_h, 4, hipMemcpyHostToDevice));
     int rows_h[16];
     CK(hipDeviceSynchronize());
@@ -184,7 +184,7 @@ int main(int argc, char** argv) {
     if (what.rfind("soak", 0) == 0) {      // soak<variant>: run one kernel back to back for `reps` x 0.1 s (power / clock sampling from outside)
         const int M = Ms[0];
         const int v = atoi(what.c_str() + (what.rfind("soakn", 0) == 0 ? 5 : 4));
-        GemmParams p0 = params(M, N, v >= 10 && v < 20, C0);   // (fused variants: 10, 11, 12, 13)
+        GemmParams p0 = params(M, N, (v >= 10 && v < 20) || v == 31 || v == 33, C0);   // (fused variants: 10, 11, 12, 13)
         using OldD = GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 1>;
         using OldF = FxCfg<DT_BF16, 256, 128, 3, false, 1>;
         auto one = [&] {
@@ -201,6 +201,10 @@ int main(int argc, char** argv) {
             else if (v == 22) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 512>>(p0, 1, 0);   // operand-value A/B: sign LUT all zero
             else if (v == 13) launch_w4<W4Cfg<DT_BF16, 256, 128, true, false, 1 | 128>>(p0, 1, 0);    // fused, sign LUT {0, 2.0}
             else if (v == 23) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 1024>>(p0, 1, 0);  // MFMA-order A/B: X-stationary (results wrong)
+            else if (v == 30) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 2048>>(p0, 1, 0);  // trickled epilogue, delta-only
+            else if (v == 31) launch_w4<W4Cfg<DT_BF16, 256, 128, true, false, 1 | 2048>>(p0, 1, 0);   // trickled epilogue, fused
+            else if (v == 32) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 8192>>(p0, 1, 0);  // k loop unrolled by four, no trickle
+            else if (v == 33) launch_w4<W4Cfg<DT_BF16, 256, 128, true, false, 1 | 8192>>(p0, 1, 0);   // same, fused
             else if (v == 3) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 64>>(p0, 1, 0);    // split-form DMA
             else if (v == 12) launch_w4<W4Cfg<DT_BF16, 256, 128, true, false, 0>>(p0, 1, 0);         // fused, VALU sign expansion (A/B)
             else if (v == 4) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 4>>(p0, 1, 0);     // energy A/B: sign fragment in the first MFMA slot (results wrong)
@@ -221,21 +225,20 @@ int main(int argc, char** argv) {
             n += 50;
             CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&total, e0, e1));
         }
-        const double fl = (v >= 10 && v < 20 ? 4.0 : 2.0) * M * N * K;
+        const double fl = ((v >= 10 && v < 20) || v == 31 || v == 33 ? 4.0 : 2.0) * M * N * K;
         printf("soak variant %d M=%d: %lld launches in %.1f ms -> %.2f us each, %.1f TF\n", v, M, n, total, total * 1e3 / n, fl * n / (total * 1e-3) / 1e12);
         return 0;
     }
 #ifdef BD_TRACE
     for (int M : Ms) {
         printf("== trace M=%d\n", M);
-        trace_one<W4Cfg<DT_BF16, 256, 256, false, false, 0>>("w4 VALU", params(M, N, false, C1), 2.0 * M * N * K);
         trace_one<W4Cfg<DT_BF16, 256, 256, false, false, 1>>("w4 LUT", params(M, N, false, C1), 2.0 * M * N * K);
-        trace_one<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 64>>("w4 LUT split-dma", params(M, N, false, C1), 2.0 * M * N * K);
-        trace_one<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 8>>("w4 LUT no-dma", params(M, N, false, C1), 2.0 * M * N * K);
-        trace_one<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 32>>("w4 LUT no-xread", params(M, N, false, C1), 2.0 * M * N * K);
-        trace_one<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 8 | 32>>("w4 LUT neither", params(M, N, false, C1), 2.0 * M * N * K);
+        trace_one<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 2048>>("w4 LUT trickle", params(M, N, false, C1), 2.0 * M * N * K);
+        trace_one<W4Cfg<DT_BF16, 256, 128, true, false, 1 | 2048>>("w4 fused trickle", params(M, N, true, C1), 4.0 * M * N * K);
+        trace_one<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 2048 | 4096>>("w4 LUT trickle, NO stores", params(M, N, false, C1), 2.0 * M * N * K);
+        trace_one<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 8192>>("w4 LUT, k loop x4", params(M, N, false, C1), 2.0 * M * N * K);
+        trace_one<W4Cfg<DT_BF16, 256, 128, true, false, 1 | 8192>>("w4 fused, k loop x4", params(M, N, true, C1), 4.0 * M * N * K);
         trace_one<W4Cfg<DT_BF16, 256, 128, true, false, 1>>("w4 fused (LUT, shipped)", params(M, N, true, C1), 4.0 * M * N * K);
-        trace_one<W4Cfg<DT_BF16, 256, 128, true, false, 0>>("w4 fused VALU expansion", params(M, N, true, C1), 4.0 * M * N * K);
     }
     return 0;
 #endif
@@ -253,15 +256,20 @@ int main(int argc, char** argv) {
         CK(hipMemset(C1, 0xff, (size_t)M * N * 2));
         launch_w4<W4L>(p1, 1, 0);
         check("w4 LUT expansion", M, N, false, true);
-        time_it("8-wave ping-pong (pf, shipped)", [&] { launch_old<OldD>(delta_gemm_pf_kernel<OldD>, p0, 1, 0); }, reps, fl);
-        time_it("w4 VALU", [&] { launch_w4<W4V>(p1, 1, 0); }, reps, fl);
+        using W4T = W4Cfg<DT_BF16, 256, 256, false, false, 1 | 2048>;
+        CK(hipMemset(C1, 0xff, (size_t)M * N * 2));
+        launch_w4<W4T>(p1, 1, 0);
+        check("w4 LUT, trickled epilogue", M, N, false, true);
+        CK(hipMemset(C1, 0xff, (size_t)M * N * 2));
+        launch_w4<W4T>(p1, 1, 0, 100);          // 100 workgroups: 3 / 6 / 11 rounds with a ragged last one
+        check("w4 LUT, trickled, grid 100", M, N, false, true);
         time_it("w4 LUT", [&] { launch_w4<W4L>(p1, 1, 0); }, reps, fl);
-        time_it("8-wave ping-pong (pf, shipped)", [&] { launch_old<OldD>(delta_gemm_pf_kernel<OldD>, p0, 1, 0); }, reps, fl);
-        time_it("w4 VALU", [&] { launch_w4<W4V>(p1, 1, 0); }, reps, fl);
+        time_it("w4 LUT trickle", [&] { launch_w4<W4T>(p1, 1, 0); }, reps, fl);
         time_it("w4 LUT", [&] { launch_w4<W4L>(p1, 1, 0); }, reps, fl);
+        time_it("w4 LUT trickle", [&] { launch_w4<W4T>(p1, 1, 0); }, reps, fl);
     }
     if (what == "all" || what == "fused") {
-        const int shapes[][2] = {{2048, 4096}, {2048, 11008}, {4096, 4096}, {8192, 4096}};
+        const int shapes[][2] = {{2048, 4096}, {2048, 11008}, {2048, 12288}, {8192, 4096}};
         for (auto& sh : shapes) {
             const int M = sh[0], Nn = sh[1];
             if (M > Mmax) continue;
@@ -274,10 +282,17 @@ int main(int argc, char** argv) {
             CK(hipMemset(C1, 0xff, (size_t)M * Nn * 2));
             launch_w4<W4F>(p1, 1, 0);
             check("w4 fused", M, Nn, true, true);
-            time_it("8-wave one-pass fused (fx, shipped)", [&] { launch_old<OldF>(delta_gemm_fx_kernel<OldF>, p0, 1, 0); }, reps, fl);
+            using W4FT = W4Cfg<DT_BF16, 256, 128, true, false, 1 | 2048>;
+            CK(hipMemset(C1, 0xff, (size_t)M * Nn * 2));
+            launch_w4<W4FT>(p1, 1, 0);
+            check("w4 fused, trickled epilogue", M, Nn, true, true);
+            CK(hipMemset(C1, 0xff, (size_t)M * Nn * 2));
+            launch_w4<W4FT>(p1, 1, 0, 100);
+            check("w4 fused, trickled, grid 100", M, Nn, true, true);
             time_it("w4 fused", [&] { launch_w4<W4F>(p1, 1, 0); }, reps, fl);
-            time_it("8-wave one-pass fused (fx, shipped)", [&] { launch_old<OldF>(delta_gemm_fx_kernel<OldF>, p0, 1, 0); }, reps, fl);
+            time_it("w4 fused trickle", [&] { launch_w4<W4FT>(p1, 1, 0); }, reps, fl);
             time_it("w4 fused", [&] { launch_w4<W4F>(p1, 1, 0); }, reps, fl);
+            time_it("w4 fused trickle", [&] { launch_w4<W4FT>(p1, 1, 0); }, reps, fl);
         }
     }
     return 0;

@@ -293,13 +293,14 @@ def test_binary_linear_vs_oracle(bd, oracle, dtype, shape):
                 bd.binary_linear(dev(a), dev(w), dev(p), dev(alpha), out_dtype=od, out=cn.view)
                 assert torch.equal(cn.result(), plain), od
                 assert cn.untouched_outside(), ("output margin overwritten", od)
-            cn = CanaryOut(B, M, N, dtype)
-            r = torch.randn(B, M, N).to(dtype)
-            cn.view.copy_(dev(r))
-            bd.binary_linear(dev(a), dev(w), dev(p), dev(alpha), residual=cn.view)
-            got = cn.result().cpu().float()
-            assert ((got - (r.float() + ref32)).abs() <= (r.float().abs() + ref32.abs()) * (2 ** -7 if dtype == torch.bfloat16 else 2 ** -10) + 1e-4).all()
-            assert cn.untouched_outside(), "residual epilogue wrote outside the output"
+            if variant is None or variant in (8, 9, 11, 12, 14, 16, 17) or variant >= 200:      # families with a residual epilogue (bd_api.hip)
+                cn = CanaryOut(B, M, N, dtype)
+                r = torch.randn(B, M, N).to(dtype)
+                cn.view.copy_(dev(r))
+                bd.binary_linear(dev(a), dev(w), dev(p), dev(alpha), residual=cn.view)
+                got = cn.result().cpu().float()
+                assert ((got - (r.float() + ref32)).abs() <= (r.float().abs() + ref32.abs()) * (2 ** -7 if dtype == torch.bfloat16 else 2 ** -10) + 1e-4).all()
+                assert cn.untouched_outside(), "residual epilogue wrote outside the output"
             assert ws_ok(), "wrote past bd_gemm_workspace_bytes()"
     finally:
         L.bd_set_gemm_variant(-1)
