@@ -17,6 +17,8 @@ Prints ONE JSON line (rank 0) with the driver contract fields plus
   delta_gemm    the W1A16 delta-GEMM alone at K = N = 4096, M in {4096, 8192, 16384} (the north star's 70 %-of-peak target), same method
   vendor_gemm   the vendor's bf16 GEMM (torch.matmul -> hipBLASLt) at the same three shapes, same process, same warm-up: the
                 calibration row for "what fraction of 2.5 PF does ANY dense bf16 GEMM reach on this board at its power cap"
+  published_shapes  the reference's own published kernel benchmark shapes (M in {1, 16}, B in {1, 8, 16}, N = K in {4096, 8192},
+                fp16) through binary_matmul / binary_bmm, TFLOP/s in the reference's convention beside the published figure + mask GB/s
   decode_7b     SURVEY.md 8(d) C2 "plus decode steps": Llama-2-7B + ONE delta, single-sequence greedy decode tokens/s (hipGraph)
   mt_decode     BASELINE.json configs[2] in the same run: Mistral-7B base + 6 tenant deltas, batched greedy decode through the
                 serving loop (fused q+k+v / gate+up launches, per-tenant embedding / norms / lm_head, argmax feedback, KV cache),
@@ -367,6 +369,96 @@ def delta_gemm_microbench(dev, Ms=(4096, 8192, 16384), N=4096, K=4096, iters=100
     return rows
 
 
+# the reference's only published kernel numbers (notebooks/binary_gemm_kernel_triton.ipynb; fp16, Triton 2.0 kernel,
+# unnamed NVIDIA GPU), TFLOP/s with its `2*B*M*N*K / t` convention.  (kind, B, M, N = K) -> published TFLOP/s, notebook line
+PUBLISHED_SHAPES = [
+    ("binary_matmul", 1, 1, 4096, 0.341, "ipynb:595"), ("binary_matmul", 1, 1, 8192, 0.683, "ipynb:603"),
+    ("binary_matmul", 1, 16, 4096, 5.46, "ipynb:677"), ("binary_matmul", 1, 16, 8192, 10.92, "ipynb:685"),
+    ("binary_bmm", 16, 1, 4096, 2.43, "ipynb:759"), ("binary_bmm", 16, 1, 8192, 2.59, "ipynb:767"),
+    ("binary_bmm", 8, 1, 4096, 1.61, "ipynb:935"), ("binary_bmm", 8, 1, 8192, 2.50, "ipynb:943"),
+    ("binary_bmm", 1, 1, 4096, 0.260, "ipynb:1036"), ("binary_bmm", 1, 1, 8192, 0.533, "ipynb:1044"),
+]
+
+
+def published_shapes_block(dev, iters=100, warmup=20):
+    """The reference's published benchmark shapes, re-measured with the SHIPPED library through the reference's Python surface
+    (`binary_matmul` / `binary_bmm`, fp16, masks pre-packed as `ipynb:630`): `warmup` launches, then `iters` launches each between two
+    HIP events on the launch stream, median.  TFLOP/s in the reference's own convention next to its published figure (other hardware:
+    not like-for-like), plus what the shape is bound by here: the sign words are read once, so mask bytes / time against the 8 TB/s HBM
+    roofline (`frac_of_hbm_peak` counts masks + activations + outputs)."""
+    import bitdelta_amd as bd
+    from bitdelta_amd import _lib
+    rows = []
+    for kind, B, M, NK, pub, src in PUBLISHED_SHAPES:
+        g = torch.Generator(device=dev).manual_seed(B * 1000 + M * 10 + NK)
+        masks = torch.randint(-2 ** 31, 2 ** 31 - 1, (B, NK // 32, NK), device=dev, generator=g, dtype=torch.int64).to(torch.int32)
+        if kind == "binary_matmul":
+            a = torch.randn(M, NK, device=dev, generator=g).half()
+            b = masks[0].contiguous()
+            fn = lambda: bd.binary_matmul(a, b)
+        else:
+            a = torch.randn(B, M, NK, device=dev, generator=g).half()
+            b = masks
+            fn = lambda: bd.binary_bmm(a, b)
+        for _ in range(warmup):
+            fn()
+        evs = []
+        for _ in range(iters):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        ts = sorted(x.elapsed_time(y) for x, y in evs)
+        eager_us = ts[len(ts) // 2] * 1e3              # one call from Python: host-bound below ~20 us (ctypes + torch.empty per call)
+        # device time: `per` calls captured into ONE hipGraph, replayed; per-call time = replay time / per (includes the launch boundaries)
+        per, graph_us, graph_err = 20, None, None
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                fn()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=side):
+                for _ in range(per):
+                    fn()
+            for _ in range(3):
+                gr.replay()
+            reps = []
+            for _ in range(max(iters // per, 5)):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                gr.replay()
+                e1.record()
+                reps.append((e0, e1))
+            torch.cuda.synchronize()
+            rt = sorted(x.elapsed_time(y) for x, y in reps)
+            graph_us = rt[len(rt) // 2] * 1e3 / per
+            del gr
+        except Exception as e:                           # capture refused: the eager figure stands
+            torch.cuda.synchronize()
+            graph_err = f"{type(e).__name__}: {e}"
+        med_us = graph_us if graph_us is not None else eager_us
+        flops = 2.0 * B * M * NK * NK
+        mask_bytes = B * NK * NK / 8.0
+        all_bytes = mask_bytes + 2.0 * B * M * NK + 2.0 * B * M * NK
+        rows.append({"op": kind, "B": B, "M": M, "N": NK, "K": NK, "dtype": "f16", "us": med_us, "eager_us_from_python": eager_us,
+                     "timed_as": f"hipGraph of {per} calls" if graph_us is not None else "eager calls", "graph_error": graph_err,
+                     "tflops": flops / med_us * 1e-6, "published_tflops": pub, "published_source": src,
+                     "ratio_to_published": flops / med_us * 1e-6 / pub, "mask_gbs": mask_bytes / med_us * 1e-3,
+                     "frac_of_hbm_peak": all_bytes / med_us * 1e-3 / PEAK_HBM_GBS,
+                     "kernel_variant": _lib.lib().bd_last_gemm_variant()})
+        del masks, a, b
+    return {"what": "reference's published benchmark shapes (BASELINE.md section 1) through binary_matmul / binary_bmm of the shipped library; "
+                    "published figures: fp16 Triton kernel on an unnamed NVIDIA GPU -- shown beside, not like-for-like",
+            "method": f"{warmup} warm-up calls; `us` = device time per call inside a replayed hipGraph of 20 calls (median of replays); "
+                      f"eager_us_from_python = one call between two events ({iters} calls, median; host-bound for the small shapes); "
+                      "TFLOP/s = 2*B*M*N*K / t (the reference's convention)",
+            "rows": rows}
+
+
 def vendor_gemm_microbench(dev, Ms=(4096, 8192, 16384), N=4096, K=4096, iters=100, warmup=100):
     """Calibration of the 2.5 PF denominator: the vendor's dense bf16 GEMM (torch.matmul -> hipBLASLt) at the delta-GEMM's shapes,
     [M, 4096] x [4096, 4096]^T, same process, same 100 + 100 launches, each launch between two HIP events on the launch stream.  It
@@ -686,6 +778,7 @@ def main():
         **bdd.runtime_info(),
         "delta_gemm": mb,
         "vendor_gemm": vendor_gemm_microbench(dev),
+        "published_shapes": published_shapes_block(dev),
         "linear_params": lin_params,
     }
     if world == 1 and not args.no_mt_decode:

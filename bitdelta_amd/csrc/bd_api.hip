@@ -982,23 +982,25 @@ int dispatch3(const Problem& q) {
         case 9:      // one-pass fused, 128x128 tile, 4-slot ring: twice the tiles when 256x128 cannot fill the CUs (128 < M <~ 768)
             if constexpr (FUSED) return launch_tile<FxCfg<DT, 128, 128, 4, OUT_F32, 1>, 3>(q);
             else return BD_E_BAD_SHAPE;
+        // (W4Cfg OPT = 1 | 8192: LUT sign expansion + the k loop unrolled by four -- bit-identical outputs, -3.6 / -5.5 % cycles per k-tile,
+        //  +0.6 % on the timed prefill step in a same-box A/B of two library builds; profiles/r05_w4_cycles.txt)
         case 13:     // four-wave persistent delta-only kernel, 256x256 tile, LUT sign expansion (bd_gemm_w4.h)
-            if constexpr (!FUSED) return launch_w4<W4Cfg<DT, 256, 256, false, OUT_F32, 1>>(q);
+            if constexpr (!FUSED) return launch_w4<W4Cfg<DT, 256, 256, false, OUT_F32, 1 | 8192>>(q);
             else return BD_E_BAD_SHAPE;
         case 14:     // four-wave persistent one-pass fused kernel, 256x128 tile, LUT sign expansion (+1.5 % over VALU expansion, same box)
             if constexpr (FUSED) {
                 if constexpr (!OUT_F32) {
                     const int cols = (g_forced_variant < 0 && g_tail_split) ? fused_tail_split_cols(q) : -1;
                     if (cols > 0) {
-                        const int rc = launch_w4<W4Cfg<DT, 256, 128, true, false, 1>>(q, cols);
+                        const int rc = launch_w4<W4Cfg<DT, 256, 128, true, false, 1 | 8192>>(q, cols);
                         if (rc != BD_OK) return rc;
                         return launch_tile<FxCfg<DT, 128, 128, 4, false, 1>, 3>(q, cols);      // same 128-wide tile columns
                     }
                 }
-                return launch_w4<W4Cfg<DT, 256, 128, true, OUT_F32, 1>>(q);      // (fp32 output: general-form epilogue only)
+                return launch_w4<W4Cfg<DT, 256, 128, true, OUT_F32, 1 | 8192>>(q);      // (fp32 output: general-form epilogue only)
             } else return BD_E_BAD_SHAPE;
         case 15:     // 14 with the SwiGLU epilogue (bd_binary_linear_swiglu: 8-interleaved gate|up pair, C has N/2 columns)
-            if constexpr (FUSED && !OUT_F32) return launch_w4<W4Cfg<DT, 256, 128, true, false, 1, 1>>(q);
+            if constexpr (FUSED && !OUT_F32) return launch_w4<W4Cfg<DT, 256, 128, true, false, 1 | 8192, 1>>(q);
             else return BD_E_BAD_SHAPE;
         case 1: return launch_tile<GemmCfg<DT, 128, 256, 1, 4, 4, FUSED, OUT_F32>>(q);
         case 2: return launch_tile<GemmCfg<DT, 64, 256, 1, 4, 4, FUSED, OUT_F32>>(q);

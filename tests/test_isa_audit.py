@@ -55,11 +55,12 @@ def test_mfma_loop_waits_and_fillers(kernels):
     _, ks = kernels
     for name, body in ks.items():
         idx = [i for i, l in enumerate(body) if "v_mfma_f32_32x32x16_bf16" in l]
-        assert len(idx) == 64, (name, len(idx))                      # one k-tile = 16 regions x 4 MFMAs, not unrolled further
+        # one k-tile = 16 regions x 4 MFMAs; the shipped form (OPT & 8192) unrolls the k loop by four and keeps one rolled copy for nk % 4
+        assert len(idx) == 5 * 64, (name, len(idx))
         loop = body[idx[0]:idx[-1] + 1]
         fused = "ELb1E" in name
         waits = [l.strip() for l in loop if "vmcnt" in l]
-        assert waits == [f"s_waitcnt vmcnt({13 if fused else 10})"], (name, waits)
+        assert waits == [f"s_waitcnt vmcnt({13 if fused else 10})"] * 5, (name, waits)
         gaps, cur = [], 0
         for l in loop[1:]:
             if "v_mfma" in l:
@@ -67,7 +68,12 @@ def test_mfma_loop_waits_and_fillers(kernels):
                 cur = 0
             elif isa_gaps.is_instr(l):
                 cur += 1
-        assert sum(gaps) / len(gaps) <= 3.0 and max(gaps) <= 12, (name, sum(gaps) / len(gaps), max(gaps))
+        # between two k-tile copies the layout holds the loader's once-per-tile slow path (next tile's coordinates: ~300 scalar
+        # instructions the hot path branches over): at most one such block per copy boundary; every other gap is an MFMA shadow
+        cold = [g for g in gaps if g > 100]
+        hot = [g for g in gaps if g <= 100]
+        assert len(cold) <= 5, (name, cold)
+        assert sum(hot) / len(hot) <= 3.0 and max(hot) <= 12, (name, sum(hot) / len(hot), max(hot))
         # accumulators live in AGPRs, operands in VGPRs
         assert all(re.search(r"v_mfma_f32_32x32x16_bf16 a\[\d+:\d+\], v\[", body[i]) for i in idx), name
 
