@@ -38,6 +38,8 @@ SIGNATURES = {
     "bd_srv_swiglu": (_ci, [_vp, _vp, _vp, _ci, _ci, _i64, _i64, _i64, _ci, _ci, _vp]),
     "bd_binary_linear_decode_fused": (_ci, [_vp, _vp, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _ci,
                                             _i64, _i64, _ci, _ci, _ci, _vp, _i64, ctypes.c_float, _ci, _vp]),
+    "bd_binary_linear_decode_handoff": (_ci, [_vp, _vp, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _ci,
+                                              _i64, _i64, _ci, _ci, _ci, _vp, _i64, ctypes.c_float, _ci, _vp, _vp, _vp, _vp]),
     "bd_srv_rope": (_ci, [_vp, _vp, _vp, _ci, _ci, _ci, _i64, _ci, _ci, _ci, _vp]),
     "bd_srv_decode_attention": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _i64, _i64, _ci, _vp, _i64, _vp]),
     "bd_srv_decode_attention_workspace_bytes": (_i64, [_ci, _ci, _ci, _ci, _ci]),

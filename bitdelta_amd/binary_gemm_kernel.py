@@ -252,8 +252,16 @@ def fused_norm_ok(B, M, K):
     return M == 1 and B <= 8 and K >= 2048 and K & (K - 1) == 0 and B * K <= 16 * 2048 and 83968 + B * (2 * K + 16) <= 160 * 1024
 
 
+def handoff_ok(B, M, K):
+    """envelope of the RMSNorm hand-off consumer of bd_binary_linear_decode_handoff (include/bitdelta_hip.h): the resident-row form"""
+    nit = (K + 127) // 128
+    return (M == 1 and B <= 8 and K >= 2048 and K % 128 == 0 and 3 * ((nit + 3) // 4) < nit and B * K <= 16 * 2048 and
+            83968 + B * (2 * K + 16) <= 160 * 1024)
+
+
 def binary_linear_decode(x, weight, mask, alpha, *, layout="tile", out_dtype=None, groups=1, residual=None,
-                         norm_weight=None, eps=1e-5, swiglu=False, weight_tiled=False, out=None):
+                         norm_weight=None, eps=1e-5, swiglu=False, weight_tiled=False, out=None, ssq_in=None, ssq_out=None,
+                         xw_out=None):
     """binary_linear for decode shapes with repacked masks: one launch of the streaming kernel.
     x: (B, M, K), M <= 16; weight (N, K); alpha fp32 (B or 1, groups);
     layout "tile":   mask = tile_masks(...)        (B or 1, ceil(N/16), K/32, 16)
@@ -261,7 +269,13 @@ def binary_linear_decode(x, weight, mask, alpha, *, layout="tile", out_dtype=Non
     Packed layout only: norm_weight (B or 1, K) fuses the HF RMSNorm of x (x = the un-normalised residual stream) into the launch;
     weight_tiled=True: `weight` is tile_weight(W) (M == 1, N % 16 == 0, K % 128 == 0);
     swiglu=True (with or without norm_weight) treats weight/mask as a gate|up pair interleaved in blocks of 8 output rows, alpha (B or 1, 2) =
-    (gate, up) scales, and returns act_fn(gate) * up, (B, M, N/2).  Both bit-identical to the separate launches."""
+    (gate, up) scales, and returns act_fn(gate) * up, (B, M, N/2).  Both bit-identical to the separate launches.
+    RMSNorm hand-off (bd_binary_linear_decode_handoff; packed layout, M == 1, B <= 8, tile-major weight):
+      ssq_out: fp32 (N/16, 16) buffer -- the launch (a residual Linear: o_proj / down_proj) also writes its output's per-row sums of squares,
+               16 columns at a time; with xw_out (B, M, N) and norm_weight = the weight of the RMSNorm that FOLLOWS, also the pre-multiplied
+               copy round(y * norm_weight);
+      ssq_in:  the buffer the PREVIOUS launch filled -- x is that launch's xw_out, 1/rms scales the accumulators: no stand-alone norm launch,
+               no per-block reduction, no multiply (`handoff_ok`); norm_weight must be None."""
     require_gpu(x, weight, mask, alpha, residual, norm_weight)
     B, M, K = x.shape
     N = weight.shape[0]
@@ -288,7 +302,23 @@ def binary_linear_decode(x, weight, mask, alpha, *, layout="tile", out_dtype=Non
     assert alpha.shape[0] in (1, B)
     sAlb = 0 if alpha.shape[0] == 1 else groups
     s_norm = 0
-    if norm_weight is not None or swiglu:
+    handoff = ssq_in is not None or ssq_out is not None
+    if handoff:
+        require_gpu(ssq_in, ssq_out, xw_out)
+        assert layout == "packed" and M == 1 and B <= 8 and (ssq_in is None or ssq_out is None)
+        for t_, cols in ((ssq_in, K), (ssq_out, N)):
+            assert t_ is None or (t_.dtype == torch.float32 and t_.is_contiguous() and t_.shape == (cols // 16, 16) and cols % 16 == 0)
+        if ssq_in is not None:        # x = the producer's pre-multiplied copy: no norm weight here
+            assert weight_tiled and handoff_ok(B, M, K) and xw_out is None and norm_weight is None and K <= 8192
+        if ssq_out is not None:
+            assert not swiglu and out_dtype == x.dtype and (xw_out is None) == (norm_weight is None)
+            if xw_out is not None:          # norm_weight = the NEXT norm's weight, over this launch's OUTPUT columns
+                assert xw_out.shape == (B, M, N) and xw_out.dtype == x.dtype and xw_out.stride(2) == 1
+                assert norm_weight.dim() == 2 and norm_weight.shape[1] == N and norm_weight.shape[0] in (1, B)
+                assert norm_weight.dtype == x.dtype and norm_weight.stride(1) == 1
+    else:
+        assert xw_out is None
+    if (norm_weight is not None and ssq_out is None) or swiglu:
         assert layout == "packed" and M == 1
         if norm_weight is not None:
             assert fused_norm_ok(B, M, K)
@@ -305,6 +335,18 @@ def binary_linear_decode(x, weight, mask, alpha, *, layout="tile", out_dtype=Non
         y = out
     else:
         y = torch.empty((B, M, N // 2 if swiglu else N), device=x.device, dtype=out_dtype)
+    if handoff:
+        if xw_out is not None:
+            assert xw_out.stride(0) == y.stride(0) and xw_out.stride(1) == y.stride(1), "xw_out uses the output's strides"
+            s_norm = 0 if (norm_weight.shape[0] == 1 and B > 1) else norm_weight.stride(0)
+        with torch.cuda.device(x.device):
+            check(lib().bd_binary_linear_decode_handoff(ptr(x), ptr(weight), ptr(mask), t_pad, ptr(alpha), ptr(y), B, M, N, K,
+                                                        x.stride(0), x.stride(1), ldw, sPb, sAlb, groups, y.stride(0),
+                                                        y.stride(1), DTYPE_CODE[x.dtype], DTYPE_CODE[out_dtype],
+                                                        1 if residual is not None else 0, ptr(norm_weight), s_norm, float(eps),
+                                                        1 if swiglu else 0, ptr(ssq_in), ptr(ssq_out), ptr(xw_out), stream_ptr()),
+                  "binary_linear_decode_handoff")
+        return y
     if norm_weight is not None or swiglu:
         with torch.cuda.device(x.device):
             check(lib().bd_binary_linear_decode_fused(ptr(x), ptr(weight), ptr(mask), t_pad, ptr(alpha), ptr(y), B, M, N, K,

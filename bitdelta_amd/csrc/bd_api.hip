@@ -141,6 +141,11 @@ struct Problem {
     int64_t sNw;
     float eps;
     int epilogue;             // layout 2 only: 1 = SwiGLU over an 8-interleaved gate|up projection (C has N/2 columns)
+    const float* ssq_in;      // layout 2 only: RMSNorm hand-off, consumer side (with norm_w): per-row partial sums of squares [K/16][16]
+    float* ssq_out;           // layout 2 only: RMSNorm hand-off, producer side: this launch writes its output's partial sums [N/16][16]
+    const void* nw_next;      // ... producer with xw_out: the NEXT RMSNorm's weight [B or 1, N] (stride sNwNext) and the pre-multiplied copy
+    int64_t sNwNext;
+    void* xw_out;
     void* ws;
     int64_t ws_bytes;
     hipStream_t st;
@@ -432,12 +437,14 @@ int launch_gemv_stream_chunk(const Problem& q) {
     sp.prs = q.mask_tiled == 1 ? 16u : (uint32_t)q.N;
     sp.tp = (uint32_t)q.t_pad;
     sp.nw = (const unsigned short*)q.norm_w; sp.sNw = q.sNw; sp.eps = q.eps;
+    sp.ssq_in = q.ssq_in; sp.ssq_out = q.ssq_out;
+    sp.nw_next = (const unsigned short*)q.nw_next; sp.sNwNext = q.sNwNext; sp.xw_out = (unsigned short*)q.xw_out;
     sp.no_res_prefetch = (g_stream_tune & 1024) ? 1 : 0;
     sp.n_bytes = q.norm_w ? (uint32_t)(((int64_t)(q.B - 1) * q.sNw + q.K) * 2) : 0u;
     sp.xs_off = (uint32_t)STREAM_XS_OFF; sp.xrow = (uint32_t)q.K * 2u + 16u;
     sp.jsh = 0;
     while ((2048 << sp.jsh) < q.K) ++sp.jsh;
-    if (q.epilogue == 1) { cpb = (cpb + 15) & ~15; sp.cpb = cpb; }      // whole [8 gate | 8 up] tiles per block
+    if (q.epilogue == 1 || q.ssq_out) { cpb = (cpb + 15) & ~15; sp.cpb = cpb; }      // whole [8 gate | 8 up] tiles / whole hand-off tiles per block
     const unsigned grid = (unsigned)((q.N + cpb - 1) / cpb);
     sp.x_bytes = (uint32_t)(((int64_t)(q.B - 1) * q.sAb + (int64_t)(q.M - 1) * q.sAm + q.K) * 2);
     sp.w_bytes = q.W ? (uint32_t)(((int64_t)(q.N - 1) * q.ldw + q.K) * 2) : 0u;
@@ -479,9 +486,27 @@ int launch_gemv_stream_chunk(const Problem& q) {
         // zero sign words expand to -1 fragments -- harmless against the zero activation fragments of the per-stage form, NOT against
         // fragments read from the resident rows (K = 1152: 9 iterations over 4 waves leave the last wave empty).
         const int nit_x = (q.K + 127) / 128;
-        const bool xres_ok = q.w_tiled && !q.norm_w && q.M == 1 && q.t_pad <= 8 && q.K >= 1024 && 3 * ((nit_x + 3) / 4) < nit_x &&
+        const bool xres_ok = q.w_tiled && (!q.norm_w || q.ssq_in) && q.M == 1 && q.t_pad <= 8 && q.K >= 1024 && 3 * ((nit_x + 3) / 4) < nit_x &&
                              (int64_t)q.B * q.K <= 16 * 2048 &&
                              (int64_t)STREAM_XS_OFF + (int64_t)q.B * (2 * (int64_t)q.K + 16) <= STREAM_LDS_MAX;
+        if (q.ssq_in) {
+            // RMSNorm by hand-off (XL = 3): the resident-row form with the rows pre-multiplied by the norm weight and the row scale in the
+            // epilogue; same envelope as the resident rows, nothing else implements it
+            if (!xres_ok) return BD_E_BAD_SHAPE;
+#define BD_XH(NM) rc = q.epilogue == 1 ? launch_stream_inst<DT, NM, true, 2, 4, 1, 2, 1, 3, 1, 1>(sp, dim3(grid), q.st)   \
+                                       : launch_stream_inst<DT, NM, true, 2, 4, 1, 2, 1, 3, 0, 1>(sp, dim3(grid), q.st)
+            switch (q.t_pad) {
+                case 1: BD_XH(1); break;
+                case 2: BD_XH(2); break;
+                case 4: BD_XH(4); break;
+                case 6: BD_XH(6); break;
+                case 8: BD_XH(8); break;
+                default: return BD_E_BAD_SHAPE;
+            }
+#undef BD_XH
+            if (rc != BD_OK) return rc;
+            return launch_status();
+        }
         // Default: wherever it applies.  (Until the prefetch depths came down to 2 stages this form lost on short launches -- at 6 stages the
         // 4096 x 4096 o projection of a 6-tenant step was +25 % -- and was dispatched by size; at 2 stages it wins on every eligible launch:
         // 6 tenants 4.805 -> 4.770 ms per step with o included, profiles/r04_decode_step_ab.txt.)
@@ -1123,7 +1148,8 @@ static int binary_linear_impl(const void* X, const void* W, const int32_t* P, co
                               int N, int K, int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb, int64_t sAlb, int G,
                               int64_t sYb, int64_t sYm, int dtype, int out_dtype, int accumulate, int mask_tiled, int t_pad,
                               void* ws, int64_t ws_bytes, void* stream, const void* norm_w = nullptr, int64_t sNw = 0,
-                              float eps = 0.f, int epilogue = 0) {
+                              float eps = 0.f, int epilogue = 0, const float* ssq_in = nullptr, float* ssq_out = nullptr,
+                              void* xw_out = nullptr) {
     if (B > 0 && M > 0 && N > 0 && !W) return BD_E_NULL;
     Problem q{};
     q.A = X; q.P = P; q.C = Y; q.W = W; q.alpha = alpha;
@@ -1138,13 +1164,27 @@ static int binary_linear_impl(const void* X, const void* W, const int32_t* P, co
         q.ldw = K;            // (extent checks below; the kernel does not use it)
     }
     q.norm_w = norm_w; q.sNw = sNw; q.eps = eps; q.epilogue = epilogue;
+    q.ssq_in = ssq_in; q.ssq_out = ssq_out;
+    if (ssq_in || ssq_out || xw_out) {
+        // RMSNorm hand-off (gemv_stream_kernel, StreamParams::ssq_in / ssq_out / xw_out): packed layout, one row per tenant, <= 8 tenants
+        if (mask_tiled != 2 || M != 1 || B > 8 || (ssq_in && ssq_out)) return BD_E_BAD_SHAPE;
+        if (ssq_in && (norm_w || !aligned16(ssq_in) || K % 16 || K > 16 * 256 * 2)) return BD_E_BAD_SHAPE;   // (X = the producer's pre-multiplied copy)
+        if (ssq_out && (N % 16 || out_dtype == BD_F32 || epilogue || !aligned16(ssq_out))) return BD_E_BAD_SHAPE;
+        if (xw_out && (!ssq_out || !norm_w || sNw < 0)) return BD_E_BAD_SHAPE;
+        if (ssq_out && norm_w && !xw_out) return BD_E_BAD_SHAPE;
+        if (ssq_out) {            // the producer's norm_w is the NEXT norm's weight (epilogue multiply), not a prologue on its own input
+            q.nw_next = norm_w; q.sNwNext = sNw; q.xw_out = xw_out;
+            q.norm_w = nullptr; norm_w = nullptr;
+        }
+    }
     if (norm_w || epilogue) {
         // fused prologue / epilogue of the packed streaming kernel: see gemv_stream_kernel (XL, EPI)
         if (mask_tiled != 2 || (epilogue != 0 && epilogue != 1)) return BD_E_BAD_SHAPE;
         if (norm_w) {
             if (!aligned16(norm_w) || sNw % 8 || sNw < 0) return BD_E_BAD_SHAPE;
             // one row per tenant (M == 1: the decode step), K = 2048 * 2^s, all rows in 16 x 16-byte chunks per thread
-            if (M != 1 || K < 2048 || (K & (K - 1)) || (int64_t)B * K > 16 * 2048) return BD_E_BAD_SHAPE;
+            // (the hand-off form needs no power of two: its copy is flat)
+            if (M != 1 || K < 2048 || (!ssq_in && (K & (K - 1))) || (int64_t)B * K > 16 * 2048) return BD_E_BAD_SHAPE;
             if ((int64_t)STREAM_XS_OFF + (int64_t)B * M * (2 * (int64_t)K + 16) > STREAM_LDS_MAX) return BD_E_BAD_SHAPE;
             if ((int64_t)(B - 1) * sNw + K >= (1ll << 30)) return BD_E_BAD_SHAPE;
         }
@@ -1215,6 +1255,17 @@ extern "C" int bd_binary_linear_decode_fused(const void* X, const void* W, const
     if (B < 1 || M < 1 || N < 1 || K < 1) return BD_E_BAD_SHAPE;
     return binary_linear_impl(X, W, P, alpha, Y, B, M, N, K, sXb, sXm, ldw, sPb, sAlb, G, sYb, sYm, dtype, out_dtype, accumulate, 2,
                               t_pad, nullptr, 0, stream, norm_w, s_norm, eps, epilogue);
+}
+
+extern "C" int bd_binary_linear_decode_handoff(const void* X, const void* W, const int32_t* P, int t_pad, const float* alpha, void* Y,
+                                               int B, int M, int N, int K, int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb,
+                                               int64_t sAlb, int G, int64_t sYb, int64_t sYm, int dtype, int out_dtype,
+                                               int accumulate, const void* norm_w, int64_t s_norm, float eps, int epilogue,
+                                               const float* ssq_in, float* ssq_out, void* xw_out, void* stream) {
+    if (!ssq_in && !ssq_out) return BD_E_NULL;
+    if (B < 1 || M < 1 || N < 1 || K < 1) return BD_E_BAD_SHAPE;
+    return binary_linear_impl(X, W, P, alpha, Y, B, M, N, K, sXb, sXm, ldw, sPb, sAlb, G, sYb, sYm, dtype, out_dtype, accumulate, 2,
+                              t_pad, nullptr, 0, stream, norm_w, s_norm, eps, epilogue, ssq_in, ssq_out, xw_out);
 }
 
 extern "C" int bd_binary_linear_residual(const void* X, const void* W, const int32_t* P, const float* alpha, void* Y, int B,

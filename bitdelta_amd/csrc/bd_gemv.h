@@ -71,6 +71,24 @@ template <int DT> __device__ __forceinline__ void store_out_residual(const GemvP
     else ((unsigned short*)p.C)[off] = (unsigned short)f32_to_half_bits<DT>(v);
 }
 
+// The two 16-bit stores above, returning the value AS STORED (rounded to the output type): the RMSNorm hand-off of the streaming decode
+// kernel sums its square (bd_gemv_stream.h, StreamParams::ssq_out).  16-bit outputs only (host-checked).
+template <int DT> __device__ __forceinline__ float store_out_ret(const GemvParams& p, int r, int n, float v) {
+    const int b = r / p.M, m = r - b * p.M;
+    const long long off = (long long)b * p.sCb + (long long)m * p.sCm + n;
+    if (p.accumulate) v += half_bits_to_f32<DT>(((const unsigned short*)p.C)[off]);
+    const uint32_t bits = f32_to_half_bits<DT>(v);
+    ((unsigned short*)p.C)[off] = (unsigned short)bits;
+    return half_bits_to_f32<DT>(bits & 0xffffu);
+}
+template <int DT> __device__ __forceinline__ float store_out_residual_ret(const GemvParams& p, int r, int n, float v, float cin) {
+    const int b = r / p.M, m = r - b * p.M;
+    const long long off = (long long)b * p.sCb + (long long)m * p.sCm + n;
+    const uint32_t bits = f32_to_half_bits<DT>(v + cin);
+    ((unsigned short*)p.C)[off] = (unsigned short)bits;
+    return half_bits_to_f32<DT>(bits & 0xffffu);
+}
+
 // In-launch split-k reduction.  Every block has stored its fp32 partial tile to ws[ks][r][n]; the block that arrives LAST at the
 // tile's ticket sums the KS partials in k-slice order (so the result does not depend on which block that is), rounds once, stores,
 // and puts the ticket back to 0 for the next launch.

@@ -86,6 +86,22 @@ struct StreamParams {
     int jsh;                 // K = 2048 << jsh
     float eps;
     int no_res_prefetch;     // A/B switch (bd_set_stream_tuning bit 10): 1 = the residual is read in the epilogue, as before round 4
+    // RMSNorm HAND-OFF between two launches of a decoder layer (round 5; removes the stand-alone rmsnorm launch without making every block
+    // re-reduce the rows):
+    //   ssq_out (producer: o / down with the residual epilogue, 16-bit output): the wave that finishes a 16-column tile also writes
+    //     sum over the tile's 16 columns of (stored value)^2 per row to ssq_out[tile][16 rows]  (tile = n / 16; fixed summation order);
+    //   ssq_in  (consumer: XL = 3): X is the producer's pre-multiplied copy round(x (.) norm_w); the block copies it into LDS, sums the K/16
+    //     partials of each row in a fixed order, and applies rsqrt(mean + eps) as a per-row SCALAR to its accumulators in the epilogue:
+    //     W . (nw (.) x) * rs  instead of  W . (nw (.) round(x * rs)) -- the same value up to the position of one rounding.
+    const float* ssq_in;
+    float* ssq_out;
+    // ... and the producer can also leave the PRE-MULTIPLIED copy behind: xw_out[row][n] = round(stored value * nw_next[row][n]) with nw_next
+    // the weight of the RMSNorm that follows (same strides as C; nw_next [tenants or 1, N], stride sNwNext elements).  The consumer (XL = 3
+    // with nw == nullptr) then reads exactly the bytes the resident-row form reads today -- no norm-weight rows, no multiply -- and only
+    // scales its accumulators.
+    const unsigned short* nw_next;
+    long long sNwNext;
+    unsigned short* xw_out;
 };
 
 // NW = waves per block (8: two per SIMD, 256 VGPRs each; 4: one per SIMD, the whole register file, deeper prefetch).
@@ -117,6 +133,11 @@ struct StreamParams {
 //   into LDS once (R * K * 2 bytes from L2, behind the first weight stages) and every stage reads its fragments from there.  A stage
 //   is then 4 W loads + the sign loads: no per-stage activation loads (4 of the 10 load instructions of a 6-tenant stage, a quarter of
 //   the bytes through the texture path), which is what lets NS = 8 stages fit the 6-bit vmcnt counter: twice the weight bytes in flight.
+// XL = 3 (packed layout, 4-wave blocks): RMSNorm by HAND-OFF (see StreamParams::ssq_in): XL = 2's resident rows -- X is the copy of the
+//   residual stream the PRODUCING launch pre-multiplied by the norm weight (xw_out) -- and the row's 1/rms, from the partial sums of squares
+//   that launch left behind, applied in the epilogue.  No per-block reduction over the rows, no extra barrier, nothing to normalise or
+//   multiply element by element; 16 registers more than XL = 2.  (A form that multiplied raw rows by the norm weight itself -- 64 more
+//   registers of norm-weight chunks, 96 KB per block from L2 -- ran the kernel at 256 VGPRs and lost what the removed launch gave.)
 // EPI = 1 (packed layout): SwiGLU epilogue for a fused gate|up projection whose output rows are interleaved in blocks of 8
 //   ([g0..7 | u0..7 | g8..15 | ...]): a 16-column tile holds 8 gate and the 8 matching up columns, the reducing wave rounds both to
 //   16 bits (what the separate Linear would have stored), and stores round16(silu(g)) * u -- N/2 output columns.  Scale group of
@@ -129,6 +150,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
     static_assert(!WT || (PK && HASW), "tile-major W: packed layout");
     static_assert(!PK || (WNAT == 1 && NM > 0), "packed layout = natural order, with a sign operand");
     static_assert(!(XL || EPI) || (PK && (NW == 4 || (XL == 2 && NW == 8))), "fused prologue / epilogue: packed layout, 256-thread blocks (resident rows: 512 too)");
+    static_assert(XL >= 0 && XL <= 3, "activation forms");
     static_assert(!XL || NS % 2 == 0, "stage parity selects the activation fragment set");
     constexpr int AUXW = AUX & 2, AUXP = (AUX & 4) ? 2 : 0;
     GemvParams p = sp.g;
@@ -171,7 +193,8 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
     // BEFORE the stream starts: the oldest entry of the wave's in-order load queue, so waiting for it never drains a weight load.
     // (A load issued at the end of a tile would be the youngest: s_waitcnt vmcnt(0), the whole prefetch lost once per tile.)
     const int g0 = EPI ? 0 : c_lo / p.gsz, ng = EPI ? 2 : (c_hi - 1) / p.gsz - g0 + 1;
-    const bool al_lds = p.alpha != nullptr && p.R * ng <= (STREAM_ALPHA_MAX < 64 * NW ? STREAM_ALPHA_MAX : 64 * NW);
+    constexpr int ALPHA_CAP = XL == 3 ? STREAM_ALPHA_MAX - 64 : STREAM_ALPHA_MAX;      // (XL = 3 keeps its row sums in the last 64 slots)
+    const bool al_lds = p.alpha != nullptr && p.R * ng <= (ALPHA_CAP < 64 * NW ? ALPHA_CAP : 64 * NW);
     float a_pre = 0.f;
     if (al_lds) {
         const int idx = min((int)threadIdx.x, p.R * ng - 1), r = idx / ng, j = idx - r * ng;
@@ -197,11 +220,40 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
         }
     }
 
+    // hand-off producer with a pre-multiplied copy: the next norm's weights for the columns this lane stores in its first tile, fetched now
+    // for the same reason as c_pre
+    [[maybe_unused]] uint32_t nw_pre[4] = {0u, 0u, 0u, 0u};
+    if constexpr (CPRE) {
+        if (sp.xw_out && wave < ntile && li < p.R) {
+            const int b = li / p.M;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = min(c_lo + wave * 16 + 4 * g + e, p.N - 1);
+                nw_pre[e] = (uint32_t)sp.nw_next[(long long)b * sp.sNwNext + n];
+            }
+        }
+    }
+
     // XL: the R raw rows (and their norm weights) are the OLDEST loads of the wave -- like the scales above, consuming them never
     // waits for a weight stage.  Thread t owns the 16-byte chunks c = 8 t + 2048 i of every row: rmsnorm_tenant_kernel's mapping.
     constexpr int XCH = NW == 8 ? 8 : 16;                                // chunks per thread: R * K <= 16 * 2048 (host-checked)
     constexpr int XNT = 64 * NW;                                         // threads that share the copy
     [[maybe_unused]] u32x4_t xraw[XL ? XCH : 1], graw[XL == 1 ? XCH : 1];
+    // XL = 3: this thread's share of the producer's partial sums of squares, rows 0..7 (host-checked: R <= 8); tiles t, t + 256, ...
+    // Raw loads only, NO arithmetic here: a sum inside a loop makes the compiler wait for each load where it is issued -- a full memory
+    // round trip (the partials were just written by another launch, from other XCDs) in front of the first weight load: +5 us on the
+    // q|k|v launch (rocprofv3 kernel trace, profiles/r05_decode_step.txt).  Buffer loads: tiles past K / 16 read as zero, no branch.
+    constexpr int SSQ_T = 2;                                             // tiles per thread: K <= 16 * 256 * 2 (host-checked)
+    [[maybe_unused]] u32x4_t ssq_raw[XL == 3 ? SSQ_T : 1][2];
+    if constexpr (XL == 3) {
+        const __amdgpu_buffer_rsrc_t rq = make_rsrc(sp.ssq_in, (uint32_t)(p.K >> 4) * 64u);
+#pragma unroll
+        for (int i = 0; i < SSQ_T; ++i) {
+            const uint32_t off = ((uint32_t)threadIdx.x + (uint32_t)XNT * i) * 64u;
+            ssq_raw[i][0] = buf_load16<0>(rq, off);
+            ssq_raw[i][1] = p.R > 4 ? buf_load16<0>(rq, off + 16u) : u32x4_t{0u, 0u, 0u, 0u};
+        }
+    }
     [[maybe_unused]] const int jsh = sp.jsh;                             // log2(chunks per row per thread): K = 2048 << jsh (host-checked)
     if constexpr (XL) {
         const __amdgpu_buffer_rsrc_t rn = make_rsrc(sp.nw, sp.n_bytes);
@@ -210,7 +262,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
             // XL = 1: K = 2048 << jsh, a thread's chunks of one row are consecutive j (the row sums need that).  XL = 2: any K % 8 == 0 --
             // chunk q = thread + 256 j of the flat [R][K / 8] array (the same chunks as the line above when K is a power of two)
             int r, c;
-            if constexpr (XL == 2) { const int q = (int)threadIdx.x + XNT * j, kc = p.K >> 3; r = q / kc; c = (q - r * kc) * 8; }
+            if constexpr (XL == 2 || XL == 3) { const int q = (int)threadIdx.x + XNT * j, kc = p.K >> 3; r = q / kc; c = (q - r * kc) * 8; }
             else { r = j >> jsh; c = ((int)threadIdx.x + 256 * (j - (r << jsh))) * 8; }      // M == 1 (host-checked): row = tenant
             const bool ok = r < p.R;
             xraw[j] = buf_load16<0>(rx, ok ? (uint32_t)(((long long)r * p.sXb + c) * 2) : STREAM_OOB);
@@ -312,11 +364,31 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
             *(u32x4_t*)(dyn_lds + slot * 16) = w;
         }
     }
-    if constexpr (XL == 2) {                      // raw rows -> LDS (same thread mapping as the norm form)
+    if constexpr (XL == 2 || XL == 3) {           // rows -> LDS (same thread mapping as the norm form)
 #pragma unroll
         for (int j = 0; j < XCH; ++j) {
             const int q = (int)threadIdx.x + XNT * j, kc = p.K >> 3, r = q / kc, c = (q - r * kc) * 8;
-            if (r < p.R) *(u32x4_t*)(dyn_lds + sp.xs_off + (uint32_t)r * sp.xrow + (uint32_t)c * 2u) = xraw[j];
+            if (r < p.R) {
+                *(u32x4_t*)(dyn_lds + sp.xs_off + (uint32_t)r * sp.xrow + (uint32_t)c * 2u) = xraw[j];   // (XL = 3: X is the producer's xw_out)
+            }
+        }
+    }
+    if constexpr (XL == 3) {
+        // per-row sums of the producer's partials: thread -> wave (fixed butterfly) -> 4 wave partials in LDS; the epilogue adds the four
+        // in wave order (rms_scale).  The slots sit at the end of the scale area (host: R * scale groups <= STREAM_ALPHA_MAX - 64).
+        float* const rpart = a_lds + (STREAM_ALPHA_MAX - 64);
+        f32x4_t ssq_lo = {0.f, 0.f, 0.f, 0.f}, ssq_hi = {0.f, 0.f, 0.f, 0.f};     // tiles t, t + 256, ... in this fixed order
+#pragma unroll
+        for (int i = 0; i < SSQ_T; ++i) {
+            ssq_lo += __builtin_bit_cast(f32x4_t, ssq_raw[i][0]);
+            ssq_hi += __builtin_bit_cast(f32x4_t, ssq_raw[i][1]);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (r < p.R) {                                    // (wave-uniform)
+                const float w = wave_sum(r < 4 ? ssq_lo[r & 3] : ssq_hi[r & 3]);
+                if (lane == 0) rpart[r * 4 + wave] = w;
+            }
         }
     }
     if constexpr (XL == 1) {
@@ -424,6 +496,11 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
         asm volatile("" ::: "memory");
         if (wave == (tile & (NW - 1)) && li < p.R) {
             const int b = li / p.M;
+            [[maybe_unused]] float rs_row = 1.f;             // XL = 3: this row's rsqrt(mean(x^2) + eps), from the producer's partial sums
+            if constexpr (XL == 3) {
+                const float* rp_ = a_lds + (STREAM_ALPHA_MAX - 64) + li * 4;
+                rs_row = rms_scale(rp_[0], rp_[1], rp_[2], rp_[3], p.K, sp.eps);
+            }
             f32x4_t sb = {0.f, 0.f, 0.f, 0.f}, sd = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int w = 0; w < NW; ++w) {                               // fixed wave order: deterministic
@@ -440,7 +517,8 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
                 const int n_out = ((c_lo + tile * 16) >> 1) + 4 * (g & 1);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float v = round16<DT>(scale_then_add(sd[e], a, HASW ? sb[e] : 0.f));
+                    const float v = round16<DT>(XL == 3 ? scale_then_add(sd[e], a, HASW ? sb[e] : 0.f) * rs_row
+                                                        : scale_then_add(sd[e], a, HASW ? sb[e] : 0.f));
                     const float u = __shfl(v, (lane + 32) & 63, 64);
                     if (g < 2) {
                         const long long off = (long long)b * p.sCb + (long long)(li - b * p.M) * p.sCm + n_out + e;
@@ -448,6 +526,7 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
                     }
                 }
             } else {
+                float sq = 0.f;                              // producer side of the hand-off: sum of squares of what this lane stores
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int n = c_lo + tile * 16 + 4 * g + e;
@@ -455,14 +534,32 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
                         float a = 1.f;
                         if (al_lds) a = a_lds[li * ng + (n / p.gsz - g0)];
                         else if (p.alpha) a = p.alpha[(long long)b * p.sAlb + n / p.gsz];
-                        const float val = scale_then_add(sd[e], a, HASW ? sb[e] : 0.f);
+                        float val = scale_then_add(sd[e], a, HASW ? sb[e] : 0.f);
+                        if constexpr (XL == 3) val *= rs_row;
                         if constexpr (CPRE) {
-                            if (c_pre_ok && tile == wave)
+                            if (sp.ssq_out) {                // (wave-uniform; the hand-off forms return what they stored)
+                                const float st_ = (c_pre_ok && tile == wave)
+                                    ? store_out_residual_ret<DT>(p, li, n, val, half_bits_to_f32<DT>(c_pre[e]))
+                                    : store_out_ret<DT>(p, li, n, val);
+                                sq = __builtin_fmaf(st_, st_, sq);
+                                if (sp.xw_out) {
+                                    const float nwv = half_bits_to_f32<DT>((tile == wave) ? nw_pre[e] : (uint32_t)sp.nw_next[(long long)b * sp.sNwNext + n]);
+                                    sp.xw_out[(long long)b * p.sCb + (long long)(li - b * p.M) * p.sCm + n] = (unsigned short)f32_to_half_bits<DT>(st_ * nwv);
+                                }
+                            } else if (c_pre_ok && tile == wave)
                                 store_out_residual<DT>(p, li, n, val, p.out_f32 ? __builtin_bit_cast(float, c_pre[e]) : half_bits_to_f32<DT>(c_pre[e]));
                             else store_out<DT>(p, li, n, val);
                         } else {
                             store_out<DT>(p, li, n, val);
                         }
+                    }
+                }
+                if constexpr (CPRE) {
+                    if (sp.ssq_out) {
+                        // the row's 16 columns live in lanes li, li + 16, li + 32, li + 48: two fixed exchange steps, lane group 0 writes
+                        sq += __shfl_xor(sq, 16, 64);
+                        sq += __shfl_xor(sq, 32, 64);
+                        if (g == 0) sp.ssq_out[(long long)((c_lo >> 4) + tile) * 16 + li] = sq;
                     }
                 }
             }

@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .binary_gemm_kernel import (binary_linear, binary_linear_swiglu, binary_linear_decode, decode_shape_ok, fused_norm_ok,
+from .binary_gemm_kernel import (binary_linear, binary_linear_swiglu, binary_linear_decode, decode_shape_ok, fused_norm_ok, handoff_ok,
                                  pack_decode_masks, tenant_linear, tile_weight)
 from .diff import binarize
 from . import serving_ops as ops
@@ -40,6 +40,7 @@ MODEL_CONFIGS = {
     "mistral-1layer": (4096, 14336, 1, 32, 8, 512),   # ONE full-width Mistral-7B layer (small vocabulary): full-size loop parity tests
 }
 
+NORM_HANDOFF_DEFAULT = True     # (profiles/r05_decode_step.txt)
 MAX_PROMPT = 1024      # demo/demo_backend.py:300-302
 MIN_PAD = 64           # demo/demo_backend.py:299
 
@@ -112,24 +113,42 @@ class FusedDeltaLinear(nn.Module):
 
     use_tiled = True              # (A/B switch)
 
-    def forward(self, x, residual=None, out_dtype=None):
-        """out_dtype=torch.float32: un-rounded partial sums (the row-parallel shards of tp.py reduce them across ranks)"""
+    def forward(self, x, residual=None, out_dtype=None, ssq_out=None, next_norm=None, xw_out=None):
+        """out_dtype=torch.float32: un-rounded partial sums (the row-parallel shards of tp.py reduce them across ranks).
+        ssq_out (decode, with residual): RMSNorm hand-off, producer side -- the launch also leaves the per-row partial sums of squares of the
+        updated residual stream for the next launch (`handoff_producer_ok`), and with next_norm [T, N] + xw_out [T, 1, N] the copy of it
+        pre-multiplied by the NEXT norm's weight."""
         if self._decode_ok(x):
             w, wt = self._dec_weight(x)
             return binary_linear_decode(x, w, self.mask_packed, self.alpha, layout="packed", groups=self.groups,
-                                        residual=residual, weight_tiled=wt, out_dtype=out_dtype)
+                                        residual=residual, weight_tiled=wt, out_dtype=out_dtype, ssq_out=ssq_out,
+                                        norm_weight=next_norm if ssq_out is not None else None, xw_out=xw_out)
+        assert ssq_out is None and xw_out is None
         return binary_linear(x, self.weight, self.mask, self.alpha, groups=self.groups, residual=residual, out_dtype=out_dtype)
 
-    def forward_fused(self, x, norm_weight, eps, swiglu=False):
+    def handoff_producer_ok(self, x):
+        """this (residual) Linear can leave the sums of squares of its output behind: decode shape, one row per tenant, tile-major weight"""
+        return (self._decode_ok(x) and x.shape[1] == 1 and x.shape[0] <= 8 and self.weight.shape[0] % 16 == 0 and
+                self.weight_tiled is not None and self.use_tiled)
+
+    def handoff_consumer_ok(self, x, swiglu=False):
+        """forward_fused(..., ssq_in=...) can take this input: the resident-row envelope, tile-major weight (an interleaved pair for SwiGLU)"""
+        B, M, K = x.shape
+        return (self._decode_ok(x) and handoff_ok(B, M, K) and self.weight_tiled is not None and self.use_tiled and
+                (not swiglu or self.interleave8))
+
+    def forward_fused(self, x, norm_weight, eps, swiglu=False, ssq_in=None):
         """[RMSNorm(x; norm_weight) ->] this Linear [-> SwiGLU] in ONE launch.  With norm_weight, x is the un-normalised residual stream
-        (`fusable(x)`); norm_weight=None keeps only the SwiGLU epilogue (x already normalised; needs `_decode_ok(x)`)."""
+        (`fusable(x)`); norm_weight=None keeps only the SwiGLU epilogue (x already normalised; needs `_decode_ok(x)`).
+        ssq_in: the partial sums of squares of the residual stream left by the launch that produced it -- the norm then costs no reduction at
+        all (`handoff_consumer_ok`); with norm_weight=None, x is the producer's pre-multiplied copy."""
         if swiglu:
             w, wt = self._dec_weight(x)
             return binary_linear_decode(x, w, self.mask_packed, self.alpha_pair, layout="packed", groups=2,
-                                        norm_weight=norm_weight, eps=eps, swiglu=True, weight_tiled=wt)
+                                        norm_weight=norm_weight, eps=eps, swiglu=True, weight_tiled=wt, ssq_in=ssq_in)
         w, wt = self._dec_weight(x)
         return binary_linear_decode(x, w, self.mask_packed, self.alpha, layout="packed", groups=self.groups,
-                                    norm_weight=norm_weight, eps=eps, weight_tiled=wt)
+                                    norm_weight=norm_weight, eps=eps, weight_tiled=wt, ssq_in=ssq_in)
 
     def swiglu_ok(self, x):
         """True when forward_swiglu can take this input: an interleaved gate|up pair at prefill size on the fused GEMM's fast path"""
@@ -214,6 +233,13 @@ class TenantDecoder(nn.Module):
         # vs 4.226 (and 4.218 vs 4.243 in a later session: a wash), 6 tenants 4.771 vs 4.700 -- the prologue's cost grows with the rows,
         # the saved launch does not (profiles/r04_decode_step_ab.txt).
         self.fuse_gateup_norm = tenants <= 4
+        # RMSNorm by HAND-OFF (round 5): o / down leave the per-row partial sums of squares of the residual stream they write; the next
+        # q|k|v / gate|up launch applies the norm weight on its resident rows and 1/rms in its epilogue -- neither a stand-alone norm launch
+        # nor a per-block reduction.  Takes precedence over the two switches above where its envelope holds (tile-major weights, <= 8
+        # tenants, hidden >= 2048); not bit-identical to the separate launches (one rounding moves), same accuracy.
+        self.norm_handoff = NORM_HANDOFF_DEFAULT
+        self._ssq = None                # [hidden / 16, 16] fp32: partial sums of squares of the current residual stream
+        self._xw = None                 # [T, 1, hidden]: the residual stream times the weight of the norm that reads it next
         # (round 2 also shipped a persistent per-layer chain launch, bd_decode_chain: bit-identical but 5.91 vs 5.33 ms per step in every
         # same-process A/B, so it was removed from the library in round 3 -- profiles/r02_decode_chain_*.txt keep the measurements)
 
@@ -289,12 +315,20 @@ class TenantDecoder(nn.Module):
             return ops.rmsnorm_tenant(x if x.is_contiguous() else x.contiguous(), w, self.eps)
         return F.rms_norm(x, (x.shape[-1],), None, self.eps) * w[:, None, :]
 
-    def _layer(self, layer, x, cos, sin, cache, li, pos_idx, attn_mask):
+    def _layer(self, layer, x, cos, sin, cache, li, pos_idx, attn_mask, ssq_valid=False, next_norm1=None):
+        """one decoder layer; returns (x, ssq_valid): whether self._ssq / self._xw hold the partial sums of squares of the returned x and its
+        copy pre-multiplied by next_norm1 (the NEXT layer's input norm weight; None after the last layer)"""
         T, S, hid = x.shape
         _, inter, _, heads, kvh, _ = self.cfg
         hd = self.hd
         fuse = S == 1 and self.fast_glue and self.fuse_glue and x.is_contiguous()
-        if fuse and self.fuse_qkv_norm and layer.qkv.fusable(x):
+        handoff = fuse and self.norm_handoff and hid % 16 == 0
+        if handoff and self._ssq is None:
+            self._ssq = torch.empty(hid // 16, 16, dtype=torch.float32, device=x.device)
+            self._xw = torch.empty(T, 1, hid, dtype=x.dtype, device=x.device)
+        if handoff and ssq_valid:
+            qkv = layer.qkv.forward_fused(self._xw, None, self.eps, ssq_in=self._ssq)    # rows already carry norm1's weight; 1/rms in the epilogue
+        elif fuse and self.fuse_qkv_norm and layer.qkv.fusable(x):
             qkv = layer.qkv.forward_fused(x, layer.norm1, self.eps)              # RMSNorm in the Linear's prologue: one launch
         else:
             qkv = layer.qkv(self._norm(x, layer.norm1))
@@ -322,8 +356,12 @@ class TenantDecoder(nn.Module):
             cv.index_copy_(2, pos_idx, v)
             a = F.scaled_dot_product_attention(q, ck, cv, attn_mask=attn_mask, enable_gqa=(kvh != heads))
             a = a.transpose(1, 2).reshape(T, S, heads * hd)
-        x = layer.o(a, residual=x)
-        if fuse and self.fuse_gateup_norm and layer.gate_up.fusable(x, swiglu=True):
+        o_hand = handoff and layer.o.handoff_producer_ok(a) and layer.gate_up.handoff_consumer_ok(x, swiglu=True)
+        x = layer.o(a, residual=x, ssq_out=self._ssq if o_hand else None, next_norm=layer.norm2 if o_hand else None,
+                    xw_out=self._xw if o_hand else None)
+        if o_hand:
+            act = layer.gate_up.forward_fused(self._xw, None, self.eps, swiglu=True, ssq_in=self._ssq)   # (RMSNorm by hand-off) gate|up -> SwiGLU
+        elif fuse and self.fuse_gateup_norm and layer.gate_up.fusable(x, swiglu=True):
             act = layer.gate_up.forward_fused(x, layer.norm2, self.eps, swiglu=True)   # RMSNorm -> gate|up -> SwiGLU: one launch
         elif fuse and layer.gate_up.interleave8 and layer.gate_up._decode_ok(x):
             act = layer.gate_up.forward_fused(self._norm(x, layer.norm2), None, self.eps, swiglu=True)   # gate|up -> SwiGLU: one launch
@@ -337,8 +375,10 @@ class TenantDecoder(nn.Module):
             else:
                 g, u = layer.gate_up.split(gu)
                 act = F.silu(g) * u
-        x = layer.down(act, residual=x)
-        return x
+        d_hand = handoff and next_norm1 is not None and layer.down.handoff_producer_ok(act) and layer.qkv.handoff_consumer_ok(x)
+        x = layer.down(act, residual=x, ssq_out=self._ssq if d_hand else None, next_norm=next_norm1 if d_hand else None,
+                       xw_out=self._xw if d_hand else None)
+        return x, d_hand
 
     @torch.no_grad()
     def forward(self, ids, pos_idx, cache, attn_mask):
@@ -348,8 +388,10 @@ class TenantDecoder(nn.Module):
         cos, sin = self.cos[pos_idx], self.sin[pos_idx]
         t_idx = torch.arange(T, device=ids.device).view(T, 1)
         x = self.embed[t_idx, ids]                                            # per-tenant embedding: one gather
+        ssq_valid = False                                                     # (the embedding rows have no producer launch: layer 0 norms itself)
         for li, layer in enumerate(self.layers):
-            x = self._layer(layer, x, cos, sin, cache, li, pos_idx, attn_mask)
+            nxt = self.layers[li + 1].norm1 if li + 1 < len(self.layers) else None
+            x, ssq_valid = self._layer(layer, x, cos, sin, cache, li, pos_idx, attn_mask, ssq_valid, nxt)
         last = self._norm(x[:, -1:, :], self.final_norm)
         return tenant_linear(last, self.lm_head)[:, 0, :]                     # per-tenant lm_head: one launch
 
@@ -419,7 +461,7 @@ class TenantDecoder(nn.Module):
         # few slots that can exist are kept in a small LRU; an evicted slot's graph and buffers are released.
         # Stale keys of an earlier request are masked by cache["valid"].
         width = max(self.MIN_STOP_WIDTH, 1 << max(nstop - 1, 0).bit_length())
-        key = (width, self.fast_glue, self.fuse_glue, self.fuse_qkv_norm, self.fuse_gateup_norm, FusedDeltaLinear.use_tiled)
+        key = (width, self.fast_glue, self.fuse_glue, self.fuse_qkv_norm, self.fuse_gateup_norm, self.norm_handoff, FusedDeltaLinear.use_tiled)
         if self._kv_cache is None:
             self._kv_cache = self.new_cache()
         slot = self._static.pop(key, None)

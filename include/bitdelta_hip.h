@@ -129,6 +129,27 @@ int bd_binary_linear_decode_fused(const void* X, const void* W, const int32_t* P
                                   int64_t sYb, int64_t sYm, int dtype, int out_dtype, int accumulate,
                                   const void* norm_w, int64_t s_norm, float eps, int epilogue, void* stream);
 
+/* RMSNorm HAND-OFF between two decode launches of a decoder layer (packed layout, M == 1, B <= 8; new in round 5 -- the reference runs
+ * the HF RMSNorm module between its Linears, demo/demo_backend.py:62-79 wraps it per tenant).  bd_binary_linear_decode_fused with three
+ * more pointers:
+ *   PRODUCER, ssq_out != NULL (the o_proj / down_proj launch: accumulate = 1 or 0, 16-bit output, N % 16 == 0, epilogue = 0): besides Y the
+ *     launch writes ssq_out[n / 16][row] = sum over the 16 columns of tile n / 16 of Y[row][n]^2 (fp32 [N/16][16], fixed order).  With
+ *     xw_out != NULL, norm_w [B or 1, N] (stride s_norm) is the weight of the RMSNorm that FOLLOWS and xw_out [B, M, N] (Y's strides)
+ *     receives round(Y (.) norm_w): the pre-multiplied copy the consumer reads instead of Y.
+ *   CONSUMER, ssq_in != NULL (the q|k|v / gate|up launch that follows; K % 16 == 0, K <= 8192, norm_w = NULL): X is the producer's xw_out
+ *     -- the consumer reads exactly what the resident-row form reads, nothing to multiply -- and rsqrt(sum(ssq_in[:, row]) / K + eps) scales
+ *     the row's accumulators in the epilogue:  Y = rs * (W + alpha S) . (norm_w (.) x)  -- HF RMSNorm followed by the Linear with the row
+ *     scale moved across the contraction (one rounding of x * norm_w instead of two; not bit-identical to the separate bd_srv_rmsnorm launch,
+ *     same accuracy).
+ *   Needs the tile-major base weight (ldw = 0) on the consumer, K >= 1024, B * K <= 32768.  Both stand-alone rmsnorm launches of a layer
+ *   disappear without any block re-reducing or re-normalising the rows.  BD_E_BAD_SHAPE outside the envelope (no fallback). */
+int bd_binary_linear_decode_handoff(const void* X, const void* W, const int32_t* P, int t_pad, const float* alpha, void* Y,
+                                    int B, int M, int N, int K,
+                                    int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb, int64_t sAlb, int G,
+                                    int64_t sYb, int64_t sYm, int dtype, int out_dtype, int accumulate,
+                                    const void* norm_w, int64_t s_norm, float eps, int epilogue,
+                                    const float* ssq_in, float* ssq_out, void* xw_out, void* stream);
+
 /* the same Linear with the residual connection folded into its epilogue:  Y[b] = Y_in[b] + X[b] . W^T + alpha * (X[b] . S[b])
  * -- the `hidden = residual + o_proj(...)` / `+ down_proj(...)` of the decoder layers that call the reference's modules.
  * Decode shapes (M <= 16, B*M <= 64): fp32 sum, one rounding.  M > 16 on the fused GEMM's fast path (K % 64 == 0, 16-byte aligned

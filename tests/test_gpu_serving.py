@@ -841,3 +841,99 @@ def test_serving_loop_prefill_through_hip_attention_matches_torch_attention(bd, 
             assert relerr(ka[t, :, L - n:L], kb_[t, :, L - n:L]) < 2e-2
         for va, vb in zip(a[2], b[2]):
             assert relerr(va[t, :, L - n:L], vb[t, :, L - n:L]) < 2e-2
+
+
+# ------------------------------------------------------------------------------------------------ RMSNorm by hand-off (round 5)
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("T,hid,N2,swiglu", [(6, 4096, 6144, False), (6, 4096, 28672, True), (1, 4096, 12288, False), (8, 4096, 1024, False),
+                                             (3, 2048, 2048, True), (4, 8192, 1024, False), (2, 5120, 2560, False)])
+def test_rmsnorm_handoff_between_two_decode_launches(bd, dtype, T, hid, N2, swiglu):
+    """bd_binary_linear_decode_handoff.  PRODUCER (a residual Linear, K1 -> hid): same output bits as the plain launch, the [hid/16, 16]
+    buffer holds the per-row sums of squares of the STORED values, 16 columns at a time, and xw_out their product with the next norm's weight.
+    CONSUMER (hid -> N2, optional SwiGLU): xw_out as resident rows + 1/rms on the accumulators == RMSNorm launch followed by the Linear, up to
+    the position of one rounding: compared
+    with the separate launches (a few 16-bit ulps) and, like them, with a dense fp32 evaluation of the same layer."""
+    from bitdelta_amd import serving_ops as ops
+    from bitdelta_amd.binary_gemm_kernel import handoff_ok
+    from bitdelta_amd.serving_loop import FusedDeltaLinear
+    assert handoff_ok(T, 1, hid) and not handoff_ok(9, 1, 4096) and not handoff_ok(T, 2, hid) and not handoff_ok(1, 1, 1024)
+    g = torch.Generator(device="cuda").manual_seed(hid + N2 + T)
+    K1 = 2048
+
+    def lin(n_out, n_in, il8=False, parts=1):
+        ws = [(torch.randn(n_out // parts, n_in, device="cuda", generator=g) * 0.02).to(dtype) for _ in range(parts)]
+        ms = [torch.randint(-2**31, 2**31 - 1, (T, n_in // 32, n_out // parts), device="cuda", generator=g, dtype=torch.int64).to(torch.int32)
+              for _ in range(parts)]
+        cs = [torch.rand(T, device="cuda", generator=g) * 1e-3 for _ in range(parts)]
+        return FusedDeltaLinear(ws, ms, cs, interleave8=il8)
+    prod = lin(hid, K1)
+    cons = lin(N2, hid, il8=swiglu, parts=2 if swiglu else 1)
+    a = torch.randn(T, 1, K1, device="cuda", generator=g).to(dtype)
+    resid = (torch.randn(T, 1, hid, device="cuda", generator=g) * 2.0).to(dtype)
+    nw = (1 + 0.1 * torch.randn(T, hid, device="cuda", generator=g)).to(dtype)
+    assert prod.handoff_producer_ok(a) and cons.handoff_consumer_ok(resid, swiglu=swiglu)
+    # ---- producer
+    plain = prod(a, residual=resid.clone())
+    ssq = torch.full((hid // 16, 16), float("nan"), device="cuda")
+    x = prod(a, residual=resid.clone(), ssq_out=ssq)
+    assert torch.equal(x, plain)
+    want = (x.float()[:, 0, :].reshape(T, hid // 16, 16) ** 2).sum(-1).T                 # [hid/16, T]
+    assert torch.allclose(ssq[:, :T], want, rtol=1e-5, atol=1e-6)
+    assert torch.isnan(ssq[:, T:]).all()                                                  # rows past the tenants are not touched
+    # ---- ... and the pre-multiplied copy round(x * nw) for the consumer (a broadcast weight, then the per-tenant one used below)
+    ssq2 = torch.zeros_like(ssq)
+    xw = torch.full_like(x, float("nan"))
+    for nrm in (nw[:1], nw):
+        x2 = prod(a, residual=resid.clone(), ssq_out=ssq2, next_norm=nrm, xw_out=xw)
+        assert torch.equal(x2, plain) and torch.equal(ssq2[:, :T], ssq[:, :T])
+        assert torch.equal(xw, (x.float() * nrm.float()[:, None, :]).to(dtype))
+    # ---- consumer: resident rows = xw, 1/rms on the accumulators
+    h = ops.rmsnorm_tenant(x, nw, 1e-5)
+    sep = cons.forward_fused(h, None, 1e-5, swiglu=True) if swiglu else cons(h)
+    got = cons.forward_fused(xw, None, 1e-5, swiglu=swiglu, ssq_in=ssq2)
+    assert got.shape == sep.shape and got.dtype == dtype
+    # dense fp32 evaluation of the same layer (HF RMSNorm in fp32, merged weights)
+    S = bd.unpack(cons.mask).float() * 2 - 1                                             # [T, hid, N2]
+    wm = cons.weight.float().T[None] + torch.stack([cons.column_alpha(t) for t in range(T)])[:, None, :] * S
+    xn = torch.nn.functional.rms_norm(x.float(), (hid,), None, 1e-5) * nw.float()[:, None, :]
+    dense = torch.bmm(xn, wm)
+    if swiglu:
+        v = dense.reshape(T, 1, N2 // 16, 2, 8)
+        dense = (torch.nn.functional.silu(v[..., 0, :]) * v[..., 1, :]).reshape(T, 1, N2 // 2)
+    rel = lambda u, r: ((u.float() - r).norm() / r.norm()).item()
+    tol = 1.5e-3 if dtype == torch.float16 else 8e-3
+    assert rel(got, dense) <= tol and rel(sep, dense) <= tol, (rel(got, dense), rel(sep, dense))
+    assert rel(got, dense) <= 1.3 * rel(sep, dense) + 1e-4                               # as accurate as the separate launches
+    assert rel(got, sep.float()) <= tol
+    # outside the envelope the entry point refuses (no silent fallback): a consumer handed a norm weight, a producer with fp32 output
+    from bitdelta_amd._lib import BitDeltaHipError
+    with pytest.raises((BitDeltaHipError, AssertionError)):
+        cons.forward_fused(xw, nw, 1e-5, swiglu=swiglu, ssq_in=ssq2)
+    with pytest.raises((BitDeltaHipError, AssertionError)):
+        prod(a, residual=resid.float(), out_dtype=torch.float32, ssq_out=ssq)
+
+
+def test_decoder_with_norm_handoff_matches_the_separate_launch_decoder(bd):
+    """TenantDecoder.norm_handoff: two Llama-width layers x 6 tenants, decode steps after a prefill -- logits within the 16-bit rounding band of
+    the separate-launch decoder's, same greedy tokens, and the hand-off really runs (no bd_srv_rmsnorm launch inside layers >= 1)."""
+    from bitdelta_amd.serving_loop import TenantDecoder
+    dec = TenantDecoder.synthetic("tiny4096", 6, "cuda", dtype=torch.float16, seed=11)
+    prompts = [[(7 * t + 3 * i) % 500 + 1 for i in range(5 + t)] for t in range(6)]
+    outs = {}
+    for flag in (False, True):
+        dec.norm_handoff = flag
+        toks, _ = dec.generate(prompts, max_new_tokens=6, use_graph=False)
+        ids, am = dec.prepare(prompts)
+        cache = dec.new_cache()
+        dec.prefill(ids, am, cache)
+        pos = torch.tensor([ids.shape[1]], device="cuda")
+        cache["valid"].index_fill_(1, pos, True)
+        logits = dec.forward(torch.full((6, 1), 17, device="cuda"), pos, cache, cache["valid"][:, None, None, :])
+        outs[flag] = (toks, logits.float())
+    assert torch.equal(outs[True][0], outs[False][0])
+    d = (outs[True][1] - outs[False][1]).abs().max().item()
+    assert d <= 2e-2 * outs[False][1].abs().max().item(), d
+    # graph replay == eager with the hand-off on
+    dec.norm_handoff = True
+    tg, _ = dec.generate(prompts, max_new_tokens=6, use_graph=True)
+    assert torch.equal(tg, outs[True][0])
