@@ -547,14 +547,18 @@ def run_mt_decode(dev, timer, model_name, tenants, kv_len, steps, warmup, layers
     ab = None
     if ab_glue and graph_ms is not None:
         # same process, same box, alternating: the step with RMSNorm / SwiGLU folded into the Linear launches vs separate glue launches
-        ab = {"fused_glue_ms": [], "fused_gateup_only_ms": [], "swiglu_epilogue_only_ms": [], "separate_glue_ms": []}
+        ab = {"norm_handoff_ms": [], "fused_glue_ms": [], "fused_gateup_only_ms": [], "swiglu_epilogue_only_ms": [], "separate_glue_ms": []}
         runners = {}
         keep = (dec.fuse_glue, dec.fuse_qkv_norm, dec.fuse_gateup_norm)
-        for name, flag, qn, gn in (("fused_glue_ms", True, True, True), ("fused_gateup_only_ms", True, False, True),
-                                   ("swiglu_epilogue_only_ms", True, False, False), ("separate_glue_ms", False, True, True)):
-            dec.fuse_glue, dec.fuse_qkv_norm, dec.fuse_gateup_norm = flag, qn, gn
+        keep_h = dec.norm_handoff
+        # (the round-2..4 arms keep their meaning: RMSNorm hand-off off; "norm_handoff_ms" = the shipped round-5 step)
+        for name, flag, qn, gn, ho in (("norm_handoff_ms", True, False, False, True), ("fused_glue_ms", True, True, True, False),
+                                       ("fused_gateup_only_ms", True, False, True, False), ("swiglu_epilogue_only_ms", True, False, False, False),
+                                       ("separate_glue_ms", False, True, True, False)):
+            dec.fuse_glue, dec.fuse_qkv_norm, dec.fuse_gateup_norm, dec.norm_handoff = flag, qn, gn, ho
             restore()
             runners[name] = dec._graph_runner(st)
+        dec.norm_handoff = keep_h
         for _ in range(3):
             for name, run in runners.items():
                 restore()

@@ -611,6 +611,7 @@ def test_serving_loop_fused_glue_matches_separate_launches(bd):
     prompts = [torch.randint(1, 512, (n,), generator=g).tolist() for n in (12, 64, 40)]
     outs = {}
     dec.fuse_qkv_norm = dec.fuse_gateup_norm = True                       # every fusion on (the shipped default leaves q|k|v's norm separate)
+    dec.norm_handoff = False        # (the RMSNorm hand-off moves one rounding: it has its own tolerance tests; this one is about bit-identity)
     for fuse in (True, False):
         dec.fuse_glue = fuse
         for graph in (True, False):
