@@ -325,11 +325,11 @@ def committed_traffic():
     """HBM/fabric-side bytes per launch of the dominant kernels, from the committed rocprofv3 PMC passes over THIS command
     (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE x 2 per MI355X_MICROARCH.md; tools/prof_bench.sh).  A bench run cannot
     read PMC counters in-process, so the line carries the committed figure and names its source."""
-    path = os.path.join(ROOT, "profiles", "r04_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r05_traffic.json")
     try:
         with open(path) as fh:
             d = json.load(fh)
-        d["_source"] = "profiles/r04_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `python bench.py`, tools/prof_bench.sh)"
+        d["_source"] = "profiles/r05_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `python bench.py`, tools/prof_bench.sh)"
         return d
     except Exception:
         return None
@@ -767,7 +767,7 @@ def main():
                      "frac": achieved / PEAK_BF16_TFLOPS,
                      "traffic": traffic.get("fused_gemm", {}).get("traffic_bytes_per_launch") if traffic else None,
                      "traffic_source": traffic.get("_source") if traffic else
-                                       "not available: PMC counters need rocprofv3 passes (tools/prof_bench.sh writes profiles/r04_traffic.json)",
+                                       "not available: PMC counters need rocprofv3 passes (tools/prof_bench.sh writes profiles/r05_traffic.json)",
                      "traffic_over_algorithmic": (traffic["fused_gemm"]["traffic_bytes_per_launch"] / (k_bytes / n_launch))
                                                  if traffic and n_launch and traffic.get("fused_gemm") else None,
                      "algorithmic_bytes_total": k_bytes, "algorithmic_bytes_per_launch": k_bytes / n_launch if n_launch else None,
