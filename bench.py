@@ -17,6 +17,8 @@ Prints ONE JSON line (rank 0) with the driver contract fields plus
   delta_gemm    the W1A16 delta-GEMM alone at K = N = 4096, M in {4096, 8192, 16384} (the north star's 70 %-of-peak target), same method
   vendor_gemm   the vendor's bf16 GEMM (torch.matmul -> hipBLASLt) at the same three shapes, same process, same warm-up: the
                 calibration row for "what fraction of 2.5 PF does ANY dense bf16 GEMM reach on this board at its power cap"
+  mfma_ceiling  a pure-MFMA soak in the same run (no memory traffic): what the matrix cores sustain on this board on random operands and with a
+                +-1 second operand -- the ceiling the delta_gemm / vendor_gemm fractions should be read against
   published_shapes  the reference's own published kernel benchmark shapes (M in {1, 16}, B in {1, 8, 16}, N = K in {4096, 8192},
                 fp16) through binary_matmul / binary_bmm, TFLOP/s in the reference's convention beside the published figure + mask GB/s
   decode_7b     SURVEY.md 8(d) C2 "plus decode steps": Llama-2-7B + ONE delta, single-sequence greedy decode tokens/s (hipGraph)
@@ -459,6 +461,28 @@ def published_shapes_block(dev, iters=100, warmup=20):
             "rows": rows}
 
 
+def mfma_ceiling_block(secs=1.5):
+    """What the matrix cores sustain on THIS board in THIS run with nothing else going on: tests/native/probes/mfma_energy_probe (pure
+    v_mfma_f32_32x32x16_bf16 stream, 16 waves per CU, operands in registers, no memory traffic), `secs` seconds each on random operands and with a
+    +-1 second operand (the delta GEMM's operand mix).  The calibration row next to `delta_gemm` / `vendor_gemm`: the datasheet 2.5 PF is a
+    zero-operand figure; on random data the board's power cap pulls the clock down (profiles/r05_mfma_energy.txt)."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "native", "probes", "mfma_energy_probe")
+    if not os.path.exists(exe):
+        return {"error": "tests/native/probes/mfma_energy_probe not built (python -c 'import __graft_entry__ as g; g.build()')"}
+    out = {"what": "pure-MFMA soak, bf16 32x32x16, no memory traffic: the sustained rate of the matrix cores under this board's power cap",
+           "seconds_each": secs}
+    for key, v in (("random_operands", 0), ("pm1_second_operand", 2)):
+        try:
+            r = subprocess.run([exe, str(v), str(secs)], capture_output=True, text=True, timeout=60)
+            m = re.search(r"-> ([0-9.]+) TF \(([0-9.]+) of", r.stdout)
+            out[key] = {"tflops": float(m.group(1)), "frac_of_peak": float(m.group(2))} if m else {"error": (r.stdout + r.stderr)[-300:]}
+        except Exception as e:
+            out[key] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
 def vendor_gemm_microbench(dev, Ms=(4096, 8192, 16384), N=4096, K=4096, iters=100, warmup=100):
     """Calibration of the 2.5 PF denominator: the vendor's dense bf16 GEMM (torch.matmul -> hipBLASLt) at the delta-GEMM's shapes,
     [M, 4096] x [4096, 4096]^T, same process, same 100 + 100 launches, each launch between two HIP events on the launch stream.  It
@@ -783,6 +807,7 @@ def main():
         "delta_gemm": mb,
         "vendor_gemm": vendor_gemm_microbench(dev),
         "published_shapes": published_shapes_block(dev),
+        "mfma_ceiling": mfma_ceiling_block(),
         "linear_params": lin_params,
     }
     if world == 1 and not args.no_mt_decode:
