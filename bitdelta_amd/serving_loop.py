@@ -113,18 +113,18 @@ class FusedDeltaLinear(nn.Module):
 
     use_tiled = True              # (A/B switch)
 
-    def forward(self, x, residual=None, out_dtype=None, ssq_out=None, next_norm=None, xw_out=None):
+    def forward(self, x, residual=None, out_dtype=None, ssq_out=None, next_norm=None, xw_out=None, out=None):
         """out_dtype=torch.float32: un-rounded partial sums (the row-parallel shards of tp.py reduce them across ranks).
         ssq_out (decode, with residual): RMSNorm hand-off, producer side -- the launch also leaves the per-row partial sums of squares of the
         updated residual stream for the next launch (`handoff_producer_ok`), and with next_norm [T, N] + xw_out [T, 1, N] the copy of it
-        pre-multiplied by the NEXT norm's weight."""
+        pre-multiplied by the NEXT norm's weight.  out: caller-provided destination (tp.py: the all-reduce's peer-mapped buffer)."""
         if self._decode_ok(x):
             w, wt = self._dec_weight(x)
             return binary_linear_decode(x, w, self.mask_packed, self.alpha, layout="packed", groups=self.groups,
                                         residual=residual, weight_tiled=wt, out_dtype=out_dtype, ssq_out=ssq_out,
-                                        norm_weight=next_norm if ssq_out is not None else None, xw_out=xw_out)
+                                        norm_weight=next_norm if ssq_out is not None else None, xw_out=xw_out, out=out)
         assert ssq_out is None and xw_out is None
-        return binary_linear(x, self.weight, self.mask, self.alpha, groups=self.groups, residual=residual, out_dtype=out_dtype)
+        return binary_linear(x, self.weight, self.mask, self.alpha, groups=self.groups, residual=residual, out_dtype=out_dtype, out=out)
 
     def handoff_producer_ok(self, x):
         """this (residual) Linear can leave the sums of squares of its output behind: decode shape, one row per tenant, tile-major weight"""
