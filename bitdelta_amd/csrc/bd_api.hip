@@ -673,7 +673,7 @@ inline GemmParams make_params(const Problem& q, int BM, int BN) {
     p.sAm = (int)q.sAm; p.sCm = (int)q.sCm; p.ldw = (int)q.ldw;
     p.sAlb = (int)q.sAlb; p.gsz = q.N / q.G;
     p.round_mode = q.round_mode; p.accumulate = q.accumulate;
-    p.nbatch = q.B;
+    p.nbatch = q.B; p.nent = q.B;
     // Tile walk order (profiles/r01_tile_order.txt): delta-only = n fastest (the XCD's run shares X row panels; the mask is tiny).
     // Fused = groups of 4 tile rows: each XCD's run covers a ~4 x 8 block of tiles, which minimises X + W bytes per XCD
     // (+3..5 % on the MLP shapes over n-fastest, equal to m-fastest on the single-round ones).
@@ -891,6 +891,48 @@ int launch_pair_splitk(const Problem& q, int KS) {
     return launch_status();
 }
 
+// four-wave PAIR tiles (W4Cfg PAIR = 1): two batch entries of <= 64 rows per 128 x 128 tile, persistent over (pair, column tile)
+template <int DT, bool OUT_F32>
+int launch_w4_pair(const Problem& q) {
+    using Cfg = W4Cfg<DT, 128, 128, true, OUT_F32, 1 | 8192, 0, 1>;
+    GemmParams p = make_params(q, Cfg::BM, Cfg::BN);          // tiles_m = 1: the tile's two wave rows are two batch entries
+    p.nent = q.B; p.nbatch = (q.B + 1) / 2;
+    auto kern = delta_gemm_w4_kernel<Cfg>;
+    static std::atomic<uint64_t> lds_done{0};
+    if (!ensure_dyn_lds((const void*)kern, Cfg::LDS_BYTES, lds_done)) return BD_E_LAUNCH;
+    const long long total = (long long)p.tiles_n * p.nbatch, cus = num_cus();
+    if (total <= 0) return BD_OK;
+    dim3 grid((unsigned)(total < cus ? total : cus));
+    hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, q.st, p);
+    return launch_status();
+}
+// ... + split-k: the persistent stream runs over (pair, k slice, column tile); fp32 partial slabs [entry * KS + slice][M][N], then the reduce launch
+// of launch_pair_splitk (residual added there).  KS must divide the k-tile count.
+template <int DT>
+int launch_w4_pair_splitk(const Problem& q, int KS) {
+    const int64_t need = GEMV_TICKET_BYTES + (int64_t)q.B * KS * q.M * q.N * 4;
+    if (!q.ws || q.ws_bytes < need) return BD_E_WORKSPACE;
+    if ((q.K / 64) % KS) return BD_E_BAD_SHAPE;
+    float* part = (float*)((char*)q.ws + GEMV_TICKET_BYTES);
+    Problem c = q;
+    c.C = part; c.out_dtype = BD_F32; c.sCm = q.N; c.sCb = (int64_t)q.M * q.N;     // slab = entry * KS + slice
+    c.accumulate = 0;
+    using Cfg = W4Cfg<DT, 128, 128, true, true, 1 | 8192, 0, 1>;
+    GemmParams p = make_params(c, Cfg::BM, Cfg::BN);
+    p.ksplit = KS; p.nent = q.B; p.nbatch = ((q.B + 1) / 2) * KS;
+    auto kern = delta_gemm_w4_kernel<Cfg>;
+    static std::atomic<uint64_t> lds_done{0};
+    if (!ensure_dyn_lds((const void*)kern, Cfg::LDS_BYTES, lds_done)) return BD_E_LAUNCH;
+    const long long total = (long long)p.tiles_n * p.nbatch, cus = num_cus();
+    dim3 grid((unsigned)(total < cus ? total : cus));
+    hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, q.st, p);
+    const long long per = (long long)q.M * q.N / 4;
+    dim3 g2((unsigned)((per + 255) / 256), (unsigned)q.B);
+    hipLaunchKernelGGL((splitk_reduce_kernel<DT>), g2, dim3(256), 0, q.st, (const float*)part, q.C, q.B, KS, q.M, q.N,
+                       (long long)q.sCb, (int)q.sCm, q.out_dtype == BD_F32 ? 1 : 0, q.accumulate);
+    return launch_status();
+}
+
 template <int DT, bool FUSED, bool OUT_F32>
 int dispatch3(const Problem& q) {
     int v = g_forced_variant;
@@ -914,9 +956,13 @@ int dispatch3(const Problem& q) {
             // several batch entries of <= 64 rows (multi-tenant prefill of short prompts, demo_backend.py:297-299): two entries per 128-row
             // tile share one W stream; narrow outputs add split-k (tools/bench_mt_prefill.py, 6 tenants x 64 rows, Mistral-7B shapes:
             // q|k|v 59 -> 50 us, o 39 -> 33, gate|up 201 -> 177, down 130 -> 91; profiles/r04_mt_prefill_tiles.txt)
+            // Round 5: the same tiles on the FOUR-WAVE schedule (bd_gemm_w4.h PAIR; variants 18 / 19) -- q|k|v 51.6 -> 51.4 us, o 35.3 -> 32.2,
+            // gate|up 192 -> 162 (1.12 PF useful), down 94.6 -> 83.4: -12 % per layer (profiles/r05_mt_prefill_tiles.txt).  Its split-k
+            // slices are whole runs of k-tiles: when the slice count does not divide K / 64 the 8-wave kernel keeps the launch.
             const int kp = pair_splitk(q);
-            v = (kp > 1 && q.N % 8 == 0 && q.sCm % 4 == 0 && q.sCb % 4 == 0 && q.ws &&
-                 q.ws_bytes >= GEMV_TICKET_BYTES + (int64_t)q.B * kp * q.M * q.N * 4) ? 17 : 16;
+            const bool split = kp > 1 && q.N % 8 == 0 && q.sCm % 4 == 0 && q.sCb % 4 == 0 && q.ws &&
+                               q.ws_bytes >= GEMV_TICKET_BYTES + (int64_t)q.B * kp * q.M * q.N * 4;
+            v = split ? (((q.K / 64) % kp == 0) ? 19 : 17) : 18;
         }
         else if (FUSED && q.M > 16 && !q.accumulate && q.sCm % 4 == 0 && q.sCb % 4 == 0 && splitk_factor(q.B, q.M, q.N, q.K) > 1 && q.ws &&
                  q.ws_bytes >= GEMV_TICKET_BYTES + (int64_t)q.B * splitk_factor(q.B, q.M, q.N, q.K) * q.M * q.N * 4) v = 10;
@@ -939,14 +985,14 @@ int dispatch3(const Problem& q) {
         else v = 3;
     } else {
         if ((v == 200 || v == 300 || v == 400 || v == 500 || v == 600) && !gemv_ok(q)) return BD_E_BAD_SHAPE;
-        if (v >= 0 && v <= 17 && !fast_ok(q)) return BD_E_BAD_SHAPE;
-        if ((v == 16 || v == 17) && !FUSED) return BD_E_BAD_SHAPE;
+        if (v >= 0 && v <= 19 && !fast_ok(q)) return BD_E_BAD_SHAPE;
+        if ((v == 16 || v == 17 || v == 18 || v == 19) && !FUSED) return BD_E_BAD_SHAPE;
         if (v == 15 && (!FUSED || OUT_F32 || q.epilogue != 1)) return BD_E_BAD_SHAPE;
         if (v == 13 && FUSED) return BD_E_BAD_SHAPE;
         if (v == 14 && !FUSED) return BD_E_BAD_SHAPE;
         if ((v == 8 || v == 9 || v == 10 || v == 11 || v == 12) && !FUSED) return BD_E_BAD_SHAPE;
         if (v == 10 && (q.N % 8 || q.sCm % 4 || q.sCb % 4 || q.accumulate)) return BD_E_BAD_SHAPE;
-        if (FUSED && q.accumulate && !(v == 8 || v == 9 || v == 11 || v == 12 || v == 14 || v == 16 || v == 17 || v == 200 || v == 300 || v == 400 || v == 500 || v == 600))
+        if (FUSED && q.accumulate && !(v == 8 || v == 9 || v == 11 || v == 12 || v == 14 || v == 16 || v == 17 || v == 18 || v == 19 || v == 200 || v == 300 || v == 400 || v == 500 || v == 600))
             return BD_E_BAD_SHAPE;            // residual epilogue: one-pass fused tiles and the decode kernels only
     }
     t_last_variant = v;
@@ -1002,6 +1048,19 @@ int dispatch3(const Problem& q) {
                 if (ks < 2) ks = (q.K / 64 >= 2) ? 2 : 1;
                 if (ks < 2 || ks > q.K / 64) return BD_E_BAD_SHAPE;       // every k slice holds at least one 64-k tile (no empty slices)
                 return launch_pair_splitk<DT>(q, ks);
+            } else return BD_E_BAD_SHAPE;
+        }
+        case 18:     // FOUR-WAVE pair tiles (bd_gemm_w4.h PAIR): one wave per SIMD, wave tile 64 x 64, persistent over (pair, column tile)
+            if constexpr (FUSED) { if (!pair_ok(q)) return BD_E_BAD_SHAPE; return launch_w4_pair<DT, OUT_F32>(q); }
+            else return BD_E_BAD_SHAPE;
+        case 19: {   // four-wave pair tiles + split-k (the narrow outputs of a multi-tenant request)
+            if constexpr (FUSED) {
+                if (!pair_ok(q) || q.N % 8 || q.sCm % 4 || q.sCb % 4) return BD_E_BAD_SHAPE;
+                int ks = pair_splitk(q);
+                if (ks < 2) ks = 2;
+                while (ks > 1 && (q.K / 64) % ks) --ks;                   // the slices are whole, equal runs of k-tiles
+                if (ks < 2) return BD_E_BAD_SHAPE;
+                return launch_w4_pair_splitk<DT>(q, ks);
             } else return BD_E_BAD_SHAPE;
         }
         case 9:      // one-pass fused, 128x128 tile, 4-slot ring: twice the tiles when 256x128 cannot fill the CUs (128 < M <~ 768)
@@ -1095,7 +1154,7 @@ extern "C" int64_t bd_gemm_workspace_bytes(int B, int M, int N, int K) {
             if (ks < 2 && g_forced_variant == 10) ks = 2;
             if (B >= 2 && M <= 64) {                      // pair tiles (variants 16 / 17) split by their own rule
                 int kp = pair_splitk_dims(B, N, K);
-                if (kp < 2 && g_forced_variant == 17) kp = 2;
+                if (kp < 2 && (g_forced_variant == 17 || g_forced_variant == 19)) kp = 2;
                 if (kp > ks) ks = kp;
             }
             if (ks < 2) return 0;

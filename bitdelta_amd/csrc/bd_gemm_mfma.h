@@ -43,6 +43,7 @@ struct GemmParams {
     int round_mode;           // 1: fp32 -> fp16 -> out (reference epilogue); 0: fp32 -> out
     int accumulate;           // delta-only: C = C_in + alpha * acc  (adds the delta onto an existing base GEMM result)
     int nbatch;               // bd_gemm_w4.h only (persistent grid over batch x tiles; the other kernels take the batch from blockIdx.y)
+    int nent;                 // bd_gemm_w4.h pair tiles only: batch entries of the problem (nbatch = pairs = (nent + 1) / 2)
     int group_m;              // tile order: tiles are walked in groups of group_m tile rows, m fastest inside a group, then n.
                               // 1 = n fastest (an XCD's contiguous run shares X row panels in its L2; right when the other
                               // operand is the tiny packed mask); tiles_m = m fastest (the XCD owns a column slice of W);

@@ -41,19 +41,23 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
 }
 
 // EPI_ = 1 (fused, 16-bit output only): SwiGLU epilogue over an 8-interleaved gate|up projection -- C has N/2 columns
-template <int DT_, int BM_, int BN_, bool FUSED_, bool OUT_F32_, int OPT_ = 0, int EPI_ = 0>
+// PAIR_ = 1 (fused, 128 x 128 tile): the tile's two 64-row wave rows are TWO batch entries of <= 64 rows each (the multi-tenant prefill of short
+//   prompts, demo/demo_backend.py:297-299: 6 tenants x 64 rows) -- one W stream per tile serves both, each wave row reads its own entry's X rows
+//   and sign words.  Wave tile 64 x 64 x {W, S} = 8 accumulators; a region is one B fragment x TWO X fragments.
+template <int DT_, int BM_, int BN_, bool FUSED_, bool OUT_F32_, int OPT_ = 0, int EPI_ = 0, int PAIR_ = 0>
 struct W4Cfg {
-    static constexpr int DT = DT_, BM = BM_, BN = BN_, NS = 3, OPT = OPT_, EPI = EPI_;
+    static constexpr int DT = DT_, BM = BM_, BN = BN_, NS = 3, OPT = OPT_, EPI = EPI_, PAIR = PAIR_;
     static_assert(EPI_ == 0 || (FUSED_ && !OUT_F32_), "SwiGLU epilogue: fused kernel, 16-bit output");
     static constexpr bool FUSED = FUSED_, OUT_F32 = OUT_F32_;
     static constexpr int WAVES_M = 2, WAVES_N = 2, NW = 4, NT = 256;
     static constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     static constexpr int NB = 4;                                   // B-operand fragments per k-step (delta: 4 S; fused: W0 S0 W1 S1)
-    static_assert(TM == 4 && (FUSED ? TN == 2 : TN == 4), "wave tile: 128 rows x 4 B fragments");
-    static constexpr int A_BYTES = BM * 128, W_BYTES = FUSED ? BN * 128 : 0, BW_BYTES = BN * 8;
+    static_assert((PAIR ? (TM == 2 && FUSED && EPI_ == 0) : TM == 4) && (FUSED ? TN == 2 : TN == 4), "wave tile: 4 B fragments x 4 (pair: 2) row blocks");
+    static constexpr int NENT = PAIR ? 2 : 1;                      // batch entries per tile (one per wave row)
+    static constexpr int A_BYTES = BM * 128, W_BYTES = FUSED ? BN * 128 : 0, BW_BYTES = BN * 8 * NENT;
     static constexpr int BW_OFF = A_BYTES + W_BYTES;
     static constexpr int STAGE = A_BYTES + W_BYTES + BW_BYTES;
-    static constexpr int A_PW = BM / 8 / NW, W_PW = FUSED ? BN / 8 / NW : 0, BW_PIECES = BN / 32, BW_PW = BW_PIECES / NW;
+    static constexpr int A_PW = BM / 8 / NW, W_PW = FUSED ? BN / 8 / NW : 0, BW_PIECES = BN / 32 * NENT, BW_PW = BW_PIECES / NW;
     static_assert(BW_PIECES % NW == 0, "sign-word pieces vs waves");
     static constexpr int DPW = A_PW + W_PW + BW_PW;                // LDS-DMA pieces per wave per k-tile
     static constexpr bool USE_LUT = (OPT & 1) != 0;
@@ -135,7 +139,7 @@ __device__ __forceinline__ void w4_dma4_m0(uint32_t voff, const void* sbase) {
 // Value transforms are gemm_epilogue's (bd_gemm_mfma.h).
 template <class Cfg>
 __device__ __forceinline__ void w4_epilogue(const GemmParams& p, f32x16_t (&acc)[4][Cfg::TM], char* stg, int m0, int n0, int wm, int wn,
-                                            int b, int lane, int wave) {
+                                            int b, int lane, int wave, int b_alpha = -1) {
     constexpr int DT = Cfg::DT, WM = Cfg::WM, WN = Cfg::WN, TM = Cfg::TM, TN = Cfg::TN, JC = Cfg::JC, ESZ = Cfg::ESZ;
     constexpr int ROWB = Cfg::STG_ROWB;
     constexpr bool FUSED = Cfg::FUSED;
@@ -148,7 +152,8 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, f32x16_t (&acc)
     const bool acc_mode = !FUSED && p.accumulate;
     const bool res_mode = FUSED && p.accumulate;
     const bool rm16 = !FUSED && p.round_mode == 1;
-    const float* al = (FUSED || acc_mode) ? p.alpha + (long long)b * p.sAlb : nullptr;
+    // (b_alpha: split-k pair tiles store to slab b = entry * ksplit + slice but scale with the ENTRY's alpha)
+    const float* al = (FUSED || acc_mode) ? p.alpha + (long long)(b_alpha >= 0 ? b_alpha : b) * p.sAlb : nullptr;
     // this lane's column scale per column block.  One scale group (the reference's scalar coeff): a scalar load.  Grouped scales: per-lane
     // loads, retired at once with a wait the compiler's waitcnt pass can see -- a VMEM load it believes pending at the k-loop entry makes
     // it put `s_waitcnt vmcnt(0)` in front of the first reuse of that register INSIDE the k loop, which drains the LDS-DMA ring every
@@ -168,7 +173,9 @@ __device__ __forceinline__ void w4_epilogue(const GemmParams& p, f32x16_t (&acc)
     }
     const bool fast = Cfg::FAST_EPI && !acc_mode && (p.N % 8 == 0) && (p.sCm % 8 == 0) && (p.sCb % 8 == 0) && (((uintptr_t)p.C & 15) == 0);
     char* buf = stg + wave * Cfg::STG_PW;
-    const bool inside = (m0 + Cfg::BM <= p.M) && (n0 + Cfg::BN <= p.N);      // wave-uniform: interior tiles store without guards
+    // pair tiles: `b` is this wave row's OWN batch entry and its rows start at 0 (the caller passes m0 = 0)
+    if constexpr (Cfg::PAIR) wm = 0;
+    const bool inside = (m0 + (Cfg::PAIR ? Cfg::WM : Cfg::BM) <= p.M) && (n0 + Cfg::BN <= p.N);      // wave-uniform: interior tiles store without guards
 
     auto pack2 = [&](float lo, float hi) -> uint32_t {
         if constexpr (DT == DT_BF16) {
@@ -544,7 +551,9 @@ __global__ void __launch_bounds__(256) delta_gemm_w4_kernel(const GemmParams p) 
     const int ntiles = p.tiles_m * p.tiles_n;
     const int ntotal = ntiles * max(p.nbatch, 1);          // the persistent stream runs over (batch entry, tile) pairs
     const int G = (int)gridDim.x;
-    const int nk = p.K >> 6;
+    // k-tiles of ONE stream element.  Pair tiles with p.ksplit > 1: the batch index of the persistent stream is pair * ksplit + slice, a slice
+    // contracts k-tiles [slice * nk, (slice + 1) * nk) and stores its fp32 partial to slab (entry * ksplit + slice) of C (host: nk divides)
+    const int nk = Cfg::PAIR ? (p.K >> 6) / p.ksplit : (p.K >> 6);
 
     uint32_t one2;
     asm volatile("v_mov_b32 %0, %1" : "=v"(one2) : "n"(One2<DT>::v));
@@ -568,7 +577,7 @@ __global__ void __launch_bounds__(256) delta_gemm_w4_kernel(const GemmParams p) 
         a_rd[s] = (uint32_t)(wm * WM + l31) * 128u + (uint32_t)(((4 * h + s) ^ swz) * 16);
         w_rd[s] = A_BYTES + (uint32_t)(wn * WN + l31) * 128u + (uint32_t)(((4 * h + s) ^ swz) * 16);
     }
-    const uint32_t bw_rd = BW_OFF + h * BN * 4 + (wn * WN + l31) * 4;
+    const uint32_t bw_rd = BW_OFF + (Cfg::PAIR ? wm * BN * 8 : 0) + h * BN * 4 + (wn * WN + l31) * 4;    // (pair: this wave row's entry's words)
 
     // ---- loader state: the k-tile being fetched (two ahead of the one being multiplied), across tile boundaries.
     //      Running wave-uniform source pointers (advanced by one k-tile per iteration), per-lane offsets fixed per tile.
@@ -581,16 +590,21 @@ __global__ void __launch_bounds__(256) delta_gemm_w4_kernel(const GemmParams p) 
     uint32_t bw_ldsw[BW_PW];
 #pragma unroll
     for (int i = 0; i < BW_PW; ++i) {
-        const int idx = wave * BW_PW + i;
+        const int idx = wave * BW_PW + i;          // LDS image [entry][word row 0..1][BN] dwords; a piece = 64 columns of one word row
         bw_ldsw[i] = lds0 + BW_OFF + (idx / (BN / 64)) * BN * 4 + (idx % (BN / 64)) * 256;
     }
     auto loader_tile = [&](int r) {
         int tm, tn, b;
         if (!tile_of(r, tm, tn, b)) { if (!tile_of(r - 1 >= 0 ? r - 1 : 0, tm, tn, b)) { tm = 0; tn = 0; b = 0; } }   // past the end: re-fetch (never read)
         const int m0 = tm * BM, n0 = tn * BN;
-        ld_a = p.A + ((long long)b * p.sAb + (long long)m0 * p.sAm) * 2;
-        ld_p = (const char*)p.P + ((long long)b * p.sPb + n0) * 4;
-        if constexpr (FUSED) ld_w = p.W + (long long)n0 * p.ldw * 2;
+        // pair tiles: b = pair index; entries 2b and 2b + 1 (the second clamped to the last entry of an odd batch: its rows are computed and
+        // dropped); entry offsets ride in the 32-bit per-lane offsets (host: sAb < 2^30, sPb < 2^29)
+        const int ksl = Cfg::PAIR ? b % p.ksplit : 0;                       // k slice of this stream element
+        const int e0 = Cfg::PAIR ? 2 * (b / p.ksplit) : b;
+        const int e1off = Cfg::PAIR ? (min(e0 + 1, p.nent - 1) - e0) : 0;
+        ld_a = p.A + ((long long)e0 * p.sAb + (long long)m0 * p.sAm) * 2 + (long long)ksl * nk * 128;
+        ld_p = (const char*)p.P + ((long long)e0 * p.sPb + n0) * 4 + (long long)ksl * nk * p_step;
+        if constexpr (FUSED) ld_w = p.W + (long long)n0 * p.ldw * 2 + (long long)ksl * nk * 128;
         int ln = lane;
         asm volatile("" : "+v"(ln));                                        // recomputed per tile, not hoisted + spilled
 #pragma unroll
@@ -598,8 +612,13 @@ __global__ void __launch_bounds__(256) delta_gemm_w4_kernel(const GemmParams p) 
             const int rg = wave * A_PW + i;
             const int r8 = rg * 8 + (ln >> 3);
             const int c = (ln & 7) ^ ((r8 >> 1) & 7);
-            const int rr = min(m0 + r8, p.M - 1) - m0;
-            a_voff[i] = (uint32_t)rr * (uint32_t)p.sAm * 2u + (uint32_t)c * 16u;
+            if constexpr (Cfg::PAIR) {
+                const int ent = r8 >> 6, rr = min(r8 & 63, p.M - 1);       // LDS rows 0..63 = entry 2b, 64..127 = entry 2b + 1
+                a_voff[i] = (uint32_t)(ent * e1off) * (uint32_t)p.sAb * 2u + (uint32_t)rr * (uint32_t)p.sAm * 2u + (uint32_t)c * 16u;
+            } else {
+                const int rr = min(m0 + r8, p.M - 1) - m0;
+                a_voff[i] = (uint32_t)rr * (uint32_t)p.sAm * 2u + (uint32_t)c * 16u;
+            }
         }
         if constexpr (FUSED) {
 #pragma unroll
@@ -614,9 +633,9 @@ __global__ void __launch_bounds__(256) delta_gemm_w4_kernel(const GemmParams p) 
 #pragma unroll
         for (int i = 0; i < BW_PW; ++i) {
             const int idx = wave * BW_PW + i;
-            const int hh = idx / (BN / 64), seg = idx % (BN / 64);
+            const int ent = idx / (2 * (BN / 64)), hh = (idx / (BN / 64)) & 1, seg = idx % (BN / 64);
             const int nn = min(n0 + seg * 64 + ln, p.N - 1) - n0;
-            bw_voff[i] = (uint32_t)hh * (uint32_t)p.N * 4u + (uint32_t)nn * 4u;
+            bw_voff[i] = (uint32_t)(ent * e1off) * (uint32_t)p.sPb * 4u + (uint32_t)hh * (uint32_t)p.N * 4u + (uint32_t)nn * 4u;
         }
     };
     // piece pc of the loader's current k-tile into the ring slot at byte offset slot_off
@@ -737,8 +756,8 @@ __global__ void __launch_bounds__(256) delta_gemm_w4_kernel(const GemmParams p) 
         if constexpr (bb < 2 && !((Cfg::OPT & 32) && MF)) {
             const char* st = (s == 3) ? st_nxt : st_cur;
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii) {
-                const int i = 2 * bb + ii;
+            for (int ii = 0; ii < TM / 2; ++ii) {                       // (two each; pair tiles: one each)
+                const int i = (TM / 2) * bb + ii;
                 xf[(s + 1) & 1][i] = *(const u32x4_t*)(st + a_rd[(s + 1) & 3] + i * 4096);
             }
         }
@@ -773,7 +792,21 @@ __global__ void __launch_bounds__(256) delta_gemm_w4_kernel(const GemmParams p) 
             constexpr bool commits = !USE_LUT && (g >= 13 || (g == 0 && TN == 4));
             constexpr bool s_type = !(FUSED && !(((g + 3) & 3) & 1));
             constexpr int nvalu = (s_type ? (USE_LUT ? 2 : 8) : 0) + (commits ? 4 : 0) + 2;
-            if constexpr ((Cfg::OPT & 64) && p1 - p0 == 1) {
+            if constexpr (TM == 2) {
+                // pair tiles: two MFMAs per region -- [MFMA, <= 2 DS, half the VALU] twice, the LDS-DMA piece(s) behind the second
+                constexpr int vq = (nvalu + 1) / 2;
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, vq, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, vq, 0);
+                if constexpr (p1 > p0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    dma_piece(IC<p0>{}, slot_ld);
+                    if constexpr (p1 - p0 > 1) dma_piece(IC<(p0 + 1 < DPW ? p0 + 1 : p0)>{}, slot_ld);
+                }
+            } else if constexpr ((Cfg::OPT & 64) && p1 - p0 == 1) {
                 // split form: [MFMA MFMA] m0 write [MFMA MFMA] load -- each statement alone in its gap
                 constexpr int vq = (nvalu + 3) / 4;
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -934,7 +967,12 @@ __global__ void __launch_bounds__(256) delta_gemm_w4_kernel(const GemmParams p) 
                 deferred = true;
             }
         }
-        if (!deferred) w4_epilogue<Cfg>(p, acc, smem + Cfg::STG_OFF, m0, n0, wm, wn, b_c, lane, wave);
+        if (!deferred) {
+            if constexpr (Cfg::PAIR) {       // each wave row stores its own entry (the absent partner of an odd batch stores nothing)
+                const int ent = 2 * (b_c / p.ksplit) + wm;
+                if (ent < p.nent) w4_epilogue<Cfg>(p, acc, smem + Cfg::STG_OFF, 0, n0, wm, wn, ent * p.ksplit + b_c % p.ksplit, lane, wave, ent);
+            } else w4_epilogue<Cfg>(p, acc, smem + Cfg::STG_OFF, m0, n0, wm, wn, b_c, lane, wave);
+        }
         BD_W4_STAMP(r, 4);
         if (!more) break;
         tm_c = tm_n; tn_c = tn_n; b_c = b_n;

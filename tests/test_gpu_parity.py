@@ -254,7 +254,14 @@ LINEAR_SHAPES = [sh for sh in SHAPES if not (sh[5] in (0, 5, 13))] + [(3, 130, 1
                           # rows per entry, a broadcast mask shared by the pair, a single k-tile per slice, wide N, and the automatic choice
                           (6, 64, 512, 640, 6, 16), (3, 33, 256, 264, 3, 16), (5, 64, 1024, 384, 5, 16), (2, 17, 192, 136, 2, 16),
                           (4, 64, 512, 640, 1, 16), (4, 64, 256, 8200, 4, 16), (6, 64, 4096, 512, 6, 17), (3, 33, 2048, 264, 3, 17),
-                          (5, 40, 1024, 1032, 5, 17), (2, 64, 128, 136, 2, 17), (6, 48, 2048, 1024, 6, None), (2, 64, 4096, 256, 2, None)]
+                          (5, 40, 1024, 1032, 5, 17), (2, 64, 128, 136, 2, 17), (6, 48, 2048, 1024, 6, None), (2, 64, 4096, 256, 2, None),
+                          # 18 = FOUR-WAVE pair tiles (bd_gemm_w4.h PAIR: one wave per SIMD, wave tile 64 x 64, persistent over (pair, column tile)):
+                          # even / odd batches, ragged rows per entry, a broadcast mask, k shorter than the ring, ragged and wide N, several rounds
+                          (6, 64, 512, 640, 6, 18), (3, 33, 256, 264, 3, 18), (5, 64, 1024, 384, 5, 18), (2, 17, 192, 136, 2, 18),
+                          (4, 64, 512, 640, 1, 18), (4, 64, 256, 8200, 4, 18), (2, 64, 64, 136, 2, 18), (7, 48, 128, 33000, 7, 18),
+                          # 19 = the same + split-k (slices of whole k-tiles; fp32 slabs + the reduce launch)
+                          (6, 64, 4096, 512, 6, 19), (3, 33, 2048, 264, 3, 19), (5, 40, 1024, 1032, 5, 19), (2, 64, 128, 136, 2, 19),
+                          (4, 64, 1536, 640, 1, 19)]
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -293,7 +300,7 @@ def test_binary_linear_vs_oracle(bd, oracle, dtype, shape):
                 bd.binary_linear(dev(a), dev(w), dev(p), dev(alpha), out_dtype=od, out=cn.view)
                 assert torch.equal(cn.result(), plain), od
                 assert cn.untouched_outside(), ("output margin overwritten", od)
-            if variant is None or variant in (8, 9, 11, 12, 14, 16, 17) or variant >= 200:      # families with a residual epilogue (bd_api.hip)
+            if variant is None or variant in (8, 9, 11, 12, 14, 16, 17, 18, 19) or variant >= 200:      # families with a residual epilogue (bd_api.hip)
                 cn = CanaryOut(B, M, N, dtype)
                 r = torch.randn(B, M, N).to(dtype)
                 cn.view.copy_(dev(r))
