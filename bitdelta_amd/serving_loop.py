@@ -310,8 +310,13 @@ class TenantDecoder(nn.Module):
         return {"k": [mk() for _ in self.layers], "v": [mk() for _ in self.layers],
                 "valid": torch.zeros(self.T, length, dtype=torch.bool, device=self.dev)}
 
+    # prefill: the HIP per-tenant RMSNorm (ONE launch) up to this many rows; stock torch beyond (F.rms_norm + the weight multiply = three
+    # launches, but faster per row on long prompts: 2048-row prefill 8.5 vs 13.1 us, profiles/r03_prefill_glue.txt).  A 6-tenant request
+    # padded to 64 tokens (384 rows) spends 15.5 us per norm in the three torch kernels against ~5 us here (profiles/r05_mt_prefill_tiles.txt).
+    HIP_NORM_MAX_ROWS = 1024
+
     def _norm(self, x, w):
-        if x.shape[1] <= 16 and self.fast_glue and x.shape[-1] % 8 == 0:
+        if self.fast_glue and x.shape[-1] % 8 == 0 and (x.shape[1] <= 16 or x.shape[0] * x.shape[1] <= self.HIP_NORM_MAX_ROWS):
             return ops.rmsnorm_tenant(x if x.is_contiguous() else x.contiguous(), w, self.eps)
         return F.rms_norm(x, (x.shape[-1],), None, self.eps) * w[:, None, :]
 
