@@ -732,10 +732,12 @@ int launch_tile(const Problem& q, int col0 = 0) {          // col0 > 0: only til
 // Four-wave persistent kernels (bd_gemm_w4.h): grid = min(batch x tiles, CUs) workgroups of 256 threads, each walking its share of the
 // (batch entry, tile) stream.
 // cols >= 0: only tile columns [0, cols) of the problem (the rest goes to another launch: launch_fused_tail_split)
+// col0 > 0: only tile columns [col0, tiles_n) (the tail launch of launch_fused_tail_split)
 template <class Cfg>
-int launch_w4(const Problem& q, int cols = -1) {
+int launch_w4(const Problem& q, int cols = -1, int col0 = 0) {
     GemmParams p = make_params(q, Cfg::BM, Cfg::BN);
     if (cols >= 0) p.tiles_n = cols;
+    if (col0 > 0) { p.tile_n0 = col0; p.tiles_n -= col0; if (p.tiles_n <= 0) return BD_OK; }
     auto kern = delta_gemm_w4_kernel<Cfg>;
     static std::atomic<uint64_t> lds_done{0};
     if (!ensure_dyn_lds((const void*)kern, Cfg::LDS_BYTES, lds_done)) return BD_E_LAUNCH;
@@ -772,11 +774,14 @@ inline int choose_big_tile(const Problem& q) {
 // one-pass fused kernel: 256x128 tile vs 128x128 tile.  Rounds of CU-wide tile waves x measured relative tile cost: a 128x128 tile
 // takes ~0.70 of a 256x128 tile's k loop (profiles/r01_small_m.txt), so it wins exactly when it does not add rounds (M <~ 1024 at
 // N = 4096; M <= 256 at N = 11008).
-inline int choose_fused_tile(const Problem& q) {
+// (round 5: the 128x128 tile on the four-wave schedule, variant 20, takes ~0.64 of a four-wave 256x128 tile's k loop -- tools/ab_w4_128.py:
+//  M = 512 gate|up 3 rounds in 145.9 us vs 2 rounds in 149.9; M = 768 q|k|v 133.5 vs 138.7 -- and is 5..17 % faster than the 8-wave 128x128
+//  tile on every shape measured: profiles/r05_mt_prefill_tiles.txt)
+inline int choose_fused_tile(const Problem& q, double rel128 = 0.70) {
     const long long cus = num_cus();
     const long long tn = (q.N + 127) / 128;
     const long long t8 = (q.M + 255) / 256 * tn * q.B, t9 = (q.M + 127) / 128 * tn * q.B;
-    const double c8 = (double)((t8 + cus - 1) / cus), c9 = (double)((t9 + cus - 1) / cus) * 0.70;
+    const double c8 = (double)((t8 + cus - 1) / cus), c9 = (double)((t9 + cus - 1) / cus) * rel128;
     return c9 < c8 ? 9 : 8;
 }
 
@@ -971,10 +976,12 @@ int dispatch3(const Problem& q) {
             // 6 tenants x 64 rows: q+k+v 56 vs 76 us, gate+up 207 vs 253 us, but o 54 vs 38 us (tools/bench_mt_prefill.py)
             v = ((long long)((q.N + 255) / 256) * q.B * 2 >= num_cus()) ? 12 : 11;
         else if (FUSED && q.M > 16) {
-            v = choose_fused_tile(q);     // fused: one-pass kernel (profiles/r01_fx_vs_two_loop.txt, r01_small_m.txt,
+            v = choose_fused_tile(q, OUT_F32 ? 0.70 : 0.64);     // fused: one-pass kernel (profiles/r01_fx_vs_two_loop.txt, r01_small_m.txt,
                                           // r01_mid_m.txt: also for 16 < M <= 64, rows padded to the 128-row tile)
-            // same 256x128 tile on the four-wave persistent schedule: +4..7 % on every shape measured (profiles/r03_w4_*.txt)
+            // same tiles on the four-wave persistent schedule: 256x128 +4..7 % on every shape measured (profiles/r03_w4_*.txt), 128x128
+            // +5..17 % (round 5)
             if (v == 8 && !OUT_F32) v = 14;
+            if (v == 9 && !OUT_F32) v = 20;
         } else if (q.M > 128) {
             v = choose_big_tile(q);
             // four-wave persistent 256x256 kernel once its tiles keep >= 80 % of the CU-rounds busy (it has no 256x128 form)
@@ -985,14 +992,14 @@ int dispatch3(const Problem& q) {
         else v = 3;
     } else {
         if ((v == 200 || v == 300 || v == 400 || v == 500 || v == 600) && !gemv_ok(q)) return BD_E_BAD_SHAPE;
-        if (v >= 0 && v <= 19 && !fast_ok(q)) return BD_E_BAD_SHAPE;
-        if ((v == 16 || v == 17 || v == 18 || v == 19) && !FUSED) return BD_E_BAD_SHAPE;
+        if (v >= 0 && v <= 20 && !fast_ok(q)) return BD_E_BAD_SHAPE;
+        if ((v == 16 || v == 17 || v == 18 || v == 19 || v == 20) && !FUSED) return BD_E_BAD_SHAPE;
         if (v == 15 && (!FUSED || OUT_F32 || q.epilogue != 1)) return BD_E_BAD_SHAPE;
         if (v == 13 && FUSED) return BD_E_BAD_SHAPE;
         if (v == 14 && !FUSED) return BD_E_BAD_SHAPE;
         if ((v == 8 || v == 9 || v == 10 || v == 11 || v == 12) && !FUSED) return BD_E_BAD_SHAPE;
         if (v == 10 && (q.N % 8 || q.sCm % 4 || q.sCb % 4 || q.accumulate)) return BD_E_BAD_SHAPE;
-        if (FUSED && q.accumulate && !(v == 8 || v == 9 || v == 11 || v == 12 || v == 14 || v == 16 || v == 17 || v == 18 || v == 19 || v == 200 || v == 300 || v == 400 || v == 500 || v == 600))
+        if (FUSED && q.accumulate && !(v == 8 || v == 9 || v == 11 || v == 12 || v == 14 || v == 16 || v == 17 || v == 18 || v == 19 || v == 20 || v == 200 || v == 300 || v == 400 || v == 500 || v == 600))
             return BD_E_BAD_SHAPE;            // residual epilogue: one-pass fused tiles and the decode kernels only
     }
     t_last_variant = v;
@@ -1053,6 +1060,9 @@ int dispatch3(const Problem& q) {
         case 18:     // FOUR-WAVE pair tiles (bd_gemm_w4.h PAIR): one wave per SIMD, wave tile 64 x 64, persistent over (pair, column tile)
             if constexpr (FUSED) { if (!pair_ok(q)) return BD_E_BAD_SHAPE; return launch_w4_pair<DT, OUT_F32>(q); }
             else return BD_E_BAD_SHAPE;
+        case 20:     // four-wave fused 128x128 tile, ONE batch entry per tile (prompts of 65 .. 128 rows per tenant; W4Cfg TM = 2, PAIR = 0)
+            if constexpr (FUSED) return launch_w4<W4Cfg<DT, 128, 128, true, OUT_F32, 1 | 8192, 0, 0>>(q);
+            else return BD_E_BAD_SHAPE;
         case 19: {   // four-wave pair tiles + split-k (the narrow outputs of a multi-tenant request)
             if constexpr (FUSED) {
                 if (!pair_ok(q) || q.N % 8 || q.sCm % 4 || q.sCb % 4) return BD_E_BAD_SHAPE;
@@ -1078,7 +1088,9 @@ int dispatch3(const Problem& q) {
                     if (cols > 0) {
                         const int rc = launch_w4<W4Cfg<DT, 256, 128, true, false, 1 | 8192>>(q, cols);
                         if (rc != BD_OK) return rc;
-                        return launch_tile<FxCfg<DT, 128, 128, 4, false, 1>, 3>(q, cols);      // same 128-wide tile columns
+                        // the remaining tile columns on 128x128 tiles -- four-wave since round 5 (variant 20's kernel: 5..17 % faster than the
+                        // 8-wave 128x128 tile on every shape measured); same 128-wide tile columns
+                        return launch_w4<W4Cfg<DT, 128, 128, true, false, 1 | 8192, 0, 0>>(q, -1, cols);
                     }
                 }
                 return launch_w4<W4Cfg<DT, 256, 128, true, OUT_F32, 1 | 8192>>(q);      // (fp32 output: general-form epilogue only)

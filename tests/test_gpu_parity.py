@@ -261,7 +261,10 @@ LINEAR_SHAPES = [sh for sh in SHAPES if not (sh[5] in (0, 5, 13))] + [(3, 130, 1
                           (4, 64, 512, 640, 1, 18), (4, 64, 256, 8200, 4, 18), (2, 64, 64, 136, 2, 18), (7, 48, 128, 33000, 7, 18),
                           # 19 = the same + split-k (slices of whole k-tiles; fp32 slabs + the reduce launch)
                           (6, 64, 4096, 512, 6, 19), (3, 33, 2048, 264, 3, 19), (5, 40, 1024, 1032, 5, 19), (2, 64, 128, 136, 2, 19),
-                          (4, 64, 1536, 640, 1, 19)]
+                          (4, 64, 1536, 640, 1, 19),
+                          # 20 = four-wave 128x128 tile, one entry per tile (65 .. 128 rows per tenant; also ragged M / several row tiles)
+                          (6, 128, 512, 640, 6, 20), (3, 100, 256, 264, 3, 20), (2, 200, 256, 520, 2, 20), (1, 257, 64, 136, 1, 20),
+                          (4, 128, 256, 8200, 1, 20)]
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -300,7 +303,7 @@ def test_binary_linear_vs_oracle(bd, oracle, dtype, shape):
                 bd.binary_linear(dev(a), dev(w), dev(p), dev(alpha), out_dtype=od, out=cn.view)
                 assert torch.equal(cn.result(), plain), od
                 assert cn.untouched_outside(), ("output margin overwritten", od)
-            if variant is None or variant in (8, 9, 11, 12, 14, 16, 17, 18, 19) or variant >= 200:      # families with a residual epilogue (bd_api.hip)
+            if variant is None or variant in (8, 9, 11, 12, 14, 16, 17, 18, 19, 20) or variant >= 200:      # families with a residual epilogue (bd_api.hip)
                 cn = CanaryOut(B, M, N, dtype)
                 r = torch.randn(B, M, N).to(dtype)
                 cn.view.copy_(dev(r))

@@ -21,7 +21,7 @@ for M in (32, 64, 128) if len(sys.argv) <= 2 else [int(a) for a in sys.argv[2:]]
         mask = torch.randint(-2**31, 2**31 - 1, (T, K // 32, N), device=dev, generator=g, dtype=torch.int64).to(torch.int32)
         alpha = torch.full((T, 1), 4e-4, device=dev)
         row = []
-        for v in (-1, 16, 17, 18, 19):
+        for v in (-1, 16, 17, 18, 19, 20, 9):
             if v in (11, 12, 16, 17, 18, 19) and M > 64:
                 continue
             L.bd_set_gemm_variant(v)
