@@ -645,6 +645,10 @@ def run_mt_decode(dev, timer, model_name, tenants, kv_len, steps, warmup, layers
         # event-timed Linear launches of the eager loop: algorithmic bytes / their summed durations
         "linear_gbs": k_bytes / k_ms * 1e-6 if k_ms > 0 else None,
         "linear_frac_of_hbm_peak": (k_bytes / k_ms * 1e-6 / PEAK_HBM_GBS) if k_ms > 0 else None,
+        "linear_note": "event-timed in the EAGER loop (launch gaps included).  Since round 5 the Linear launches also carry the RMSNorm's work "
+                       "(hand-off: producers write sums of squares + the pre-multiplied stream, consumers sum them), so this per-launch figure "
+                       "drops while the step gets faster; `step_frac_of_hbm_peak` (graph replay, all bytes of the step) is the comparable number",
+        "norm_handoff": bool(getattr(dec, "norm_handoff", False)),
         # the whole step against the bytes its Linears must stream (everything else counted as overhead)
         "step_gbs": (lin_bytes + head_bytes) / (best_ms * 1e-3) * 1e-9,
         "step_frac_of_hbm_peak": (lin_bytes + head_bytes) / (best_ms * 1e-3) * 1e-9 / PEAK_HBM_GBS,
