@@ -800,8 +800,8 @@ def main():
                                                  if traffic and n_launch and traffic.get("fused_gemm") else None,
                      "algorithmic_bytes_total": k_bytes, "algorithmic_bytes_per_launch": k_bytes / n_launch if n_launch else None,
                      "kernel": "bd::delta_gemm_w4_kernel<bf16, 256x128 tile, fused> (four-wave persistent one-pass fused kernel: "
-                               "x.W^T + alpha*(x.S), 4*M*N*K flop/launch; a tail split hands the last partial round's columns to "
-                               "bd::delta_gemm_fx_kernel<128x128>)",
+                               "x.W^T + alpha*(x.S), 4*M*N*K flop/launch; a tail split hands the last partial round's columns to the same "
+                               "kernel on 128x128 tiles)",
                      "launches": n_launch, "kernel_ms_total": k_ms, "algorithmic_flops_total": k_flops,
                      "measured_in": "a second pass of the same K steps with one HIP event pair per fused launch (the timed region of `value` "
                                     "carries no events)",
