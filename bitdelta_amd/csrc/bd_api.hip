@@ -20,12 +20,19 @@
 #include "bd_serving.h"
 #include "bd_attn_prefill.h"
 #include <algorithm>
+#include <cstdlib>
 #include <atomic>
 
 using namespace bd;
 
-static thread_local int g_forced_variant = -1;
-static thread_local int g_tail_split = 1;          // A/B hook (bd_set_tail_split)
+// Environment override of the shape -> variant table (build notes): BD_GEMM_VARIANT=<n> is the initial value of every thread's
+// forced variant (exactly bd_set_gemm_variant(n), which still overrides it); BD_TAIL_SPLIT=0 switches the tail split off.  Read once per thread.
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+static thread_local int g_forced_variant = env_int("BD_GEMM_VARIANT", -1);
+static thread_local int g_tail_split = env_int("BD_TAIL_SPLIT", 1) ? 1 : 0;          // A/B hook (bd_set_tail_split)
 static thread_local int g_forced_group_m = 0;        // 0 = automatic tile order
 static thread_local int g_col16_small_lut = -1;      // sign LUT of the 16-column decode kernel: -1 auto, 1 = single 4-KiB table, 0 = 16-copy conflict-free
                                         // table whenever it fits.  Auto = 16 copies for delta-only launches (-16..18 % at 6-8 masks;

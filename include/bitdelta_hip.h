@@ -236,7 +236,10 @@ int bd_merge_delta(void* W, int64_t ldw, const int32_t* P, const float* coeff, i
  * 13 / 14 = the FOUR-WAVE PERSISTENT kernels (bd_gemm_w4.h: one wave per SIMD, 16 AGPR accumulators, grid = min(tiles, CUs)):
  * 13 delta-only on 256x256 tiles (automatic once those tiles fill >= 80 % of the CU-rounds), 14 fused on 256x128 tiles (automatic
  * wherever 8 was; with fp32 output only its general-form epilogue); 15 = 14 with the SwiGLU epilogue (bd_binary_linear_swiglu only).
+ * 16 / 17 = 8-wave PAIR tiles (two batch entries of <= 64 rows per 128x128 tile; 17 + split-k); 18 / 19 = the same on the four-wave schedule
+ * (automatic since round 5); 20 = four-wave fused 128x128 tile, one entry per tile (automatic wherever 9 was, 16-bit outputs).
  * A forced variant whose preconditions fail returns BD_E_BAD_SHAPE instead of silently falling back.
+ * Environment: BD_GEMM_VARIANT=<n> is every thread's initial forced variant (overridden by this call), BD_TAIL_SPLIT=0 disables the tail split.
  * The bd_set_* entry points below are TUNING / TEST HOOKS: thread-local, not part of the stable interface a reference-side binding
  * needs (INTEGRATION.md binds none of them), and free to change between versions. */
 int bd_set_gemm_variant(int variant);

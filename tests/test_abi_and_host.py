@@ -153,3 +153,11 @@ def test_build_gate_is_a_content_hash_of_every_source(tmp_path, monkeypatch):
     api = root / "include" / "bitdelta_hip.h"
     api.write_bytes(api.read_bytes() + b"\n")
     assert b.needs_build()
+
+
+def test_variant_table_has_an_environment_override():
+    """SURVEY.md section 5 build note: the shape -> variant table can be overridden from the environment (BD_GEMM_VARIANT), not only through
+    the bd_set_gemm_variant hook -- checked on the source (the library reads it once per thread) and on the header that documents it."""
+    api = open(os.path.join(ROOT, "bitdelta_amd", "csrc", "bd_api.hip")).read()
+    assert 'env_int("BD_GEMM_VARIANT", -1)' in api and 'env_int("BD_TAIL_SPLIT", 1)' in api
+    assert "BD_GEMM_VARIANT" in open(os.path.join(ROOT, "include", "bitdelta_hip.h")).read()

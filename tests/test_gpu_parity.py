@@ -775,3 +775,24 @@ def test_per_device_kernel_attributes_on_second_gpu(bd):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert torch.equal(outs[0][0], outs[2][0])
     assert torch.equal(outs[0][1], outs[0][0][:, :1]) or (outs[0][1].float() - outs[0][0][:, :1].float()).abs().max() < 1e-2
+
+
+def test_environment_override_of_the_variant_table(bd):
+    """BD_GEMM_VARIANT in the environment = every thread's initial forced variant (SURVEY.md section 5 build note): a child process with
+    BD_GEMM_VARIANT=20 runs a fused Linear the automatic rule would give to another tile, and reports the variant that ran."""
+    import subprocess
+    code = ("import torch, bitdelta_amd as bd; from bitdelta_amd import _lib; "
+            "x = torch.randn(1, 256, 512, device='cuda').bfloat16(); w = (torch.randn(1024, 512, device='cuda') * 0.02).bfloat16(); "
+            "p = torch.randint(-2**31, 2**31 - 1, (1, 16, 1024), device='cuda', dtype=torch.int64).to(torch.int32); "
+            "bd.binary_linear(x, w, p, torch.full((1, 1), 4e-4, device='cuda')); print('variant', _lib.lib().bd_last_gemm_variant())")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for v in (None, "20", "9"):
+        env = dict(os.environ)
+        env.pop("BD_GEMM_VARIANT", None)
+        if v is not None:
+            env["BD_GEMM_VARIANT"] = v
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs[v] = int(r.stdout.strip().split()[-1])
+    assert outs["20"] == 20 and outs["9"] == 9 and outs[None] not in (-1,), outs
