@@ -24,3 +24,13 @@ def oracle():
     from oracle import bd_oracle
     bd_oracle.lib()
     return bd_oracle
+
+
+@pytest.fixture(autouse=True)
+def _seed_unseeded_draws(request):
+    """Every test starts from its OWN global RNG state (a hash of its node id): draws that do not pass a generator are reproducible and do not
+    depend on which tests ran before (a 1-in-40 tolerance miss in a residual check surfaced only under one test ordering -- round 5)."""
+    import zlib
+    import torch
+    torch.manual_seed(zlib.crc32(request.node.nodeid.encode()) & 0x7fffffff)
+    yield

@@ -309,7 +309,8 @@ def test_binary_linear_vs_oracle(bd, oracle, dtype, shape):
                 cn.view.copy_(dev(r))
                 bd.binary_linear(dev(a), dev(w), dev(p), dev(alpha), residual=cn.view)
                 got = cn.result().cpu().float()
-                assert ((got - (r.float() + ref32)).abs() <= (r.float().abs() + ref32.abs()) * (2 ** -7 if dtype == torch.bfloat16 else 2 ** -10) + 1e-4).all()
+                # (up to one ulp of the Linear output + one ulp of the sum: two roundings at M > 16, and the kernel may sit 1 ulp from the oracle)
+                assert ((got - (r.float() + ref32)).abs() <= (r.float().abs() + ref32.abs()) * (2 ** -6 if dtype == torch.bfloat16 else 2 ** -9) + 1e-4).all()
                 assert cn.untouched_outside(), "residual epilogue wrote outside the output"
             assert ws_ok(), "wrote past bd_gemm_workspace_bytes()"
     finally:
@@ -434,7 +435,9 @@ def test_four_wave_persistent_kernels(bd, oracle):
         want = (r.float() + y32.to(dt).float()).to(dt)
         # one ulp at the magnitude of the larger addend (the sum may cancel to something much smaller than its terms) ...
         d = (got.cpu().float() - want.float()).abs()
-        assert (d <= (r.float().abs() + y32.abs()) * (2 ** -10 if dt == torch.float16 else 2 ** -7) + 1e-4).all()
+        # (ulp(y) + ulp(sum): the kernel's y may sit 1 ulp from the oracle's and the sum can then round the other way -- seen at 2 of 80
+        #  residual draws with the former half-width band while the kernel equalled the separate ops bit for bit; tools/dbg_fourwave.py)
+        assert (d <= (r.float().abs() + y32.abs()) * (2 ** -9 if dt == torch.float16 else 2 ** -6) + 1e-4).all()
         assert (got.cpu() == want).float().mean().item() >= 0.99
         # ... and exactly the separate ops wherever the Linear output itself is bit-equal
         y16 = forced(14, lambda: bd.binary_linear(dev(a), dev(w), dev(p), dev(al1)))
@@ -740,7 +743,7 @@ def test_binary_linear_decode_layouts_vs_oracle(bd, oracle, dtype, shape):
         out = bd.binary_linear_decode(dev(a), dev(w), m, dev(alpha), layout=layout, residual=dev(r).clone())
         want = (r.float() + ref32).to(dtype)
         d = (out.cpu().float() - want.float()).abs()
-        assert (d <= (r.float().abs() + ref32.abs()) * (2 ** -7 if dtype == torch.bfloat16 else 2 ** -10) + 1e-4).all()
+        assert (d <= (r.float().abs() + ref32.abs()) * (2 ** -6 if dtype == torch.bfloat16 else 2 ** -9) + 1e-4).all()
         # canaries: ragged N / several tenants / 16-row chunks of the streaming kernel into poisoned margins -- same bits, nothing else touched
         for plain, od in ((y32, torch.float32), (y16, dtype)):
             cn = CanaryOut(B, M, N, od)
