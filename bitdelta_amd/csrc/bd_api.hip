@@ -14,6 +14,7 @@
 #include "bd_gemm_w4.h"
 #include "bd_gemv.h"
 #include "bd_gemv_stream.h"
+#include "bd_gemv_rows.h"
 #ifdef BD_AB_VARIANTS
 #include "../../tests/native/ab/bd_gemv_ring.h"     // LDS-DMA loader / consumer decode kernel: lost its A/B (profiles/r04_decode_ring_ab.txt)
 #endif
@@ -33,6 +34,8 @@ static int env_int(const char* name, int dflt) {
 }
 static thread_local int g_forced_variant = env_int("BD_GEMM_VARIANT", -1);
 static thread_local int g_tail_split = env_int("BD_TAIL_SPLIT", 1) ? 1 : 0;          // A/B hook (bd_set_tail_split)
+// delta_rows_kernel A/B hook (environment only): bits 1-2 = masks per block forced to 1 / 2 / 4 (value 1 / 2 / 3), bit 4 = never chosen automatically
+static thread_local int g_rows_tune = env_int("BD_ROWS_TUNE", 0);
 static thread_local int g_forced_group_m = 0;        // 0 = automatic tile order
 static thread_local int g_col16_small_lut = -1;      // sign LUT of the 16-column decode kernel: -1 auto, 1 = single 4-KiB table, 0 = 16-copy conflict-free
                                         // table whenever it fits.  Auto = 16 copies for delta-only launches (-16..18 % at 6-8 masks;
@@ -598,6 +601,62 @@ int launch_gemv_stream_chunk(const Problem& q) {
 
 // batches of more than 16 activation rows run as consecutive launches over chunks of floor(16 / M) batch entries (each chunk streams
 // the base weight again; still far cheaper than M = 1 tiles of the MFMA tile kernels, which re-read it once per batch entry)
+// ---- delta only, one mask per row, reference layout (delta_rows_kernel, bd_gemv_rows.h): the reference's published binary_bmm shape
+inline bool rows_ok(const Problem& q) {
+    if (q.W || q.alpha || q.accumulate || q.M != 1 || q.B < 2 || q.sPb <= 0 || q.mask_tiled != 0) return false;
+    if (q.N % 64 || q.K % 128 || q.sPb % 4 || q.sAb % 8 || q.sAb < 0 || !aligned16(q.A) || !aligned16(q.P)) return false;
+    const int64_t lim = (1ll << 31) - 64;                       // 32-bit buffer offsets, out-of-range sentinel at 2 GiB
+    const int64_t xb = ((int64_t)(q.B - 1) * q.sAb + q.K) * 2, pb = ((int64_t)(q.B - 1) * q.sPb + (int64_t)(q.K / 32) * q.N) * 4;
+    return xb > 0 && xb < lim && pb > 0 && pb < lim;
+}
+inline int rows_masks_per_block(const Problem& q) {
+    if (g_forced_variant > 800 && g_forced_variant <= 804) return g_forced_variant == 801 ? 1 : g_forced_variant == 802 ? 2 : 4;   // test hook
+    const int forced = (g_rows_tune >> 1) & 3;
+    if (forced) return 1 << (forced - 1);
+    // two masks per block when that still gives every CU TWO blocks (192 VGPRs, 66 KB of LDS: they are co-resident and overlap each other's
+    // start and end), one mask per block otherwise.  tools/bench_rows.py, us per launch at 1 / 2 / 4 masks per block: B = 16, 4096^2 14.6 /
+    // 13.3 / 13.8; B = 8, 8192^2 23.1 / 18.8 / 21.6; B = 16, 8192^2 43.2 / 35.9 / 40.2; B = 8, 4096^2 8.2 / 8.7 / 12.9; B = 4, 4096^2 6.1 / 7.9 / 12.1
+    // (four masks per block -- 336 VGPRs, one block per CU -- stays behind the 804 test hook)
+    const int mc = (int64_t)(q.N / 64) * ((q.B + 1) / 2) >= 2 * (int64_t)num_cus() ? 2 : 1;
+    return mc;
+}
+// automatic choice: enough (super-tile, chunk) blocks to occupy at least half of the chip
+inline bool rows_auto(const Problem& q) {
+    if ((g_rows_tune & 16) || !rows_ok(q) || q.B < 4) return false;
+    const int mc = rows_masks_per_block(q);
+    return (int64_t)(q.N / 64) * ((q.B + mc - 1) / mc) * 2 >= num_cus();
+}
+template <int DT, int MC, int NS, int AUXP>
+int launch_rows_inst(const RowsParams& rp, unsigned grid, hipStream_t st) {
+    auto kern = delta_rows_kernel<DT, MC, NS, AUXP>;
+    static std::atomic<uint64_t> lds_done{0};
+    constexpr int lds = STREAM_LUT_BYTES + 4 * MC * 64 * 4;
+    if (!ensure_dyn_lds((const void*)kern, lds, lds_done)) return BD_E_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, rp);
+    return BD_OK;
+}
+template <int DT>
+int launch_rows(const Problem& q) {
+    if (!rows_ok(q)) return BD_E_BAD_SHAPE;
+    RowsParams rp{};
+    rp.X = (const unsigned short*)q.A; rp.P = (const uint32_t*)q.P; rp.C = q.C;
+    rp.B = q.B; rp.N = q.N; rp.K = q.K; rp.sXb = q.sAb; rp.sPb = q.sPb; rp.sCb = q.sCb;
+    rp.x_bytes = (uint32_t)(((int64_t)(q.B - 1) * q.sAb + q.K) * 2);
+    rp.p_bytes = (uint32_t)(((int64_t)(q.B - 1) * q.sPb + (int64_t)(q.K / 32) * q.N) * 4);
+    rp.round_mode = q.round_mode; rp.out_f32 = (q.out_dtype == BD_F32);
+    const int mc = rows_masks_per_block(q);
+    const unsigned grid = (unsigned)((q.N / 64) * ((q.B + mc - 1) / mc));
+    // 4 stages of loads per wave, nt policy on the sign loads (default policy and 2 stages measured within +-4 % of it, mixed signs:
+    // tests/native/rows_bench.hip keeps those instantiations)
+    int rc;
+#define BD_RW(MC) rc = launch_rows_inst<DT, MC, 4, 2>(rp, grid, q.st)
+    if (mc == 4) BD_RW(4); else if (mc == 2) BD_RW(2); else BD_RW(1);
+#undef BD_RW
+    if (rc != BD_OK) return rc;
+    t_last_variant = 800;
+    return launch_status();
+}
+
 template <int DT>
 int launch_gemv(const Problem& q, bool valu_form, bool col16 = false, bool stream = false) {
     const int cb = GEMV_MAX_R / q.M;
@@ -953,6 +1012,7 @@ int dispatch3(const Problem& q) {
     if (v > 400 && v <= 464) v = 400;        // 400 (+ KS): force the MFMA + LUT decode kernel
     if (v > 500 && v <= 564) v = 500;        // 500 (+ KS): force the no-split-k 16-column decode kernel
     if (v > 600 && v <= 664) v = 600;        // 600 (+ columns per block / 4): force the streaming decode kernel
+    if (v > 800 && v <= 804) v = 800;        // 800 (+ masks per block): force the one-mask-per-row delta kernel (bd_gemv_rows.h)
     if (v == 700) {                           // 700: the loader / consumer decode kernel (packed sign layout, fused Linear only); the
         if (q.mask_tiled != 2 || !q.W) return BD_E_BAD_SHAPE;     // stream path picks it up (launch_gemv_stream_chunk, ring_wanted)
         v = 600;
@@ -1113,6 +1173,8 @@ int dispatch3(const Problem& q) {
         // the MFMA + LUT kernel wins when the delta dominates (delta-only with >= 8 masks) and on narrow outputs (k/v projections)
         // ... and whenever a mask is shared by >= 2 rows (M > 1 or a broadcast mask): it expands each word once for all rows
         case 200: {
+            // one mask per row, delta only, reference layout (binary_bmm at M = 1): 64-column super-tiles, the whole batch in one launch
+            if constexpr (!FUSED) { if (g_forced_variant < 0 && rows_auto(q)) return launch_rows<DT>(q); }
             const int cb = GEMV_MAX_R / q.M, bc = q.B < cb ? q.B : cb, nmask = q.sPb == 0 ? 1 : bc;
             // streaming kernel: one launch, one block per CU, everything in flight from the first cycle (profiles/r02_decode_*.txt)
             if (stream_ok(q, bc * q.M, nmask)) { t_last_variant = 600; return launch_gemv<DT>(q, false, false, true); }
@@ -1139,6 +1201,9 @@ int dispatch3(const Problem& q) {
             if (!stream_ok(q, bc * q.M, nmask)) return BD_E_BAD_SHAPE;
             return launch_gemv<DT>(q, false, false, true);
         }
+        case 800:    // delta_rows_kernel (801 / 802 / 804: masks per block forced)
+            if constexpr (!FUSED) return launch_rows<DT>(q);
+            else return BD_E_BAD_SHAPE;
         default: return BD_E_BAD_SHAPE;
     }
 }

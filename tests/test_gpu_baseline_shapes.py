@@ -301,3 +301,32 @@ def test_config4_llama2_70b_tp8_shard_prefill2048(bd, oracle, name):
     w, p, alpha = make_layer(N, K, torch.bfloat16, 1, seed=800 + N % 79)
     x = torch.randn(1, 2048, K, generator=torch.Generator().manual_seed(12)).bfloat16()
     check_linear(bd, oracle, x, w, p, alpha, cols=sample_columns(N, 40, seed=N))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the reference's published binary_bmm benchmark shapes (notebooks/binary_gemm_kernel_triton.ipynb:800-1044,
+# fp16, M = 1, one mask per batch entry) at FULL size through the reference surface: the one-mask-per-row kernel (variant 800) takes
+# them, and every output row agrees with the oracle on sampled columns
+@pytest.mark.parametrize("B,NK", [(8, 4096), (16, 4096), (8, 8192), (16, 8192)])
+def test_published_binary_bmm_shapes_fp16(bd, oracle, B, NK):
+    from bitdelta_amd import _lib
+    g = torch.Generator().manual_seed(900 + B + NK)
+    x = torch.randn(B, 1, NK, generator=g).half()
+    p = torch.randint(-2 ** 31, 2 ** 31 - 1, (B, NK // 32, NK), generator=g, dtype=torch.int64).to(torch.int32)
+    cols = torch.randperm(NK, generator=g)[:64].sort().values
+    check_delta(bd, oracle, x, p, cols=cols)
+    assert _lib.lib().bd_last_gemm_variant() == 800, _lib.lib().bd_last_gemm_variant()
+    # the same launch is deterministic, and equals the streaming / split-k kernels it replaced within one rounding of the fp32 sum
+    xd, pd = x.cuda(), p.cuda()
+    c0 = bd.binary_bmm(xd, pd)
+    assert torch.equal(c0, bd.binary_bmm(xd, pd))
+    L = _lib.lib()
+    L.bd_set_gemm_variant(600)                         # the streaming kernel (<= 8 masks per launch)
+    try:
+        old = bd.binary_bmm(xd[:8].contiguous(), pd[:8].contiguous())
+    finally:
+        L.bd_set_gemm_variant(-1)
+    assert L.bd_last_gemm_variant() == 600
+    new8, old8 = c0[:8].cpu().contiguous(), old.cpu()
+    ok = (ulp_diff(new8, old8) <= 1) | ((new8.float() - old8.float()).abs() <= cancel_floor(old8, NK))
+    assert bool(ok.all())

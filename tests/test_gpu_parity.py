@@ -197,7 +197,12 @@ SHAPES = [
     (2, 200, 256, 520, 2, 13), (3, 130, 64, 300, 1, 13), (1, 700, 512, 1032, 1, 13), (1, 257, 128, 77, 1, 13),
     (2, 200, 256, 520, 2, 14), (3, 130, 64, 300, 1, 14), (1, 700, 512, 1032, 1, 14), (1, 257, 128, 77, 1, 14), (6, 64, 512, 640, 6, 14),
 ]
-DELTA_SHAPES = [sh for sh in SHAPES if sh[5] != 14]
+# 800 (+ masks per block) = delta_rows_kernel (bd_gemv_rows.h): delta only, M = 1, one mask per row, 64-column super-tiles.  A ragged last
+# chunk (5 masks in chunks of 4), waves with an empty k range (K = 640: 5 iterations over 4 waves; K = 128: one), fewer iterations than
+# prefetch stages, long k (4 rounds of stages), more than 16 rows in ONE launch, and the automatic choice (64 super-tiles x 4 chunks)
+ROWS_SHAPES = [(8, 1, 1024, 256, 8, 804), (16, 1, 4096, 128, 16, 804), (5, 1, 512, 192, 5, 804), (3, 1, 640, 64, 3, 802),
+               (7, 1, 128, 320, 7, 801), (16, 1, 8192, 64, 16, 802), (40, 1, 256, 192, 40, 800), (4, 1, 2048, 4096, 4, None)]
+DELTA_SHAPES = [sh for sh in SHAPES if sh[5] != 14] + ROWS_SHAPES
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
