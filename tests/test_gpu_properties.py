@@ -62,6 +62,33 @@ def test_delta_bmm_linear_and_odd(bd, b, m, kw, n, seed, dtype):
     assert torch.equal(f(x2, p), 2 * y)
 
 
+@settings(max_examples=24, deadline=None)
+@given(b=st.integers(2, 40), st_n=st.integers(1, 5), nit=st.integers(1, 11), mc=st.sampled_from([800, 801, 802, 804]), seed=st.integers(0, 2 ** 16),
+       dtype=st.sampled_from([torch.bfloat16, torch.float16]))
+def test_one_mask_per_row_kernel_random_geometries(bd, b, st_n, nit, mc, seed, dtype):
+    """delta_rows_kernel (variant 800 + masks per block; bd_gemv_rows.h) over random (rows, 64-column super-tiles, 128-k iterations): equals
+    unpack + fp32 bmm, is odd in its signs and exactly linear under a power-of-two scaling of the activations -- and every row uses ITS mask"""
+    from bitdelta_amd import _lib
+    g = torch.Generator().manual_seed(seed)
+    N, K = 64 * st_n, 128 * nit
+    x = torch.randn(b, 1, K, generator=g).to(dtype).cuda()
+    p = torch.randint(-2 ** 31, 2 ** 31 - 1, (b, K // 32, N), generator=g, dtype=torch.int64).to(torch.int32).cuda()
+    L = _lib.lib()
+    L.bd_set_gemm_variant(mc)
+    try:
+        f = lambda xx, pp: bd.delta_bmm(xx, pp, out_dtype=torch.float32, round_mode=0)
+        y = f(x, p)
+        assert L.bd_last_gemm_variant() == 800
+        s = bd.unpack(p).float() * 2 - 1
+        assert torch.allclose(y, torch.bmm(x.float(), s), rtol=1e-5, atol=1e-4 * K ** 0.5)
+        assert torch.allclose(f(x, ~p), -y, rtol=1e-5, atol=1e-5)
+        assert torch.equal(f((x.float() * 2).to(dtype), p), 2 * y)
+        perm = torch.randperm(b, generator=g).cuda()                      # rows and masks permuted together: the same rows come back
+        assert torch.equal(f(x[perm].contiguous(), p[perm].contiguous()), y[perm])
+    finally:
+        L.bd_set_gemm_variant(-1)
+
+
 def test_prefill_attention_random_geometries():
     """bd_srv_prefill_attention over random (batch, length, heads, kv heads, padding, causal) against fp32 softmax attention"""
     import random
