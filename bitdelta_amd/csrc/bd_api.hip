@@ -34,8 +34,10 @@ static int env_int(const char* name, int dflt) {
 }
 static thread_local int g_forced_variant = env_int("BD_GEMM_VARIANT", -1);
 static thread_local int g_tail_split = env_int("BD_TAIL_SPLIT", 1) ? 1 : 0;          // A/B hook (bd_set_tail_split)
-// delta_rows_kernel A/B hook (environment only): bits 1-2 = masks per block forced to 1 / 2 / 4 (value 1 / 2 / 3), bit 4 = never chosen automatically
+// delta_rows_kernel A/B hook (environment only): bits 1-2 = masks per block forced to 1 / 2 / 4 (value 1 / 2 / 3), bit 4 = never chosen automatically,
+// bit 5 = 64-column super-tiles even when they leave CUs idle, bit 6 = 32-column super-tiles always
 static thread_local int g_rows_tune = env_int("BD_ROWS_TUNE", 0);
+static thread_local int g_rows_shared_min = env_int("BD_ROWS_SHARED_MIN", 1);       // shared mask: rows from which the kernel is chosen automatically
 static thread_local int g_forced_group_m = 0;        // 0 = automatic tile order
 static thread_local int g_col16_small_lut = -1;      // sign LUT of the 16-column decode kernel: -1 auto, 1 = single 4-KiB table, 0 = 16-copy conflict-free
                                         // table whenever it fits.  Auto = 16 copies for delta-only launches (-16..18 % at 6-8 masks;
@@ -601,57 +603,80 @@ int launch_gemv_stream_chunk(const Problem& q) {
 
 // batches of more than 16 activation rows run as consecutive launches over chunks of floor(16 / M) batch entries (each chunk streams
 // the base weight again; still far cheaper than M = 1 tiles of the MFMA tile kernels, which re-read it once per batch entry)
-// ---- delta only, one mask per row, reference layout (delta_rows_kernel, bd_gemv_rows.h): the reference's published binary_bmm shape
-inline bool rows_ok(const Problem& q) {
-    if (q.W || q.alpha || q.accumulate || q.M != 1 || q.B < 2 || q.sPb <= 0 || q.mask_tiled != 0) return false;
-    if (q.N % 64 || q.K % 128 || q.sPb % 4 || q.sAb % 8 || q.sAb < 0 || !aligned16(q.A) || !aligned16(q.P)) return false;
+// ---- delta only, <= 16 activation rows per block, reference layout (delta_rows_kernel, bd_gemv_rows.h): the reference's published
+//      binary_bmm (M = 1, one mask per batch entry) and binary_matmul (one mask, M <= 16) decode shapes
+struct RowsPlan { int rpm, mc, cw; unsigned grid; };
+inline bool rows_plan(const Problem& q, RowsPlan& pl) {
+    if (q.W || q.alpha || q.accumulate || q.mask_tiled != 0 || q.M < 1 || q.M > 16 || q.sPb < 0) return false;
+    if (q.N % 32 || q.K % 128 || q.sPb % 2 || q.sAb % 8 || q.sAm % 8 || q.sAb < 0 || q.sAm < 0 || !aligned16(q.A) || !aligned16(q.P)) return false;
     const int64_t lim = (1ll << 31) - 64;                       // 32-bit buffer offsets, out-of-range sentinel at 2 GiB
-    const int64_t xb = ((int64_t)(q.B - 1) * q.sAb + q.K) * 2, pb = ((int64_t)(q.B - 1) * q.sPb + (int64_t)(q.K / 32) * q.N) * 4;
-    return xb > 0 && xb < lim && pb > 0 && pb < lim;
+    const int nmask = q.sPb == 0 ? 1 : q.B;
+    const int64_t xb = ((int64_t)(q.B - 1) * q.sAb + (int64_t)(q.M - 1) * q.sAm + q.K) * 2;
+    const int64_t pb = ((int64_t)(nmask - 1) * q.sPb + (int64_t)(q.K / 32) * q.N) * 4;
+    if (!(xb > 0 && xb < lim && pb > 0 && pb < lim)) return false;
+    const int64_t cus = num_cus();
+    if (q.sPb == 0) {                                            // one mask shared by every row: one chunk of B * M rows
+        if ((int64_t)q.B * q.M > 16) return false;
+        pl.rpm = q.B * q.M; pl.mc = 1;
+    } else {
+        pl.rpm = q.M;
+        // two masks per block when that still gives every CU TWO blocks (<= 220 VGPRs, 66 KB of LDS at M = 1: they are co-resident and overlap
+        // each other's start and end), one mask per block otherwise.  tools/bench_rows.py, us per launch at 1 / 2 / 4 masks per block:
+        // B = 16, 4096^2 14.6 / 13.3 / 13.8; B = 8, 8192^2 23.1 / 18.8 / 21.6; B = 16, 8192^2 43.2 / 35.9 / 40.2; B = 8, 4096^2 8.2 / 8.7 / 12.9;
+        // B = 4, 4096^2 6.1 / 7.9 / 12.1  (four masks per block -- 336 VGPRs, one block per CU -- stays behind the 804 test hook)
+        pl.mc = (2 * q.M <= 16 && (int64_t)(q.N / 64) * ((q.B + 1) / 2) >= 2 * cus) ? 2 : 1;
+    }
+    if (g_forced_variant > 800 && g_forced_variant <= 804 && q.sPb != 0) pl.mc = g_forced_variant == 801 ? 1 : g_forced_variant == 802 ? 2 : 4;   // test hook
+    { const int forced = (g_rows_tune >> 1) & 3; if (forced && q.sPb != 0) pl.mc = 1 << (forced - 1); }
+    if (pl.mc * pl.rpm > 16) return false;
+    const int64_t nch = q.sPb == 0 ? 1 : (q.B + pl.mc - 1) / pl.mc;
+    // 64-column super-tiles (dwordx4 sign loads) when they give every CU a block, 32-column ones (dwordx2) otherwise
+    pl.cw = (q.N % 64 == 0 && ((int64_t)(q.N / 64) * nch >= cus || (g_rows_tune & 32))) ? 4 : 2;
+    if (g_rows_tune & 64) pl.cw = 2;
+    if (pl.cw == 4 && (q.sPb % 4)) return false;
+    if (pl.mc == 4 && pl.cw == 2) pl.cw = 4;                     // (the 804 hook keeps its one instantiation)
+    if (pl.cw == 4 && q.N % 64) return false;
+    pl.grid = (unsigned)((q.N / (16 * pl.cw)) * nch);
+    return true;
 }
-inline int rows_masks_per_block(const Problem& q) {
-    if (g_forced_variant > 800 && g_forced_variant <= 804) return g_forced_variant == 801 ? 1 : g_forced_variant == 802 ? 2 : 4;   // test hook
-    const int forced = (g_rows_tune >> 1) & 3;
-    if (forced) return 1 << (forced - 1);
-    // two masks per block when that still gives every CU TWO blocks (192 VGPRs, 66 KB of LDS: they are co-resident and overlap each other's
-    // start and end), one mask per block otherwise.  tools/bench_rows.py, us per launch at 1 / 2 / 4 masks per block: B = 16, 4096^2 14.6 /
-    // 13.3 / 13.8; B = 8, 8192^2 23.1 / 18.8 / 21.6; B = 16, 8192^2 43.2 / 35.9 / 40.2; B = 8, 4096^2 8.2 / 8.7 / 12.9; B = 4, 4096^2 6.1 / 7.9 / 12.1
-    // (four masks per block -- 336 VGPRs, one block per CU -- stays behind the 804 test hook)
-    const int mc = (int64_t)(q.N / 64) * ((q.B + 1) / 2) >= 2 * (int64_t)num_cus() ? 2 : 1;
-    return mc;
-}
-// automatic choice: enough (super-tile, chunk) blocks to occupy at least half of the chip
+// automatic choice: launches with enough blocks to occupy at least half of the chip; per-entry masks from 4 rows on, a shared mask always
+// (tools/bench_rows.py, 800 against the streaming kernel, us: M = 1, one mask 5.4 vs 7.1 at 4096^2 and 7.5 vs 13.2 at 8192^2; M = 16 7.8 vs 9.4 and
+// 12.2 vs 21.3; B = 2, M = 8 at 8192^2 10.1 vs 23.9 -- the streaming kernel re-reads all 16 activation rows for every 16-column tile)
 inline bool rows_auto(const Problem& q) {
-    if ((g_rows_tune & 16) || !rows_ok(q) || q.B < 4) return false;
-    const int mc = rows_masks_per_block(q);
-    return (int64_t)(q.N / 64) * ((q.B + mc - 1) / mc) * 2 >= num_cus();
+    RowsPlan pl;
+    if ((g_rows_tune & 16) || !rows_plan(q, pl)) return false;
+    const bool shared = q.sPb == 0 || q.B == 1;
+    if (shared ? ((int64_t)q.B * q.M < g_rows_shared_min) : ((int64_t)q.B * q.M < 4)) return false;
+    return (int64_t)pl.grid * 2 >= num_cus();
 }
-template <int DT, int MC, int NS, int AUXP>
-int launch_rows_inst(const RowsParams& rp, unsigned grid, hipStream_t st) {
-    auto kern = delta_rows_kernel<DT, MC, NS, AUXP>;
+template <int DT, int MC, int CW>
+int launch_rows_inst(const RowsParams& rp, int R, unsigned grid, hipStream_t st) {
+    // 4 stages of loads per wave, nt policy on the sign loads (default policy and 2 stages measured within +-4 % of it, mixed signs:
+    // tests/native/rows_bench.hip keeps those instantiations)
+    auto kern = delta_rows_kernel<DT, MC, 4, 2, 0, CW>;
     static std::atomic<uint64_t> lds_done{0};
-    constexpr int lds = STREAM_LUT_BYTES + 4 * MC * 64 * 4;
-    if (!ensure_dyn_lds((const void*)kern, lds, lds_done)) return BD_E_LAUNCH;
+    const int lds = STREAM_LUT_BYTES + 4 * R * 16 * CW * 4;
+    if (!ensure_dyn_lds((const void*)kern, STREAM_LUT_BYTES + 4 * 16 * 16 * CW * 4, lds_done)) return BD_E_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, rp);
     return BD_OK;
 }
 template <int DT>
 int launch_rows(const Problem& q) {
-    if (!rows_ok(q)) return BD_E_BAD_SHAPE;
+    RowsPlan pl;
+    if (!rows_plan(q, pl)) return BD_E_BAD_SHAPE;
     RowsParams rp{};
     rp.X = (const unsigned short*)q.A; rp.P = (const uint32_t*)q.P; rp.C = q.C;
-    rp.B = q.B; rp.N = q.N; rp.K = q.K; rp.sXb = q.sAb; rp.sPb = q.sPb; rp.sCb = q.sCb;
-    rp.x_bytes = (uint32_t)(((int64_t)(q.B - 1) * q.sAb + q.K) * 2);
-    rp.p_bytes = (uint32_t)(((int64_t)(q.B - 1) * q.sPb + (int64_t)(q.K / 32) * q.N) * 4);
+    rp.B = q.B; rp.M = q.M; rp.N = q.N; rp.K = q.K; rp.rpm = pl.rpm;
+    rp.sXb = q.sAb; rp.sXm = q.sAm; rp.sPb = q.sPb; rp.sCb = q.sCb; rp.sCm = q.sCm;
+    const int nmask = q.sPb == 0 ? 1 : q.B;
+    rp.x_bytes = (uint32_t)(((int64_t)(q.B - 1) * q.sAb + (int64_t)(q.M - 1) * q.sAm + q.K) * 2);
+    rp.p_bytes = (uint32_t)(((int64_t)(nmask - 1) * q.sPb + (int64_t)(q.K / 32) * q.N) * 4);
     rp.round_mode = q.round_mode; rp.out_f32 = (q.out_dtype == BD_F32);
-    const int mc = rows_masks_per_block(q);
-    const unsigned grid = (unsigned)((q.N / 64) * ((q.B + mc - 1) / mc));
-    // 4 stages of loads per wave, nt policy on the sign loads (default policy and 2 stages measured within +-4 % of it, mixed signs:
-    // tests/native/rows_bench.hip keeps those instantiations)
+    const int R = pl.mc * pl.rpm;
     int rc;
-#define BD_RW(MC) rc = launch_rows_inst<DT, MC, 4, 2>(rp, grid, q.st)
-    if (mc == 4) BD_RW(4); else if (mc == 2) BD_RW(2); else BD_RW(1);
-#undef BD_RW
+    if (pl.mc == 4) rc = launch_rows_inst<DT, 4, 4>(rp, R, pl.grid, q.st);
+    else if (pl.mc == 2) rc = pl.cw == 4 ? launch_rows_inst<DT, 2, 4>(rp, R, pl.grid, q.st) : launch_rows_inst<DT, 2, 2>(rp, R, pl.grid, q.st);
+    else rc = pl.cw == 4 ? launch_rows_inst<DT, 1, 4>(rp, R, pl.grid, q.st) : launch_rows_inst<DT, 1, 2>(rp, R, pl.grid, q.st);
     if (rc != BD_OK) return rc;
     t_last_variant = 800;
     return launch_status();

@@ -238,9 +238,10 @@ int bd_merge_delta(void* W, int64_t ldw, const int32_t* P, const float* coeff, i
  * wherever 8 was; with fp32 output only its general-form epilogue); 15 = 14 with the SwiGLU epilogue (bd_binary_linear_swiglu only).
  * 16 / 17 = 8-wave PAIR tiles (two batch entries of <= 64 rows per 128x128 tile; 17 + split-k); 18 / 19 = the same on the four-wave schedule
  * (automatic since round 5); 20 = four-wave fused 128x128 tile, one entry per tile (automatic wherever 9 was, 16-bit outputs).
- * 800 = delta_rows_kernel (bd_gemv_rows.h): delta only, M = 1, one mask per row in the reference layout (the reference's published
- * binary_bmm shape): 64-column super-tiles x chunks of 1 / 2 / 4 masks per block, the whole batch in one launch (automatic for B >= 4 when
- * those blocks occupy at least half of the chip; 801 / 802 / 804 force the chunk size).  Needs N % 64 == 0, K % 128 == 0, no scale.
+ * 800 = delta_rows_kernel (bd_gemv_rows.h): delta only, reference sign layout, M <= 16, no scale -- the reference's published binary_bmm /
+ * binary_matmul decode shapes: 64- or 32-column super-tiles x (1 / 2 masks per block x M rows each, or one mask shared by all B * M <= 16 rows),
+ * the whole batch in one launch (automatic when those blocks occupy at least half of the chip: per-entry masks from 4 rows on, a shared mask
+ * always; 801 / 802 / 804 force the masks per block).  Needs N % 32 == 0, K % 128 == 0.
  * A forced variant whose preconditions fail returns BD_E_BAD_SHAPE instead of silently falling back.
  * Environment: BD_GEMM_VARIANT=<n> is every thread's initial forced variant (overridden by this call), BD_TAIL_SPLIT=0 disables the tail split.
  * The bd_set_* entry points below are TUNING / TEST HOOKS: thread-local, not part of the stable interface a reference-side binding

@@ -34,3 +34,11 @@ def _seed_unseeded_draws(request):
     import torch
     torch.manual_seed(zlib.crc32(request.node.nodeid.encode()) & 0x7fffffff)
     yield
+
+
+try:        # property tests draw the SAME examples on every run (here, on the GPU box, in the driver's round-end run)
+    from hypothesis import settings as _hyp_settings
+    _hyp_settings.register_profile("reproducible", derandomize=True, deadline=None, database=None)
+    _hyp_settings.load_profile("reproducible")
+except ImportError:
+    pass

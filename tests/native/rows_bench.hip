@@ -30,7 +30,7 @@ __global__ void fill_f16(unsigned short* x, size_t n, uint32_t seed) {
 
 template <int MC, int NS, int AUXP, int ABL>
 float run(const char* tag, int B, int NK, int nset, unsigned short* X, uint32_t* P, unsigned short* C, int reps) {
-    auto kern = delta_rows_kernel<DT_F16, MC, NS, AUXP, ABL>;
+    auto kern = delta_rows_kernel<DT_F16, MC, NS, AUXP, ABL, 4>;
     constexpr int lds = STREAM_LUT_BYTES + 4 * MC * 64 * 4;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const size_t pw = (size_t)B * (NK / 32) * NK;
@@ -42,8 +42,8 @@ float run(const char* tag, int B, int NK, int nset, unsigned short* X, uint32_t*
         CK(hipEventRecord(e0));
         for (int i = 0; i < nl; ++i) {
             RowsParams rp{};
-            rp.X = X; rp.P = P + (size_t)(i % nset) * pw; rp.C = C; rp.B = B; rp.N = NK; rp.K = NK;
-            rp.sXb = NK; rp.sPb = (long long)(NK / 32) * NK; rp.sCb = NK;
+            rp.X = X; rp.P = P + (size_t)(i % nset) * pw; rp.C = C; rp.B = B; rp.M = 1; rp.rpm = 1; rp.N = NK; rp.K = NK;
+            rp.sXb = NK; rp.sXm = NK; rp.sPb = (long long)(NK / 32) * NK; rp.sCb = NK; rp.sCm = NK;
             rp.x_bytes = (uint32_t)((size_t)B * NK * 2); rp.p_bytes = (uint32_t)(pw * 4);
             const unsigned grid = (unsigned)((NK / 64) * ((B + MC - 1) / MC));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, rp);

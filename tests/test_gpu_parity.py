@@ -197,11 +197,16 @@ SHAPES = [
     (2, 200, 256, 520, 2, 13), (3, 130, 64, 300, 1, 13), (1, 700, 512, 1032, 1, 13), (1, 257, 128, 77, 1, 13),
     (2, 200, 256, 520, 2, 14), (3, 130, 64, 300, 1, 14), (1, 700, 512, 1032, 1, 14), (1, 257, 128, 77, 1, 14), (6, 64, 512, 640, 6, 14),
 ]
-# 800 (+ masks per block) = delta_rows_kernel (bd_gemv_rows.h): delta only, M = 1, one mask per row, 64-column super-tiles.  A ragged last
-# chunk (5 masks in chunks of 4), waves with an empty k range (K = 640: 5 iterations over 4 waves; K = 128: one), fewer iterations than
-# prefetch stages, long k (4 rounds of stages), more than 16 rows in ONE launch, and the automatic choice (64 super-tiles x 4 chunks)
+# 800 (+ masks per block) = delta_rows_kernel (bd_gemv_rows.h): delta only, <= 16 activation rows per block, 64- or 32-column super-tiles.
+# One mask per row (M = 1): a ragged last chunk (5 masks in chunks of 4), waves with an empty k range (K = 640: 5 iterations over 4 waves;
+# K = 128: one), fewer iterations than prefetch stages, long k (4 rounds of stages), more than 16 rows in ONE launch, the automatic choice.
+# M > 1 rows per mask (two masks x 4 rows per block, 5 rows per mask), ONE mask shared by every row (binary_matmul with M = 16; 2 x 8 and
+# 3 x 2 rows of a batch; 16 batch entries on one mask), N % 64 != 0 (32-column super-tiles), and the automatic choice for 16 rows on one mask
 ROWS_SHAPES = [(8, 1, 1024, 256, 8, 804), (16, 1, 4096, 128, 16, 804), (5, 1, 512, 192, 5, 804), (3, 1, 640, 64, 3, 802),
-               (7, 1, 128, 320, 7, 801), (16, 1, 8192, 64, 16, 802), (40, 1, 256, 192, 40, 800), (4, 1, 2048, 4096, 4, None)]
+               (7, 1, 128, 320, 7, 801), (16, 1, 8192, 64, 16, 802), (40, 1, 256, 192, 40, 800), (4, 1, 2048, 4096, 4, None),
+               (1, 16, 512, 320, 1, 800), (1, 1, 1024, 96, 1, 800), (4, 4, 640, 160, 4, 800), (4, 4, 640, 128, 4, 802), (3, 5, 256, 64, 3, 800),
+               (2, 8, 384, 192, 1, 800), (3, 2, 512, 512, 1, 800), (16, 1, 2048, 256, 1, 800), (1, 16, 2048, 4096, 1, None),
+               (9, 3, 384, 8192, 9, None)]
 DELTA_SHAPES = [sh for sh in SHAPES if sh[5] != 14] + ROWS_SHAPES
 
 

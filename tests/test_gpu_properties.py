@@ -62,17 +62,26 @@ def test_delta_bmm_linear_and_odd(bd, b, m, kw, n, seed, dtype):
     assert torch.equal(f(x2, p), 2 * y)
 
 
-@settings(max_examples=24, deadline=None)
-@given(b=st.integers(2, 40), st_n=st.integers(1, 5), nit=st.integers(1, 11), mc=st.sampled_from([800, 801, 802, 804]), seed=st.integers(0, 2 ** 16),
+@settings(max_examples=40, deadline=None)
+@given(data=st.data(), m=st.integers(1, 16), shared=st.booleans(), n32=st.integers(1, 10), nit=st.integers(1, 11), seed=st.integers(0, 2 ** 16),
        dtype=st.sampled_from([torch.bfloat16, torch.float16]))
-def test_one_mask_per_row_kernel_random_geometries(bd, b, st_n, nit, mc, seed, dtype):
-    """delta_rows_kernel (variant 800 + masks per block; bd_gemv_rows.h) over random (rows, 64-column super-tiles, 128-k iterations): equals
-    unpack + fp32 bmm, is odd in its signs and exactly linear under a power-of-two scaling of the activations -- and every row uses ITS mask"""
+def test_rows_kernel_random_geometries(bd, data, m, shared, n32, nit, seed, dtype):
+    """delta_rows_kernel (variant 800 + masks per block; bd_gemv_rows.h) over random (batch, rows per mask, shared / per-entry masks, 32-column
+    units, 128-k iterations): equals unpack + fp32 bmm, is odd in its signs and exactly linear under a power-of-two scaling of the
+    activations -- and every batch entry uses ITS mask"""
     from bitdelta_amd import _lib
+    per = {800: 1, 801: 1, 802: 2, 804: 4}
+    if shared:                                   # one mask for every row: at most 16 rows in the launch
+        b, mc = data.draw(st.integers(1, 16 // m)), 800
+    else:                                        # per-entry masks: masks per block x rows per mask <= 16
+        mc = data.draw(st.sampled_from([v for v in per if per[v] * m <= 16]))
+        b = data.draw(st.integers(2, max(2, 48 // m)))
     g = torch.Generator().manual_seed(seed)
-    N, K = 64 * st_n, 128 * nit
-    x = torch.randn(b, 1, K, generator=g).to(dtype).cuda()
-    p = torch.randint(-2 ** 31, 2 ** 31 - 1, (b, K // 32, N), generator=g, dtype=torch.int64).to(torch.int32).cuda()
+    N, K = 32 * n32, 128 * nit
+    if mc == 804:
+        N = 64 * ((n32 + 1) // 2)                                       # (four masks per block: 64-column super-tiles only)
+    x = torch.randn(b, m, K, generator=g).to(dtype).cuda()
+    p = torch.randint(-2 ** 31, 2 ** 31 - 1, (1 if shared else b, K // 32, N), generator=g, dtype=torch.int64).to(torch.int32).cuda()
     L = _lib.lib()
     L.bd_set_gemm_variant(mc)
     try:
@@ -80,11 +89,11 @@ def test_one_mask_per_row_kernel_random_geometries(bd, b, st_n, nit, mc, seed, d
         y = f(x, p)
         assert L.bd_last_gemm_variant() == 800
         s = bd.unpack(p).float() * 2 - 1
-        assert torch.allclose(y, torch.bmm(x.float(), s), rtol=1e-5, atol=1e-4 * K ** 0.5)
+        assert torch.allclose(y, torch.matmul(x.float(), s), rtol=1e-5, atol=1e-4 * K ** 0.5)
         assert torch.allclose(f(x, ~p), -y, rtol=1e-5, atol=1e-5)
         assert torch.equal(f((x.float() * 2).to(dtype), p), 2 * y)
-        perm = torch.randperm(b, generator=g).cuda()                      # rows and masks permuted together: the same rows come back
-        assert torch.equal(f(x[perm].contiguous(), p[perm].contiguous()), y[perm])
+        perm = torch.randperm(b, generator=g).cuda()                      # entries and masks permuted together: the same rows come back
+        assert torch.equal(f(x[perm].contiguous(), p if shared else p[perm].contiguous()), y[perm])
     finally:
         L.bd_set_gemm_variant(-1)
 
