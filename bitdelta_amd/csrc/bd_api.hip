@@ -37,6 +37,7 @@ static thread_local int g_tail_split = env_int("BD_TAIL_SPLIT", 1) ? 1 : 0;     
 // delta_rows_kernel A/B hook (environment only): bits 1-2 = masks per block forced to 1 / 2 / 4 (value 1 / 2 / 3), bit 4 = never chosen automatically,
 // bit 5 = 64-column super-tiles even when they leave CUs idle, bit 6 = 32-column super-tiles always
 static thread_local int g_rows_tune = env_int("BD_ROWS_TUNE", 0);
+static thread_local int g_attn_depth = env_int("BD_ATTN_DEPTH", 0);                 // decode attention K / V ring depth: 0 = by cache length, 2, 4 (A/B hook)
 static thread_local int g_rows_shared_min = env_int("BD_ROWS_SHARED_MIN", 1);       // shared mask: rows from which the kernel is chosen automatically
 static thread_local int g_forced_group_m = 0;        // 0 = automatic tile order
 static thread_local int g_col16_small_lut = -1;      // sign LUT of the 16-column decode kernel: -1 auto, 1 = single 4-KiB table, 0 = 16-copy conflict-free
@@ -1540,7 +1541,8 @@ extern "C" int bd_srv_rope(void* X, const void* cos_t, const void* sin_t, int ro
 #ifndef BD_ATTN_SPLITS
 #define BD_ATTN_SPLITS 4
 #endif
-constexpr int ATTN_SPLITS = BD_ATTN_SPLITS;   // (a build-time knob for A/B runs; 4 measured best, profiles/r03_decode_attn_splits.txt)
+constexpr int ATTN_SPLITS = BD_ATTN_SPLITS;
+static_assert(ATTN_SPLITS <= ATTN_MAX_SPLITS, "decode_attn_kernel merges at most ATTN_MAX_SPLITS partials");   // (a build-time knob for A/B runs; 4 measured best, profiles/r03_decode_attn_splits.txt)
 constexpr int64_t ATTN_TICKET_BYTES = 16384;       // one arrival counter per (tenant, kv head): T * KVH <= 4096
 extern "C" int64_t bd_srv_decode_attention_workspace_bytes(int T, int H, int KVH, int head_dim, int Lc) {
     if (T <= 0 || H <= 0 || KVH <= 0 || Lc < 256) return 0;       // short caches run unsplit
@@ -1572,7 +1574,7 @@ extern "C" int bd_srv_decode_attention(const void* QKV, const void* cos_t, const
     dim3 grid((unsigned)(T * KVH), (unsigned)p.nsplit);
 #define BD_ATT(DT, GG)                                                                                      \
     do {                                                                                                    \
-        if (Lc <= 2048) hipLaunchKernelGGL((decode_attn_kernel<DT, GG, 2>), grid, dim3(512), 0, st, p);    \
+        if (g_attn_depth ? g_attn_depth == 2 : Lc <= 2048) hipLaunchKernelGGL((decode_attn_kernel<DT, GG, 2>), grid, dim3(512), 0, st, p);    \
         else hipLaunchKernelGGL((decode_attn_kernel<DT, GG, 4>), grid, dim3(512), 0, st, p);                \
     } while (0)
     // G = query heads per kv head: 1 (Llama-2-7B), 4 (Mistral-7B), 8 (Llama-2-70B -- also per rank under tensor parallelism).

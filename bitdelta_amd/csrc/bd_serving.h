@@ -176,6 +176,7 @@ __device__ __forceinline__ float attn_ws_load(const float* src) {
     return __hip_atomic_load(const_cast<float*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+constexpr int ATTN_MAX_SPLITS = 4;            // key-range splits per (tenant, kv head) the in-launch merge is written for (host: nsplit <= this)
 template <int DT, int G, int DEPTH = 4>
 __global__ void __launch_bounds__(512) decode_attn_kernel(const AttnParams p) {
     constexpr int HD = 128, NWV = 8, RPI = 4 * NWV;
@@ -200,33 +201,49 @@ __global__ void __launch_bounds__(512) decode_attn_kernel(const AttnParams p) {
     const long long l_lo = (long long)blockIdx.y * per_split, l_hi = l_lo + per_split < nrows_all ? l_lo + per_split : nrows_all;
     const bool owns_new = l_lo <= pos && pos < l_hi;      // the split that holds the new token appends it to the cache
 
-    struct Rows { u32x4_t kk, vv; bool ok; };
+    // (the validity byte is kept RAW and tested where the row is used: compared here -- `ok = in && vld[lc] != 0` -- the byte load sat behind a
+    //  branch and its compare waited vmcnt(0) right after the row's K / V loads were issued, i.e. one full memory round trip per ring slot in the
+    //  prologue and per refill in the loop; read in the ISA, round 5)
+    struct Rows { u32x4_t kk, vv; uint32_t vb; bool in; };
     auto load_row = [&](long long l, Rows& r) {
         const bool in = l < pos && l < l_hi;              // row `pos` itself comes from LDS (it is being written by its block)
         const long long lc = in ? l : 0;
         r.kk = *(const u32x4_t*)(kbase + lc * HD + 8 * d8);
         r.vv = *(const u32x4_t*)(vbase + lc * HD + 8 * d8);
-        r.ok = in && vld[lc] != 0;
+        r.vb = vld[lc];
+        r.in = in;
     };
-    // the first DEPTH iterations' rows go in flight before anything else (they do not depend on the new token)
+    // ---- phase 0 inputs FIRST (raw bits; L2 hits -- the row was just written by the q|k|v launch), the K / V ring behind them, the arithmetic
+    //      after both: loads return in issue order, so RoPE inputs queued behind the ring would wait for the ring's HBM round trip (and the ring,
+    //      issued behind a wait for the RoPE inputs, would start late).  Thread i owns element i of the G query heads; the last two waves also own
+    //      the new key / value element d = i - 384 = i % 128 (the same cos / sin entry).  Unconditional loads from clamped indices: no branch, no wait.
+    const int i0 = min((int)threadIdx.x, G * HD - 1), g0 = i0 / HD, d0 = threadIdx.x % HD, dp0 = d0 < HD / 2 ? d0 + HD / 2 : d0 - HD / 2;
+    const unsigned short* qrow0 = row + (long long)(kvh * G + g0) * HD;
+    const unsigned short* krow = row + (long long)(p.H + kvh) * HD;
+    const unsigned short rq_x = qrow0[d0], rq_r = qrow0[dp0], r_cs = cs[d0], r_sn = sn[d0];
+    const unsigned short rk_x = krow[d0], rk_r = krow[dp0], r_vn = row[(long long)(p.H + p.KVH + kvh) * HD + d0];
+    asm volatile("" ::: "memory");                       // (hipcc sank two of the seven loads below the ring without this)
+    __builtin_amdgcn_sched_barrier(0);
+    // the first DEPTH iterations' rows go in flight next (they do not depend on the new token)
     Rows ring[DEPTH];
 #pragma unroll
     for (int u = 0; u < DEPTH; ++u) load_row(l_lo + (long long)u * RPI + slot, ring[u]);
 
     // ---- phase 0: RoPE of the G query heads and of the new key (torch: round16(round16(x*cos) + rot*sin)), cache append
-    auto rope = [&](const unsigned short* v, int d) {
-        const float x = half_bits_to_f32<DT>(v[d]), xr = half_bits_to_f32<DT>(v[d < HD / 2 ? d + HD / 2 : d - HD / 2]);
-        const float a = round16<DT>(x * half_bits_to_f32<DT>(cs[d]));
-        return round16<DT>(a + xr * half_bits_to_f32<DT>(sn[d]));
+    auto rope_bits = [&](unsigned short xb, unsigned short xrb, unsigned short cb, unsigned short sb) {
+        const float a = round16<DT>(half_bits_to_f32<DT>(xb) * half_bits_to_f32<DT>(cb));
+        return round16<DT>(a + half_bits_to_f32<DT>(xrb) * half_bits_to_f32<DT>(sb));
     };
-    for (int i = threadIdx.x; i < G * HD; i += 64 * NWV) {
+    auto rope = [&](const unsigned short* v, int d) { return rope_bits(v[d], v[d < HD / 2 ? d + HD / 2 : d - HD / 2], cs[d], sn[d]); };
+    if ((int)threadIdx.x < G * HD) q_lds[g0][d0] = rope_bits(rq_x, rq_r, r_cs, r_sn) * p.scale;
+    for (int i = threadIdx.x + 64 * NWV; i < G * HD; i += 64 * NWV) {          // (G = 8: the second half of the query heads)
         const int g = i / HD, d = i % HD;
         q_lds[g][d] = rope(row + (long long)(kvh * G + g) * HD, d) * p.scale;
     }
     if (owns_new && threadIdx.x >= 64 * NWV - HD) {      // the last two waves (the first ones may be busy with the q heads)
-        const int d = threadIdx.x - (64 * NWV - HD);
-        const float kr = rope(row + (long long)(p.H + kvh) * HD, d);
-        const unsigned short vn = row[(long long)(p.H + p.KVH + kvh) * HD + d];
+        const int d = d0;
+        const float kr = rope_bits(rk_x, rk_r, r_cs, r_sn);
+        const unsigned short vn = r_vn;
         kn_lds[d] = kr;
         vn_lds[d] = half_bits_to_f32<DT>(vn);
         kbase[pos * HD + d] = (unsigned short)f32_to_half_bits<DT>(kr);
@@ -273,7 +290,7 @@ __global__ void __launch_bounds__(512) decode_attn_kernel(const AttnParams p) {
         for (int u = 0; u < DEPTH; ++u) {
             const long long l = l_lo + (it0 + u) * RPI + slot;
             float kf[8], vf[8];
-            bool use = ring[u].ok;
+            bool use = ring[u].in && ring[u].vb != 0;
             if (l == pos && owns_new) {
                 use = true;
 #pragma unroll
@@ -347,14 +364,28 @@ __global__ void __launch_bounds__(512) decode_attn_kernel(const AttnParams p) {
     for (int i = threadIdx.x; i < G * HD; i += 64 * NWV) {
         const int g = i / HD, d = i % HD;
         const float* w = p.ws + ((long long)blockIdx.x * p.nsplit * G + g) * (HD + 2);
+        // every partial of this element is fetched FIRST (3 loads per split, all in flight together), then merged in split order: written as
+        // two loops over a run-time split count, each relaxed-atomic load was waited for where it was issued -- up to 8 dependent L2 round
+        // trips on the critical path of the last block (the launch is latency, not bandwidth: profiles/r05_decode_step.txt)
+        float mv[ATTN_MAX_SPLITS], sv[ATTN_MAX_SPLITS], av[ATTN_MAX_SPLITS];
+#pragma unroll
+        for (int c = 0; c < ATTN_MAX_SPLITS; ++c) {
+            const float* wc = w + (long long)min(c, p.nsplit - 1) * G * (HD + 2);
+            mv[c] = attn_ws_load(&wc[HD]);
+            sv[c] = attn_ws_load(&wc[HD + 1]);
+            av[c] = attn_ws_load(&wc[d]);
+        }
         float mm = -1e30f;
-        for (int c = 0; c < p.nsplit; ++c) mm = fmaxf(mm, attn_ws_load(&w[(long long)c * G * (HD + 2) + HD]));
+#pragma unroll
+        for (int c = 0; c < ATTN_MAX_SPLITS; ++c) if (c < p.nsplit) mm = fmaxf(mm, mv[c]);
         float ssum = 0.f, a = 0.f;
-        for (int c = 0; c < p.nsplit; ++c) {
-            const float* wc = w + (long long)c * G * (HD + 2);
-            const float f = __expf(attn_ws_load(&wc[HD]) - mm);
-            ssum += attn_ws_load(&wc[HD + 1]) * f;
-            a += attn_ws_load(&wc[d]) * f;
+#pragma unroll
+        for (int c = 0; c < ATTN_MAX_SPLITS; ++c) {
+            if (c < p.nsplit) {
+                const float f = __expf(mv[c] - mm);
+                ssum += sv[c] * f;
+                a += av[c] * f;
+            }
         }
         p.out[(long long)t * p.s_out + (long long)(kvh * G + g) * HD + d] = (unsigned short)f32_to_half_bits<DT>(a / ssum);
     }
