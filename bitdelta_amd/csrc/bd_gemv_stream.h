@@ -154,6 +154,8 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
     static_assert(!XL || NS % 2 == 0, "stage parity selects the activation fragment set");
     constexpr int AUXW = AUX & 2, AUXP = (AUX & 4) ? 2 : 0;
     GemvParams p = sp.g;
+    if constexpr (XL != 0) p.M = 1;         // the resident / normalised-row forms are decode launches with one row per tenant (host-checked): a constant
+                                            // lets the compiler fold the ~8 run-time divisions by M out of the prologue (row -> (tenant, row) maps)
     if constexpr (NM == 0) {       // blockIdx.y = tenant: its own activation rows, weight matrix and output rows
         p.X += (long long)blockIdx.y * sp.sXt;
         p.W += (long long)blockIdx.y * sp.sWt;
@@ -257,12 +259,26 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
     [[maybe_unused]] const int jsh = sp.jsh;                             // log2(chunks per row per thread): K = 2048 << jsh (host-checked)
     if constexpr (XL) {
         const __amdgpu_buffer_rsrc_t rn = make_rsrc(sp.nw, sp.n_bytes);
+        // XL = 2 / 3: chunk q = thread + XNT j of the flat [R][K / 8] array.  (row, chunk) advance INCREMENTALLY -- one division here instead of one per
+        // chunk: written as r = q / kc inside the loop, the 16 run-time divisions put ~870 instructions (~1.7 us on a one-wave-per-SIMD kernel) in
+        // front of the first weight load of the launch (read in the ISA, round 5)
+        [[maybe_unused]] const int kc = p.K >> 3;
+        [[maybe_unused]] int xr_ = (int)threadIdx.x / kc, xc_ = (int)threadIdx.x - xr_ * kc;
 #pragma unroll
         for (int j = 0; j < XCH; ++j) {
             // XL = 1: K = 2048 << jsh, a thread's chunks of one row are consecutive j (the row sums need that).  XL = 2: any K % 8 == 0 --
             // chunk q = thread + 256 j of the flat [R][K / 8] array (the same chunks as the line above when K is a power of two)
             int r, c;
-            if constexpr (XL == 2 || XL == 3) { const int q = (int)threadIdx.x + XNT * j, kc = p.K >> 3; r = q / kc; c = (q - r * kc) * 8; }
+            if constexpr (XL == 2 || XL == 3) {
+                r = xr_; c = xc_ * 8;
+                xc_ += XNT;
+#pragma unroll
+                for (int w_ = 0; w_ < XNT / 128; ++w_) {                 // (K >= 1024, host-checked: at most XNT / 128 wraps; selects, no branch)
+                    const bool wrap = xc_ >= kc;
+                    xc_ -= wrap ? kc : 0;
+                    xr_ += wrap ? 1 : 0;
+                }
+            }
             else { r = j >> jsh; c = ((int)threadIdx.x + 256 * (j - (r << jsh))) * 8; }      // M == 1 (host-checked): row = tenant
             const bool ok = r < p.R;
             xraw[j] = buf_load16<0>(rx, ok ? (uint32_t)(((long long)r * p.sXb + c) * 2) : STREAM_OOB);
@@ -365,11 +381,21 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
         }
     }
     if constexpr (XL == 2 || XL == 3) {           // rows -> LDS (same thread mapping as the norm form)
+        const int kc = p.K >> 3;
+        int r = (int)threadIdx.x / kc, cq = (int)threadIdx.x - r * kc;       // (incremental, as in the load loop above)
 #pragma unroll
         for (int j = 0; j < XCH; ++j) {
-            const int q = (int)threadIdx.x + XNT * j, kc = p.K >> 3, r = q / kc, c = (q - r * kc) * 8;
-            if (r < p.R) {
-                *(u32x4_t*)(dyn_lds + sp.xs_off + (uint32_t)r * sp.xrow + (uint32_t)c * 2u) = xraw[j];   // (XL = 3: X is the producer's xw_out)
+            const int c = cq * 8;
+            const int r_ = r;
+            cq += XNT;
+#pragma unroll
+            for (int w_ = 0; w_ < XNT / 128; ++w_) {
+                const bool wrap = cq >= kc;
+                cq -= wrap ? kc : 0;
+                r += wrap ? 1 : 0;
+            }
+            if (r_ < p.R) {
+                *(u32x4_t*)(dyn_lds + sp.xs_off + (uint32_t)r_ * sp.xrow + (uint32_t)c * 2u) = xraw[j];   // (XL = 3: X is the producer's xw_out)
             }
         }
     }

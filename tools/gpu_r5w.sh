@@ -3,8 +3,8 @@
 # 6-tenant and 1-tenant decode step against the library built before the change (BD_HIP_LIB selects the build)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; OUT=gpurun_out/r5w; mkdir -p $OUT
-timeout 900 python -m pytest tests/test_gpu_serving.py -q -x 2>&1 | tail -3 | tee $OUT/tests.log
-A=$PWD/bitdelta_amd/lib/libbitdelta_hip.so.oldattn; B=$PWD/bitdelta_amd/lib/libbitdelta_hip.so
+timeout 900 python -m pytest tests/test_gpu_serving.py tests/test_gpu_parity.py -q -x -k "decode or serving or stream or handoff or norm" 2>&1 | tail -3 | tee $OUT/tests.log
+A=$PWD/bitdelta_amd/lib/libbitdelta_hip.so.prev; B=$PWD/bitdelta_amd/lib/libbitdelta_hip.so
 for i in 1 2; do for tag in A B; do
   lib=$A; [ $tag = B ] && lib=$B
   for T in 6 1; do
