@@ -543,11 +543,31 @@ def run_mt_decode(dev, timer, model_name, tenants, kv_len, steps, warmup, layers
 
     for _ in range(warmup):
         dec._decode_step(st)
+    eager_s = bdd.timed_region(lambda: dec._decode_step(st), steps, device_sync=torch.cuda.synchronize)
+    restore()
+    # Event-timed Linear launches.  The eager loop is HOST-bound (~6 ms of Python / ctypes per 4.6 ms step): a launch that finds the queue empty
+    # has the host's time between `e0.record()` and the kernel's enqueue inside its event pair, and the faster the step's kernels get, the more
+    # launches find it empty (the figure fell from 0.55 to 0.49 across two changes that made the replayed step 4.4 % faster).  So the
+    # timed pass enqueues every step BEHIND a calibrated GPU-side spin that outlasts the host's enqueue time: the events then see back-to-back
+    # device execution, whatever the host does.
+    queued, hold = False, None
+    try:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(200000); torch.cuda.synchronize()
+        e0.record(); torch.cuda._sleep(2000000); e1.record(); torch.cuda.synchronize()
+        cyc_per_ms = 2000000 / max(e0.elapsed_time(e1), 1e-3)
+        hold = int(cyc_per_ms * max(2.0 * eager_s / steps * 1e3, 8.0))          # >= twice the eager step
+        queued = True
+    except Exception:                       # no spin kernel in this torch build: the eager figure, labelled as such
+        queued = False
     timer.reset()
     timer.enabled = True
-    eager_s = bdd.timed_region(lambda: dec._decode_step(st), steps, device_sync=torch.cuda.synchronize)
-    timer.enabled = False
+    for _ in range(steps):
+        if queued:
+            torch.cuda._sleep(hold)
+        dec._decode_step(st)
     torch.cuda.synchronize()
+    timer.enabled = False
     n_launch, k_ms, _, k_bytes = timer.summary()
     restore()
     graph_ms, graph_err, reps_out = None, None, None
@@ -645,9 +665,12 @@ def run_mt_decode(dev, timer, model_name, tenants, kv_len, steps, warmup, layers
         # event-timed Linear launches of the eager loop: algorithmic bytes / their summed durations
         "linear_gbs": k_bytes / k_ms * 1e-6 if k_ms > 0 else None,
         "linear_frac_of_hbm_peak": (k_bytes / k_ms * 1e-6 / PEAK_HBM_GBS) if k_ms > 0 else None,
-        "linear_note": "event-timed in the EAGER loop (launch gaps included).  Since round 5 the Linear launches also carry the RMSNorm's work "
-                       "(hand-off: producers write sums of squares + the pre-multiplied stream, consumers sum them), so this per-launch figure "
-                       "drops while the step gets faster; `step_frac_of_hbm_peak` (graph replay, all bytes of the step) is the comparable number",
+        "linear_timed": "queued behind a GPU-side spin (host gaps excluded)" if queued else "eager loop (host gaps included)",
+        "linear_note": "one HIP event pair per Linear launch.  Until late in round 5 the pairs were recorded in the plain eager loop, which is host-bound: "
+                       "a launch that found the queue empty had the host's enqueue time inside its pair (0.49 - 0.55 depending on the box and on how fast "
+                       "the OTHER kernels of the step were).  Now every timed step is enqueued behind a calibrated GPU-side spin, so the pairs see "
+                       "back-to-back device execution.  Since round 5 the Linear launches also carry the RMSNorm's work (hand-off); "
+                       "`step_frac_of_hbm_peak` (graph replay, all bytes of the step) is the end-to-end number",
         "norm_handoff": bool(getattr(dec, "norm_handoff", False)),
         # the whole step against the bytes its Linears must stream (everything else counted as overhead)
         "step_gbs": (lin_bytes + head_bytes) / (best_ms * 1e-3) * 1e-9,
