@@ -135,3 +135,69 @@ def test_prefill_attention_isa(attn_kernels):
             for i, l in enumerate(code):
                 if l.startswith("v_cvt_pk_bf16_f32"):
                     assert code[i - 1].startswith("s_nop"), (name, code[i - 2:i + 1])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Decode-step kernels: waits and prologue work the source never asked for, each found in the ISA in round 5 and each worth 2 - 3 % of the
+# decode step (profiles/r05_decode_step.txt, r05_reference_notebook_shapes.txt).  Asserted on the text so they cannot come back silently.
+@pytest.fixture(scope="module")
+def decode_kernels(tmp_path_factory):
+    import isa_gaps
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "decode.s"
+    src = os.path.join(ROOT, "tests", "native", "decode_isa_probe.hip")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-pass-failed", "--cuda-device-only", "-S", "-o", str(out), src])
+    return {name: body for name, body in isa_gaps.kernels(str(out))}
+
+
+def _one(ks, key):
+    hits = [(n, b) for n, b in ks.items() if key in n]
+    assert len(hits) == 1, (key, [n for n, _ in hits])
+    return hits[0][1]
+
+
+def test_decode_attention_has_no_accidental_waits(decode_kernels):
+    body = _one(decode_kernels, "decode_attn_kernel")
+    first_barrier = next(i for i, l in enumerate(body) if "s_barrier" in l)
+    head = body[:first_barrier]
+    # RoPE inputs first, then the K / V ring (2 rows x (K, V) + the validity byte each), and no wait for the ring before the barrier that
+    # publishes the rotated query (the validity byte's compare used to wait vmcnt(0) behind every row: one HBM round trip per ring slot)
+    loads = [i for i, l in enumerate(head) if re.search(r"\bglobal_load_", l)]
+    ring = [i for i in loads if "global_load_dwordx4" in head[i]]
+    assert len(ring) == 4 and sum("global_load_ubyte" in head[i] for i in loads) == 2
+    assert sum("global_load_ushort" in head[i] for i in loads if i < ring[0]) == 7, "the seven RoPE inputs are issued ahead of the ring"
+    assert not any("vmcnt(0)" in l for l in head[ring[0]:]), "no full drain between the ring's issue and the first barrier"
+    # the split merge: all 12 partial loads of an element in flight together, then counted waits
+    sc1 = [i for i, l in enumerate(body) if "global_load_dword " in l and "sc1" in l]
+    assert len(sc1) == 12
+    between = body[sc1[0]:sc1[-1] + 1]
+    assert not any("s_waitcnt vmcnt" in l for l in between), "a wait between the merge loads serialises them (8 dependent L2 round trips before)"
+
+
+def test_resident_row_linear_reaches_its_first_weight_load_early(decode_kernels):
+    body = _one(decode_kernels, "gemv_stream_kernel")
+    loads = [i for i, l in enumerate(body) if "buffer_load_dwordx4" in l]
+    first_barrier = next(i for i, l in enumerate(body) if "s_barrier" in l)
+    # 16 activation-row chunks, then the first weight stage: it sat behind ~870 instructions (32 run-time integer divisions per thread in the
+    # rows -> LDS copy) before round 5; incremental addressing brought it to ~590 and the barrier from ~1380 to ~910
+    assert loads[16] < 700, loads[16]
+    assert first_barrier < 1050, first_barrier
+    head = body[:loads[16]]
+    assert sum(1 for l in head if "v_rcp_iflag_f32" in l) <= 4, "integer divisions in front of the first weight load"
+    assert not any("scratch_" in l for l in body)
+
+
+def test_rows_kernel_stream_is_branch_free(decode_kernels):
+    for key, nmfma in (("delta_rows_kernelILi0ELi2ELi4ELi2ELi0ELi4E", 128), ("delta_rows_kernelILi0ELi1ELi4ELi2ELi0ELi2E", 32)):
+        body = _one(decode_kernels, key)
+        idx = [i for i, l in enumerate(body) if "v_mfma_f32_16x16x32" in l]
+        assert len(idx) == nmfma, (key, len(idx))                      # 4 stages x 4 steps x (masks x tiles) MFMAs, one rolled round
+        loop = body[idx[0]:idx[-1] + 1]
+        # the sign / activation loads of a stage are selected (v_cndmask on an opaque offset), never wrapped in a divergent branch: hipcc sank them
+        # into both arms of one, with s_waitcnt vmcnt(0) between, when the offset was a plain conditional expression (-15 ... -25 %)
+        assert not any("s_cbranch" in l for l in loop), key
+        assert not any("vmcnt(0)" in l for l in loop), key
+        assert sum("buffer_load_dword" in l for l in loop) >= 4 * 5 - 5, key
+        assert not any("scratch_" in l for l in body), key
