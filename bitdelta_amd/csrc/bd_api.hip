@@ -1541,12 +1541,26 @@ extern "C" int bd_srv_rope(void* X, const void* cos_t, const void* sin_t, int ro
 #ifndef BD_ATTN_SPLITS
 #define BD_ATTN_SPLITS 4
 #endif
-constexpr int ATTN_SPLITS = BD_ATTN_SPLITS;
-static_assert(ATTN_SPLITS <= ATTN_MAX_SPLITS, "decode_attn_kernel merges at most ATTN_MAX_SPLITS partials");   // (a build-time knob for A/B runs; 4 measured best, profiles/r03_decode_attn_splits.txt)
+constexpr int ATTN_SPLITS = BD_ATTN_SPLITS;   // (a build-time knob for A/B runs; 4 measured best at 6 tenants x 8 kv heads, profiles/r03_decode_attn_splits.txt, r05_decode_step.txt)
+constexpr int ATTN_SPLITS_MAX = 16;
+static_assert(ATTN_SPLITS <= 4, "decode_attn_kernel<.., MAXS = 4> merges at most 4 partials");
 constexpr int64_t ATTN_TICKET_BYTES = 16384;       // one arrival counter per (tenant, kv head): T * KVH <= 4096
+static thread_local int g_attn_splits_max = env_int("BD_ATTN_SPLITS_MAX", ATTN_SPLITS_MAX);       // A/B hook: 4 = the fixed split count of rounds 3 - 5
+// key-range splits of a launch: ATTN_SPLITS, doubled while the launch would still cover at most a QUARTER of the CUs (one or two sequences of a
+// grouped-query model: a single sequence on 8 kv heads is 32 blocks at 4 splits -- and the launch is a dependent chain of memory round trips, so
+// fewer rows per block = fewer load rounds), never more than one split per 32 cache rows.  Same-box A/B, Mistral-7B, 4 -> this rule (tools/gpu_r5y.sh):
+// 1 tenant 3.319 -> 3.275 ms/step (-1.3 %, 16 splits), 2 tenants 3.548 -> 3.544 (8 splits); doubling up to HALF of the CUs was +0.6 % at 4 tenants
+// (8 splits, 256 blocks), so 32 (tenant, kv head) pairs and more keep 4.  A function of (T, KVH, Lc) only.
+inline int attn_splits(int T, int KVH, int Lc) {
+    if (Lc < 256) return 1;                                       // short caches run unsplit
+    int ns = ATTN_SPLITS;
+    const int cap = g_attn_splits_max < ATTN_SPLITS ? ATTN_SPLITS : (g_attn_splits_max > ATTN_SPLITS_MAX ? ATTN_SPLITS_MAX : g_attn_splits_max);
+    while (ns * 2 <= cap && (int64_t)T * KVH * ns * 4 <= num_cus() && ns * 2 * 32 <= Lc) ns *= 2;
+    return ns;
+}
 extern "C" int64_t bd_srv_decode_attention_workspace_bytes(int T, int H, int KVH, int head_dim, int Lc) {
     if (T <= 0 || H <= 0 || KVH <= 0 || Lc < 256) return 0;       // short caches run unsplit
-    return ATTN_TICKET_BYTES + (int64_t)T * H * ATTN_SPLITS * (head_dim + 2) * 4;
+    return ATTN_TICKET_BYTES + (int64_t)T * H * ATTN_SPLITS_MAX * (head_dim + 2) * 4;      // (sized for the largest split count: independent of the A/B hook)
 }
 
 extern "C" int bd_srv_decode_attention(const void* QKV, const void* cos_t, const void* sin_t, void* kcache, void* vcache,
@@ -1567,15 +1581,21 @@ extern "C" int bd_srv_decode_attention(const void* QKV, const void* cos_t, const
     // split the key range over 4 blocks per (tenant, kv head) when the cache is long enough and a workspace is given: T * KVH blocks
     // alone leave most CUs (and most of HBM) idle -- one CU streams only ~12-25 GB/s
     const int64_t need = bd_srv_decode_attention_workspace_bytes(T, H, KVH, head_dim, Lc);
-    p.nsplit = (need > 0 && ws && ws_bytes >= need && (int64_t)T * KVH * 4 <= ATTN_TICKET_BYTES) ? ATTN_SPLITS : 1;
+    p.nsplit = (need > 0 && ws && ws_bytes >= need && (int64_t)T * KVH * 4 <= ATTN_TICKET_BYTES) ? attn_splits(T, KVH, Lc) : 1;
     p.tickets = (unsigned*)ws;
     p.ws = (float*)((char*)ws + ATTN_TICKET_BYTES);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)(T * KVH), (unsigned)p.nsplit);
 #define BD_ATT(DT, GG)                                                                                      \
     do {                                                                                                    \
-        if (g_attn_depth ? g_attn_depth == 2 : Lc <= 2048) hipLaunchKernelGGL((decode_attn_kernel<DT, GG, 2>), grid, dim3(512), 0, st, p);    \
-        else hipLaunchKernelGGL((decode_attn_kernel<DT, GG, 4>), grid, dim3(512), 0, st, p);                \
+        const bool d2_ = g_attn_depth ? g_attn_depth == 2 : Lc <= 2048;                                                    \
+        if (p.nsplit <= 4) {                                                                                               \
+            if (d2_) hipLaunchKernelGGL((decode_attn_kernel<DT, GG, 2, 4>), grid, dim3(512), 0, st, p);                    \
+            else hipLaunchKernelGGL((decode_attn_kernel<DT, GG, 4, 4>), grid, dim3(512), 0, st, p);                        \
+        } else {                                                                                                           \
+            if (d2_) hipLaunchKernelGGL((decode_attn_kernel<DT, GG, 2, 16>), grid, dim3(512), 0, st, p);                   \
+            else hipLaunchKernelGGL((decode_attn_kernel<DT, GG, 4, 16>), grid, dim3(512), 0, st, p);                       \
+        }                                                                                                                  \
     } while (0)
     // G = query heads per kv head: 1 (Llama-2-7B), 4 (Mistral-7B), 8 (Llama-2-70B -- also per rank under tensor parallelism).
     // Depth of the K / V row ring: 2 iterations for caches of up to 2048 positions (a split is then <= 16 iterations; 4.698 -> 4.661 ms on the

@@ -176,9 +176,11 @@ __device__ __forceinline__ float attn_ws_load(const float* src) {
     return __hip_atomic_load(const_cast<float*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-constexpr int ATTN_MAX_SPLITS = 4;            // key-range splits per (tenant, kv head) the in-launch merge is written for (host: nsplit <= this)
-template <int DT, int G, int DEPTH = 4>
+// MAXS = key-range splits per (tenant, kv head) the in-launch merge is written for (host: nsplit <= MAXS): 4, or 16 for launches with few
+// (tenant, kv head) pairs -- a single sequence on 8 kv heads is 32 blocks at 4 splits
+template <int DT, int G, int DEPTH = 4, int MAXS = 4>
 __global__ void __launch_bounds__(512) decode_attn_kernel(const AttnParams p) {
+    constexpr int ATTN_MAX_SPLITS = MAXS;
     constexpr int HD = 128, NWV = 8, RPI = 4 * NWV;
     __shared__ float q_lds[G][HD];              // rotated, pre-scaled queries
     __shared__ float kn_lds[HD], vn_lds[HD];    // the new token's rotated key / value (also written to the cache)
