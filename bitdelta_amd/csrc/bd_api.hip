@@ -37,6 +37,7 @@ static thread_local int g_tail_split = env_int("BD_TAIL_SPLIT", 1) ? 1 : 0;     
 // delta_rows_kernel A/B hook (environment only): bits 1-2 = masks per block forced to 1 / 2 / 4 (value 1 / 2 / 3), bit 4 = never chosen automatically,
 // bit 5 = 64-column super-tiles even when they leave CUs idle, bit 6 = 32-column super-tiles always
 static thread_local int g_rows_tune = env_int("BD_ROWS_TUNE", 0);
+static thread_local int g_norm_rows_min = env_int("BD_NORM_ROWS_MIN", 64);           // bd_srv_rmsnorm: rows from which the wave-per-row kernel runs (A/B hook)
 static thread_local int g_attn_depth = env_int("BD_ATTN_DEPTH", 0);                 // decode attention K / V ring depth: 0 = by cache length, 2, 4 (A/B hook)
 static thread_local int g_rows_shared_min = env_int("BD_ROWS_SHARED_MIN", 1);       // shared mask: rows from which the kernel is chosen automatically
 static thread_local int g_forced_group_m = 0;        // 0 = automatic tile order
@@ -1493,6 +1494,17 @@ extern "C" int bd_srv_rmsnorm(const void* X, const void* Wt, void* Y, int rows, 
     if (!X || !Wt || !Y) return BD_E_NULL;
     if (H % 8 || sx % 8 || sy % 8 || sw % 8 || !aligned16(X) || !aligned16(Wt) || !aligned16(Y)) return BD_E_BAD_SHAPE;
     hipStream_t st = (hipStream_t)stream;
+    // many rows of 2048 / 4096 / 6144 / 8192 elements: one wave per row, the row in registers (rmsnorm_rows_kernel; bit-identical results)
+    if (rows >= g_norm_rows_min && H % 2048 == 0 && H <= 8192) {
+        const dim3 grid((unsigned)((rows + 3) / 4));
+#define BD_NR(DT, NCH) hipLaunchKernelGGL((rmsnorm_rows_kernel<DT, NCH>), grid, dim3(256), 0, st, (const unsigned short*)X, (const unsigned short*)Wt, \
+                                          (unsigned short*)Y, rows, (long long)sx, (long long)sy, (long long)sw, rows_per_tenant, eps)
+        const int nch = H / 2048;
+        if (dtype == BD_BF16) { if (nch == 1) BD_NR(DT_BF16, 1); else if (nch == 2) BD_NR(DT_BF16, 2); else if (nch == 3) BD_NR(DT_BF16, 3); else BD_NR(DT_BF16, 4); }
+        else { if (nch == 1) BD_NR(DT_F16, 1); else if (nch == 2) BD_NR(DT_F16, 2); else if (nch == 3) BD_NR(DT_F16, 3); else BD_NR(DT_F16, 4); }
+#undef BD_NR
+        return launch_status();
+    }
     if (dtype == BD_BF16)
         hipLaunchKernelGGL((rmsnorm_tenant_kernel<DT_BF16>), dim3(rows), dim3(256), 0, st, (const unsigned short*)X, (const unsigned short*)Wt,
                            (unsigned short*)Y, H, (long long)sx, (long long)sy, (long long)sw, rows_per_tenant, eps);

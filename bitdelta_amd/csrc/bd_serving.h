@@ -88,6 +88,46 @@ __global__ void __launch_bounds__(256) rmsnorm_tenant_kernel(const unsigned shor
         *(u32x4_t*)(yr + c) = norm8<DT>(*(const u32x4_t*)(xr + c), *(const u32x4_t*)(wr + c), rs);
 }
 
+// The same norm for MANY rows (prefill: hundreds to thousands of rows): ONE WAVE per row, four rows per block, the row held in registers between
+// the two passes -- no block barrier, no second read of x.  Bit-identical to rmsnorm_tenant_kernel: lane l plays that kernel's threads l, l + 64,
+// l + 128, l + 192 (its four waves), so the four per-wave sums are formed by the same lanes in the same order and meet in rms_scale as before.
+// H = 2048 * NCH, NCH = 1 .. 4 (host-checked).  One block-per-row launch of 2048 rows x 4096 measured 13.1 us against torch's 8.5
+// (profiles/r03_prefill_glue.txt): a 256-thread block per 8-KB row is one 16-byte load per thread and a barrier.
+template <int DT, int NCH>
+__global__ void __launch_bounds__(256) rmsnorm_rows_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
+                                                           unsigned short* __restrict__ y, int rows, long long sx, long long sy,
+                                                           long long sw, int rows_per_tenant, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;                                                // (wave-uniform; no barrier in this kernel)
+    const int t = r / rows_per_tenant;
+    const unsigned short* xr = x + (long long)r * sx;
+    const unsigned short* wr = w + (long long)t * sw;
+    unsigned short* yr = y + (long long)r * sy;
+    u32x4_t xv[4][NCH], wv[4][NCH];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) xv[v][i] = *(const u32x4_t*)(xr + 8 * (lane + 64 * v) + 2048 * i);
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) wv[v][i] = *(const u32x4_t*)(wr + 8 * (lane + 64 * v) + 2048 * i);
+    float part[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) ss = sumsq8<DT>(xv[v][i], ss);
+        part[v] = wave_sum(ss);
+    }
+    const float rs = rms_scale(part[0], part[1], part[2], part[3], 2048 * NCH, eps);
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) *(u32x4_t*)(yr + 8 * (lane + 64 * v) + 2048 * i) = norm8<DT>(xv[v][i], wv[v][i], rs);
+}
+
 // g, u [rows, I] (row strides sg, su; the fused gate|up output passes u = g + I) -> y [rows, I];  I % 8 == 0.
 // il8 = 1: the projection output is interleaved in blocks of 8 ([g0..7 | u0..7 | g8..15 | u8..15 ...], the row order
 // FusedDeltaLinear gives a gate|up pair so that the decode kernel can apply SwiGLU in its epilogue): g = gp + 2c, u = gp + 2c + 8.

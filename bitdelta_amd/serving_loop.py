@@ -310,13 +310,18 @@ class TenantDecoder(nn.Module):
         return {"k": [mk() for _ in self.layers], "v": [mk() for _ in self.layers],
                 "valid": torch.zeros(self.T, length, dtype=torch.bool, device=self.dev)}
 
-    # prefill: the HIP per-tenant RMSNorm (ONE launch) up to this many rows; stock torch beyond (F.rms_norm + the weight multiply = three
-    # launches, but faster per row on long prompts: 2048-row prefill 8.5 vs 13.1 us, profiles/r03_prefill_glue.txt).  A 6-tenant request
+    # prefill: the HIP per-tenant RMSNorm (ONE launch).  Its block-per-row form is used up to this many rows and stock torch beyond (F.rms_norm +
+    # the weight multiply = three launches, but faster per row on long prompts: 2048-row prefill 8.5 vs 13.1 us, profiles/r03_prefill_glue.txt);
+    # since late in round 5 hidden sizes that are multiples of 2048 take the wave-per-row form at every size (rmsnorm_rows_kernel, bit-identical):
+    # 6 tenants x 256 rows 10.7 us against 21.2 for the torch composition, 2048 rows 12.0 against 22.5 (tools/bench_norm.py; torch's rms_norm with
+    # a FUSED weight -- one weight for all rows, not this loop's per-tenant weights -- is 10.1: bench_model keeps it).  A 6-tenant request
     # padded to 64 tokens (384 rows) spends 15.5 us per norm in the three torch kernels against ~5 us here (profiles/r05_mt_prefill_tiles.txt).
     HIP_NORM_MAX_ROWS = 1024
 
     def _norm(self, x, w):
-        if self.fast_glue and x.shape[-1] % 8 == 0 and (x.shape[1] <= 16 or x.shape[0] * x.shape[1] <= self.HIP_NORM_MAX_ROWS):
+        H = x.shape[-1]
+        # (hidden sizes of 2048 / 4096 / 6144 / 8192: the wave-per-row kernel, any number of rows -- bd_srv_rmsnorm picks it from 64 rows on)
+        if self.fast_glue and H % 8 == 0 and (x.shape[1] <= 16 or x.shape[0] * x.shape[1] <= self.HIP_NORM_MAX_ROWS or (H % 2048 == 0 and H <= 8192)):
             return ops.rmsnorm_tenant(x if x.is_contiguous() else x.contiguous(), w, self.eps)
         return F.rms_norm(x, (x.shape[-1],), None, self.eps) * w[:, None, :]
 

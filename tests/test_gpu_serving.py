@@ -1,6 +1,8 @@
 """GPU tests of the serving-side pieces: per-tenant dense weights, residual epilogue,
 the opt-in differentiable delta term.  Checked against the REFERENCE EXPRESSIONS restated in plain torch fp32 on the device
 (demo/demo_backend.py:62-79 for the per-tenant loop, bitdelta/diff.py:39 for the training composition) and the CPU oracle."""
+import os
+import sys
 import pytest
 import torch
 import torch.nn as nn
@@ -938,3 +940,39 @@ def test_decoder_with_norm_handoff_matches_the_separate_launch_decoder(bd):
     dec.norm_handoff = True
     tg, _ = dec.generate(prompts, max_new_tokens=6, use_graph=True)
     assert torch.equal(tg, outs[True][0])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T,M,H", [(1, 2048, 4096), (6, 64, 4096), (3, 100, 2048), (1, 257, 8192), (2, 96, 6144), (1, 70, 4096)])
+def test_rmsnorm_many_rows_kernel_is_bit_identical_to_the_row_per_block_kernel(bd, dtype, T, M, H):
+    """rmsnorm_rows_kernel (one wave per row, the row in registers; bd_srv_rmsnorm from 64 rows on) forms the four per-wave sums of
+    rmsnorm_tenant_kernel with the same lanes in the same order: the two launches must agree BIT FOR BIT (a child process with
+    BD_NORM_ROWS_MIN raised runs the block-per-row kernel), on strided rows too, and both match the HF definition"""
+    import subprocess
+    import torch.nn.functional as F
+    from bitdelta_amd import serving_ops as ops
+    g = torch.Generator().manual_seed(T * 1000 + M + H)
+    xfull = torch.randn(T, M, H + 64, generator=g).to(dtype).cuda()
+    x = xfull[..., :H]                                        # row stride H + 64: rows are not back to back
+    w = (1 + 0.1 * torch.randn(T, H, generator=g)).to(dtype).cuda()
+    got = ops.rmsnorm_tenant(x, w, 1e-5)
+    v = x.float()
+    want = (v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + 1e-5)).to(dtype) * w[:, None, :]       # HF LlamaRMSNorm
+    assert torch.allclose(got.float(), want.float(), rtol=2 ** -7 if dtype == torch.bfloat16 else 2 ** -10, atol=1e-3)
+    # the block-per-row kernel in a child process (the dispatch threshold is read once per thread from the environment)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "gpurun_out", f"_norm_ab_{os.getpid()}.pt")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    torch.save({"x": xfull.cpu(), "w": w.cpu(), "H": H}, path)
+    code = ("import torch, sys; from bitdelta_amd import serving_ops as ops; d = torch.load(sys.argv[1]); "
+            "x = d['x'].cuda()[..., :d['H']]; y = ops.rmsnorm_tenant(x, d['w'].cuda(), 1e-5); torch.save(y.cpu(), sys.argv[1] + '.out')")
+    try:
+        r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, cwd=root, timeout=300,
+                           env=dict(os.environ, BD_NORM_ROWS_MIN="1000000000"))
+        assert r.returncode == 0, r.stderr[-1500:]
+        old = torch.load(path + ".out")
+    finally:
+        for f in (path, path + ".out"):
+            if os.path.exists(f):
+                os.remove(f)
+    assert torch.equal(got.cpu(), old)
