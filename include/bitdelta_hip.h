@@ -244,6 +244,10 @@ int bd_merge_delta(void* W, int64_t ldw, const int32_t* P, const float* coeff, i
  * always; 801 / 802 / 804 force the masks per block).  Needs N % 32 == 0, K % 128 == 0.
  * A forced variant whose preconditions fail returns BD_E_BAD_SHAPE instead of silently falling back.
  * Environment: BD_GEMM_VARIANT=<n> is every thread's initial forced variant (overridden by this call), BD_TAIL_SPLIT=0 disables the tail split.
+ * Further A/B hooks read once per thread from the environment (none is needed in production): BD_ROWS_TUNE (delta_rows_kernel: bits 1-2 masks per
+ * block, bit 4 never automatic, bit 5 / 6 force 64- / 32-column super-tiles), BD_ROWS_SHARED_MIN (rows from which a shared-mask launch takes it),
+ * BD_ATTN_DEPTH (decode attention K / V ring: 2 / 4), BD_ATTN_SPLITS_MAX (key-range splits: 4 = fixed, 16 = by tenants x kv heads),
+ * BD_NORM_ROWS_MIN (rows from which bd_srv_rmsnorm runs its wave-per-row kernel).
  * The bd_set_* entry points below are TUNING / TEST HOOKS: thread-local, not part of the stable interface a reference-side binding
  * needs (INTEGRATION.md binds none of them), and free to change between versions. */
 int bd_set_gemm_variant(int variant);
