@@ -555,9 +555,11 @@ def run_mt_decode(dev, timer, model_name, tenants, kv_len, steps, warmup, layers
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda._sleep(200000); torch.cuda.synchronize()
         e0.record(); torch.cuda._sleep(2000000); e1.record(); torch.cuda.synchronize()
-        cyc_per_ms = 2000000 / max(e0.elapsed_time(e1), 1e-3)
-        hold = int(cyc_per_ms * max(2.0 * eager_s / steps * 1e3, 8.0))          # >= twice the eager step
-        queued = True
+        t_cal = e0.elapsed_time(e1)
+        cyc_per_ms = 2000000 / max(t_cal, 1e-3)
+        hold_ms = min(max(2.0 * eager_s / steps * 1e3, 8.0), 60.0)               # >= twice the eager step, never more than 60 ms per step
+        hold = int(cyc_per_ms * hold_ms)
+        queued = 0.05 < t_cal < 500.0                                            # (a calibration outside this window: keep the eager figure)
     except Exception:                       # no spin kernel in this torch build: the eager figure, labelled as such
         queued = False
     timer.reset()
