@@ -42,6 +42,11 @@ def test_library_exports_every_declared_symbol():
     assert L.bd_gemm_workspace_bytes(64, 1, 4096, 4096) > 0 and L.bd_gemm_workspace_bytes(65, 1, 4096, 4096) == 0
     assert L.bd_gemm_workspace_bytes(1, 64, 4096, 4096) == 65536 + 8 * 64 * 4096 * 4
     assert L.bd_gemm_workspace_bytes(1, 1024, 4096, 4096) == 0
+    # decode attention: ticket area + one (acc[128], max, sum) partial per (tenant, query head, key-range split), sized for the LARGEST split count
+    # the run-time rule can pick (16), a function of the geometry only; caches shorter than 256 positions run unsplit and need none
+    assert L.bd_srv_decode_attention_workspace_bytes(6, 32, 8, 128, 576) == 16384 + 6 * 32 * 16 * 130 * 4
+    assert L.bd_srv_decode_attention_workspace_bytes(1, 32, 32, 128, 4096) == 16384 + 32 * 16 * 130 * 4
+    assert L.bd_srv_decode_attention_workspace_bytes(6, 32, 8, 128, 128) == 0
 
 
 def test_python_surface_matches_reference_names_and_signatures():
