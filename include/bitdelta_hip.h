@@ -202,7 +202,8 @@ int bd_srv_decode_attention(const void* QKV, const void* cos_t, const void* sin_
 int bd_srv_prefill_attention(const void* Q, const void* K, const void* V, void* O, int B, int S, int H, int KVH, int head_dim,
                              int64_t sqb, int64_t sqs, int64_t skb, int64_t sks, int64_t svb, int64_t svs, int64_t sob, int64_t sos,
                              const int32_t* kv_start, float scale, int causal, int dtype, void* stream);
-/* scratch for bd_srv_decode_attention's split of the key range over 4 blocks per (tenant, kv head), merged inside the launch by the
+/* scratch for bd_srv_decode_attention's split of the key range over 4 blocks per (tenant, kv head) (up to 16 for one or two sequences of a
+ * grouped-query model; the size returned covers the largest split count and depends on the geometry only), merged inside the launch by the
  * block that finishes last (0 = the cache is short enough to run unsplit; ws may then be NULL).  Without a workspace the kernel
  * runs unsplit.  CONTRACT: the first 16 KiB of ws (arrival counters) are ZERO when the launch is enqueued; the kernel puts them
  * back to zero, so a buffer that is zero-filled once and used by one stream at a time can be reused by every call. */
