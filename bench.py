@@ -39,6 +39,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+def _pin_from_env():
+    """The pinned child of cpu_baseline(): adopt the affinity mask the parent chose BEFORE torch (and its OpenMP / MKL pools) is imported."""
+    cores = os.environ.get("BD_CPU_BASELINE_CORES")
+    if "--cpu-baseline-child" in sys.argv and cores and hasattr(os, "sched_setaffinity"):
+        try:
+            os.sched_setaffinity(0, [int(c) for c in cores.split(",") if c != ""])
+        except (OSError, ValueError):
+            pass
+
+
+_pin_from_env()
+
 import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0        # dense MFMA peak, MI355X_MICROARCH.md (AMD's 5 PF figure is 2:1 sparse)
@@ -138,18 +151,14 @@ def cpu_baseline(seq=2048, reps=5):
     import subprocess
     cores = physical_cores()
 
-    def pin():
-        if hasattr(os, "sched_setaffinity"):
-            try:
-                os.sched_setaffinity(0, cores)
-            except OSError:
-                pass
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    env.update(OMP_NUM_THREADS=str(len(cores)), MKL_NUM_THREADS=str(len(cores)))
+    # (no preexec_fn: this process has torch / HIP threads, and Python documents fork-time callbacks as unsafe then -- ADVICE r05.  The child
+    #  receives the core list in BD_CPU_BASELINE_CORES and pins itself as its FIRST statement, before torch is imported: _pin_from_env below.)
+    env.update(OMP_NUM_THREADS=str(len(cores)), MKL_NUM_THREADS=str(len(cores)), BD_CPU_BASELINE_CORES=",".join(str(c) for c in cores))
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--seq", str(seq), "--steps", str(reps)],
-                       capture_output=True, text=True, preexec_fn=pin, env=env, cwd=ROOT, timeout=900)
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if r.returncode != 0 or not lines:
         raise RuntimeError(f"cpu_baseline child failed (rc {r.returncode}): {r.stderr[-1500:]}")
@@ -267,7 +276,8 @@ def parity_block(dev):
     c32 = bd.delta_bmm(x.to(dev), p.to(dev), out_dtype=torch.float32, round_mode=0)
     ref32 = o.delta_bmm(x, p[:, :, cols].contiguous(), out_dtype=torch.float32, round_mode=0)
     d = ulp(c16[:, :, cols.to(dev)].cpu().contiguous(), ref32.bfloat16())
-    out["delta_gemm_4096"] = {"kernel_variant": v, "sampled_columns": len(cols), "max_ulp": int(d.max()), "bit_equal": float((d == 0).float().mean()),
+    out["delta_gemm_4096"] = {"kernel_variant": v, "sampled_columns": len(cols), "max_ulp": int(d.max()), "n_needed_floor": 0, "n_checked": int(d.numel()),
+                              "bit_equal": float((d == 0).float().mean()),
                               "fp32_mode_rel_frobenius": float(((c32[:, :, cols.to(dev)].cpu().double() - ref32.double()).norm() / ref32.double().norm()))}
     # (2) the fused Linear of the timed prefill at its largest shape (2048 x 4096 -> 11008)
     M, N = 2048, 11008
@@ -286,6 +296,7 @@ def parity_block(dev):
     ok = (d <= 1) | ((got.float() - ref32.bfloat16().float()).abs() <= floor)
     out["fused_linear_2048x4096_to_11008"] = {
         "kernel_variant": v, "sampled_columns": len(cols), "max_ulp": int(d.max()), "all_within_gate": bool(ok.all()),
+        "n_needed_floor": int((d > 1).sum()), "n_checked": int(d.numel()),
         "bit_equal": float((d == 0).float().mean()),
         "fp32_mode_rel_frobenius": float(((y32[:, :, cols.to(dev)].cpu().double() - ref32.double()).norm() / ref32.double().norm())),
         "rel_frobenius_16bit_vs_fp32_oracle": float(((got.double() - ref32.double()).norm() / ref32.double().norm()))}
@@ -317,7 +328,8 @@ def parity_block(dev):
         floor = 2.0 ** -22 * (K ** 0.5) * ref32.abs().amax(dim=-1, keepdim=True)      # per activation row
         ok = (d <= 1) | ((got.float() - ref32.bfloat16().float()).abs() <= floor)
         out[name] = {"kernel_variant": v, "scale_groups": lin.groups, "sampled_columns": len(cols), "max_ulp": int(d.max()),
-                     "all_within_gate": bool(ok.all()), "bit_equal": float((d == 0).float().mean()),
+                     "all_within_gate": bool(ok.all()), "n_needed_floor": int((d > 1).sum()), "n_checked": int(d.numel()),
+                     "bit_equal": float((d == 0).float().mean()),
                      "fp32_mode_rel_frobenius": float(((y32[:, :, cols.to(dev)].cpu().double() - ref32.double()).norm() / ref32.double().norm()))}
         del lin, x, y16, y32
     return out
@@ -797,69 +809,108 @@ def main():
     value = tokens / dt
     n_layers = len(model.layers)
     lin_params = model.linear_param_count()
+    model_glue = getattr(model, "glue", "RMSNorm: torch; RoPE, causal attention (bd_srv_prefill_attention), SwiGLU: HIP kernels of this library")
     del model
     torch.cuda.empty_cache()
     if rank != 0:
         return
     mb = delta_gemm_microbench(dev)
+    vg = vendor_gemm_microbench(dev)
+    ceil = mfma_ceiling_block()
     traffic = committed_traffic()
     achieved = k_flops / k_ms * 1e-9 if k_ms > 0 else 0.0
+    detail = {"delta_gemm": mb, "vendor_gemm": vg, "mfma_ceiling": ceil, "published_shapes": published_shapes_block(dev)}
+
+    def fr(x, nd=4):
+        return round(x, nd) if isinstance(x, (int, float)) else x
+
+    # The contract line stays SHORT (< 6 KB: the driver's record truncates long lines and keeps only `roofline` / `cpu_baseline` / `config` of the
+    # non-contract keys): every figure the north star names sits inside `roofline`; the long blocks go to a "# bench detail" line printed BEFORE it.
+    roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+            "traffic": traffic.get("fused_gemm", {}).get("traffic_bytes_per_launch") if traffic else None,
+            "traffic_source": "profiles/r05_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE passes over this command)" if traffic else "none",
+            "traffic_over_algorithmic": fr(traffic["fused_gemm"]["traffic_bytes_per_launch"] / (k_bytes / n_launch), 3)
+                                        if traffic and n_launch and traffic.get("fused_gemm") else None,
+            "algorithmic_bytes_per_launch": k_bytes / n_launch if n_launch else None,
+            "kernel": "bd::delta_gemm_w4_kernel<bf16, 256x128, fused> (x.W^T + alpha*(x.S), 4MNK flop/launch; tail on 128x128 tiles)",
+            "launches": n_launch, "kernel_ms_total": fr(k_ms, 3), "algorithmic_flops_total": k_flops,
+            "measured_in": "second pass of the same K steps, one HIP event pair per fused launch",
+            "ms_per_step_with_events": fr(dt_events / args.steps * 1e3, 3),
+            "share_of_step_time": fr((k_ms / 1e3) / dt_events, 4) if dt_events > 0 else None,
+            # the north star's own figure: the W1A16 delta-GEMM ALONE (2MNK) at K = N = 4096, fraction of 2.5 PF per M; the vendor's bf16 GEMM and the
+            # pure-MFMA soak of the same run beside it
+            "delta_gemm": {str(r["shape"][0]): fr(r["frac_of_peak"]) for r in mb},
+            "delta_gemm_tflops": {str(r["shape"][0]): fr(r["tflops"], 1) for r in mb},
+            "vendor_gemm": {str(r["shape"][0]): fr(r["frac_of_peak"]) for r in vg},
+            "mfma_ceiling": {k: fr(v.get("frac_of_peak")) for k, v in ceil.items() if isinstance(v, dict) and "frac_of_peak" in v}}
     out = {
         "metric": "W1A16 binary-delta GEMM TFLOP/s + tokens/s, Llama-2-7B+Vicuna delta, 1/2/4/8 MI355X "
-                  "(value = end-to-end prefill tokens/s; delta_gemm.tflops = the GEMM figure)",
+                  "(value = end-to-end prefill tokens/s; roofline.delta_gemm = the GEMM figure)",
         "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"{args.model} base + one 1-bit delta, prefill seq {args.seq}, batch 1 per GPU "
-                               f"(BASELINE.json configs[1]); {n_layers} layers x 4 fused-Linear launches (q|k|v, o, gate|up, down = the 7 BinaryDiff "
-                               f"projections of a layer)",
+        "config": {"workload": f"{args.model} base + one 1-bit delta, prefill seq {args.seq}, batch 1 per GPU (BASELINE.json configs[1])",
+                   "launches": f"{n_layers} layers x 4 fused-Linear launches (q|k|v, o, gate|up, down = a layer's 7 BinaryDiff projections)",
                    "seq_len": args.seq, "global_batch": world, "parallelism": f"dp{world} independent replicas, no collective",
-                   "glue": "RMSNorm: torch; RoPE (q|k in place), causal attention (bd_srv_prefill_attention), SwiGLU: HIP kernels of this library",
-                   "valid": args.layers is None},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_BF16_TFLOPS,
-                     "traffic": traffic.get("fused_gemm", {}).get("traffic_bytes_per_launch") if traffic else None,
-                     "traffic_source": traffic.get("_source") if traffic else
-                                       "not available: PMC counters need rocprofv3 passes (tools/prof_bench.sh writes profiles/r05_traffic.json)",
-                     "traffic_over_algorithmic": (traffic["fused_gemm"]["traffic_bytes_per_launch"] / (k_bytes / n_launch))
-                                                 if traffic and n_launch and traffic.get("fused_gemm") else None,
-                     "algorithmic_bytes_total": k_bytes, "algorithmic_bytes_per_launch": k_bytes / n_launch if n_launch else None,
-                     "kernel": "bd::delta_gemm_w4_kernel<bf16, 256x128 tile, fused> (four-wave persistent one-pass fused kernel: "
-                               "x.W^T + alpha*(x.S), 4*M*N*K flop/launch; a tail split hands the last partial round's columns to the same "
-                               "kernel on 128x128 tiles)",
-                     "launches": n_launch, "kernel_ms_total": k_ms, "algorithmic_flops_total": k_flops,
-                     "measured_in": "a second pass of the same K steps with one HIP event pair per fused launch (the timed region of `value` "
-                                    "carries no events)",
-                     "ms_per_step_with_events": dt_events / args.steps * 1e3,
-                     "share_of_step_time": (k_ms / 1e3) / dt_events if dt_events > 0 else None},
+                   "glue": model_glue, "valid": args.layers is None},
+        "roofline": roof,
         **bdd.runtime_info(),
-        "delta_gemm": mb,
-        "vendor_gemm": vendor_gemm_microbench(dev),
-        "published_shapes": published_shapes_block(dev),
-        "mfma_ceiling": mfma_ceiling_block(),
         "linear_params": lin_params,
     }
-    if world == 1 and not args.no_mt_decode:
+    single = world == 1 and not args.no_mt_decode
+    dec_keys = ("tenants", "valid", "eager_ms_per_step", "hipgraph_ms_per_step", "hipgraph_error", "tokens_per_s", "linear_frac_of_hbm_peak",
+                "step_frac_of_hbm_peak", "norm_handoff")
+
+    def decode_leg(key, model, tenants, what):
         try:
-            out["mt_decode"] = run_mt_decode(dev, timer, "mistral-7b", args.tenants or 6, args.kv_len, 20, 3, layers=args.layers)
+            d = run_mt_decode(dev, timer, model, tenants, args.kv_len, 20, 3, layers=args.layers)
+            detail[key] = d
+            out[key] = {"what": what, **{k: fr(d.get(k)) for k in dec_keys}}
+            out[key + "_ms"] = fr(d["hipgraph_ms_per_step"] or d["eager_ms_per_step"])
+            roof[key + "_ms"] = out[key + "_ms"]
+            roof[key + "_frac_of_hbm_peak"] = fr(d["step_frac_of_hbm_peak"])
         except Exception as e:
-            out["mt_decode"] = {"error": f"{type(e).__name__}: {e}"}
-    if world == 1 and not args.no_mt_decode:
-        # SURVEY.md 8(d) C2 "plus decode steps": the headline model itself, one sequence, one delta, greedy decode (hipGraph replay)
+            out[key] = {"error": f"{type(e).__name__}: {e}"}
+    if single:
+        decode_leg("mt_decode", "mistral-7b", args.tenants or 6, "configs[2]: Mistral-7B base + 6 tenant deltas, batched greedy decode, kv 512, hipGraph replay")
+        # SURVEY.md 8(d) C2 "plus decode steps": the headline model itself, one sequence, one delta
+        decode_leg("decode_7b", "llama-2-7b", 1, "Llama-2-7B base + ONE delta, single-sequence greedy decode, hipGraph replay")
+        # configs[4]'s per-GPU unit: 32 tenants sharded 4 per GPU over 8 GPUs (no collective) -- one GPU's share
+        decode_leg("mt_decode_t4", "mistral-7b", 4, "configs[4] per-GPU unit: Mistral-7B base + 4 tenant deltas (32 tenants over 8 GPUs, no collective)")
+        # configs[3]'s per-GPU unit: ONE rank's Llama-2-70B TP = 8 shards, all 80 layers, on this GPU; the all-reduce after o / down is STUBBED OUT
         try:
-            d7 = run_mt_decode(dev, timer, "llama-2-7b", 1, args.kv_len, 20, 3, layers=args.layers)
-            out["decode_7b"] = {k: d7[k] for k in ("workload", "tenants", "steps", "valid", "eager_ms_per_step", "hipgraph_ms_per_step",
-                                                   "hipgraph_error", "tokens_per_s", "delta_linear_bytes_per_step", "lm_head_bytes_per_step",
-                                                   "linear_gbs", "linear_frac_of_hbm_peak", "step_gbs", "step_frac_of_hbm_peak")}
+            from bitdelta_amd.tp import bench_tp70b_shard
+            d = bench_tp70b_shard(dev, timer, layers=args.layers)
+            detail["tp70b_shard"] = d
+            out["tp70b_shard"] = {k: fr(v) for k, v in d.items() if k in ("what", "exchange", "layers", "prefill_ms", "prefill_fused_frac_of_mfma_peak",
+                                                                          "decode_ms", "decode_frac_of_hbm_peak", "valid")}
+            roof["tp70b_shard_decode_ms"] = fr(d.get("decode_ms"))
+            roof["tp70b_shard_decode_frac_of_hbm_peak"] = fr(d.get("decode_frac_of_hbm_peak"))
+            roof["tp70b_shard_prefill_ms"] = fr(d.get("prefill_ms"))
+            roof["tp70b_shard_prefill_frac_of_mfma_peak"] = fr(d.get("prefill_fused_frac_of_mfma_peak"))
         except Exception as e:
-            out["decode_7b"] = {"error": f"{type(e).__name__}: {e}"}
+            out["tp70b_shard"] = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        cb = cpu_baseline()
+        detail["cpu_baseline_sample"] = cb.get("sample")
+        cb["sample"] = (f"one {args.seq}-token sequence through a layer's 7 projections x 32 layers; per distinct shape 1 warm-up + median of 5 "
+                        f"calls; unpack inside the timed region; {cb.get('cores')} threads pinned one per physical core (full text: detail line)")
+        cb["matmul_only"] = {"value": fr(cb.get("matmul_only", {}).get("value"), 3), "unit": "tokens/s", "what": "pre-unpacked signs, torch.matmul only"}
+        out["cpu_baseline"] = cb
         try:
-            out["parity"] = parity_block(dev)
+            pb = parity_block(dev)
+            detail["parity"] = pb
+            out["parity"] = {"oracle": "oracle/bd_oracle.c, sampled columns x all rows x all k (gate text: detail line)",
+                             **{k: {kk: fr(vv, 6) for kk, vv in v.items() if kk in ("kernel_variant", "max_ulp", "all_within_gate", "n_needed_floor",
+                                                                                    "n_checked", "bit_equal", "fp32_mode_rel_frobenius")}
+                                for k, v in pb.items() if isinstance(v, dict)}}
         except Exception as e:
             out["parity"] = {"error": f"{type(e).__name__}: {e}"}
-    print(json.dumps(out), flush=True)
+    print("# bench detail (long blocks; the ONE contract line follows): " + json.dumps(detail), flush=True)
+    line = json.dumps(out)
+    if len(line) > 6000:
+        print(f"bench.py: warning: contract line is {len(line)} bytes (> 6000)", file=sys.stderr)
+    print(line, flush=True)
 
 
 if __name__ == "__main__":

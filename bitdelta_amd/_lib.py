@@ -40,6 +40,7 @@ SIGNATURES = {
                                             _i64, _i64, _ci, _ci, _ci, _vp, _i64, ctypes.c_float, _ci, _vp]),
     "bd_binary_linear_decode_handoff": (_ci, [_vp, _vp, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _ci,
                                               _i64, _i64, _ci, _ci, _ci, _vp, _i64, ctypes.c_float, _ci, _vp, _vp, _vp, _vp]),
+    "bd_srv_cache_warm": (_ci, [_vp, _i64, _vp, _i64, _ci, _vp]),
     "bd_srv_rope": (_ci, [_vp, _vp, _vp, _ci, _ci, _ci, _i64, _ci, _ci, _ci, _vp]),
     "bd_srv_decode_attention": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _i64, _i64, _ci, _vp, _i64, _vp]),
     "bd_srv_decode_attention_workspace_bytes": (_i64, [_ci, _ci, _ci, _ci, _ci]),
@@ -58,6 +59,7 @@ SIGNATURES = {
     "bd_set_decode_wave_spec": (_ci, [_ci]),
     "bd_set_decode_small_lut": (_ci, [_ci]),
     "bd_set_stream_tuning": (_ci, [_ci]),
+    "bd_last_decode_form": (_ci, []),
     "bd_set_decode_generic_loop": (_ci, [_ci]),
     "bd_set_decode_engine": (_ci, [_ci]),
     "bd_set_ring_tuning": (_ci, [_ci]),

@@ -3,6 +3,7 @@
 // change what other threads launch; the per-DEVICE caches (CU count, "max dynamic LDS already raised for this kernel") are keyed
 // by the current device id -- the reference's demo runs one process over several GPUs (demo/demo_backend.py:23-25).
 #include "../../include/bitdelta_hip.h"
+#include "../../include/bitdelta_hip_test.h"
 #include "bd_bits.h"
 #include "bd_gemm_generic.h"
 #include "bd_gemm_mfma.h"
@@ -57,6 +58,7 @@ static thread_local int g_ring_tune = -1;             // variant 700 knobs, -1 =
                                                       // ring even when a resident copy fits, bit 2 = ONE loader wave (default two), bits 8..13 = cap on
                                                       // the ring slots (0 = none)
 static thread_local int t_last_variant = -1;
+static thread_local int t_last_decode_form = 0;    // 1 = the last streaming decode launch took the fine-grid form
 
 extern "C" int bd_version(void) { return 1; }
 extern "C" int bd_set_gemm_variant(int v) { g_forced_variant = v; return BD_OK; }
@@ -68,6 +70,7 @@ extern "C" int bd_set_decode_wave_spec(int on) { g_gemv_wave_spec = on ? 1 : 0; 
 extern "C" int bd_set_launch_chunking(int on) { g_launch_chunking = on ? 1 : 0; return BD_OK; }
 extern "C" int bd_set_decode_generic_loop(int on) { g_col16_no_per4 = on ? 1 : 0; return BD_OK; }
 extern "C" int bd_set_stream_tuning(int flags) { g_stream_tune = flags; return BD_OK; }
+extern "C" int bd_last_decode_form(void) { return t_last_decode_form; }
 extern "C" int bd_set_decode_engine(int engine) { g_decode_engine = engine < 0 ? -1 : (engine ? 1 : 0); return BD_OK; }
 extern "C" int bd_set_ring_tuning(int flags) { g_ring_tune = flags; return BD_OK; }
 extern "C" int bd_set_decode_small_lut(int mode) { g_col16_small_lut = mode < 0 ? -1 : (mode ? 1 : 0); return BD_OK; }
@@ -340,6 +343,7 @@ int launch_gemv_col16_chunk(const Problem& q) {
 // ---- streaming decode kernel (gemv_stream_kernel, variant 600): one 8-wave block per CU, contiguous column range per block
 constexpr int STREAM_MIN_N = 512;
 constexpr int STREAM_WT_NT_DEFAULT = 1;           // (-3.6 % on the 6-tenant Mistral decode step, same process: profiles/r04_decode_ab.txt)
+constexpr int STREAM_FG_DEFAULT = 1;              // fine grid (single-tile blocks, two per CU) where the tile count is between one and two per CU
 constexpr int STREAM_XRES_DEFAULT = 1;            // activation rows resident in LDS + deeper prefetch (XL = 2) where the rule below says so
 // (STREAM_WT_NT_DEFAULT: non-temporal policy on the tile-major weight loads of the streaming kernel)
 inline bool stream_ok(const Problem& q, int rows, int nmask) {
@@ -354,13 +358,14 @@ inline bool stream_ok(const Problem& q, int rows, int nmask) {
 }
 
 constexpr int STREAM_LDS_MAX = 160 * 1024;        // LDS of a gfx950 CU: the fused-norm kernels add R activation rows to STREAM_LDS_BYTES
-template <int DT, int NM, bool HASW, int NS, int NW = 8, int WNAT = 0, int AUX = 2, int PK = 0, int XL = 0, int EPI = 0, int WT = 0>
+template <int DT, int NM, bool HASW, int NS, int NW = 8, int WNAT = 0, int AUX = 2, int PK = 0, int XL = 0, int EPI = 0, int WT = 0, int FG = 0>
 int launch_stream_inst(const StreamParams& sp, dim3 grid, hipStream_t st) {
-    auto kern = gemv_stream_kernel<DT, NM, HASW, NS, NW, WNAT, AUX, PK, XL, EPI, WT>;
+    auto kern = gemv_stream_kernel<DT, NM, HASW, NS, NW, WNAT, AUX, PK, XL, EPI, WT, FG>;
     static std::atomic<uint64_t> lds_done{0};
-    const int lds = XL ? std::max((int)(sp.xs_off + (uint32_t)sp.g.R * sp.xrow), STREAM_LDS_BYTES) : STREAM_LDS_BYTES;
-    if (lds > STREAM_LDS_MAX) return BD_E_BAD_SHAPE;
-    if (!ensure_dyn_lds((const void*)kern, XL ? STREAM_LDS_MAX : STREAM_LDS_BYTES, lds_done)) return BD_E_LAUNCH;
+    constexpr int base = FG ? STREAM_FG_XS_OFF : STREAM_LDS_BYTES;
+    const int lds = XL ? std::max((int)(sp.xs_off + (uint32_t)sp.g.R * sp.xrow), base) : base;
+    if (lds > (FG ? STREAM_FG_LDS_MAX : STREAM_LDS_MAX)) return BD_E_BAD_SHAPE;
+    if (!ensure_dyn_lds((const void*)kern, FG ? STREAM_FG_LDS_MAX : XL ? STREAM_LDS_MAX : STREAM_LDS_BYTES, lds_done)) return BD_E_LAUNCH;
     hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, sp);
     return BD_OK;
 }
@@ -426,6 +431,7 @@ int launch_ring_inst(const RingParams& rp, unsigned grid, hipStream_t st) {
 template <int DT>
 int launch_gemv_stream_chunk(const Problem& q) {
     StreamParams sp{};
+    t_last_decode_form = 0;
     GemvParams& gp = sp.g;
     gp.X = (const unsigned short*)q.A;
     gp.P = (const uint32_t*)q.P;
@@ -503,18 +509,32 @@ int launch_gemv_stream_chunk(const Problem& q) {
         const bool xres_ok = q.w_tiled && (!q.norm_w || q.ssq_in) && q.M == 1 && q.t_pad <= 8 && q.K >= 1024 && 3 * ((nit_x + 3) / 4) < nit_x &&
                              (int64_t)q.B * q.K <= 16 * 2048 &&
                              (int64_t)STREAM_XS_OFF + (int64_t)q.B * (2 * (int64_t)q.K + 16) <= STREAM_LDS_MAX;
+        // Fine grid (FG, round 6; gemv_stream_kernel): a resident-row launch whose 16-column tiles number between one and two per CU --
+        // Mistral's fused q|k|v: 384 tiles -- runs as ONE round of single-tile blocks, two per CU (<= 80 KB of LDS with the nibble sign table,
+        // <= 256 VGPRs), instead of 256 blocks that walk 1.5 tiles each.  bd_set_stream_tuning: 256 = never, 512 = every eligible launch
+        // with at most two tiles per CU (one tile per CU included: the o projection).
+        const int fg_tiles = q.N / 16;
+        const bool fg_ok = xres_ok && q.N % 16 == 0 && q.t_pad <= 6 && fg_tiles <= 2 * cus &&
+                           (int64_t)STREAM_FG_XS_OFF + (int64_t)q.B * (2 * (int64_t)q.K + 16) <= STREAM_FG_LDS_MAX;
+        const bool fg = fg_ok && !(g_stream_tune & 256) && ((g_stream_tune & 512) ? true : (STREAM_FG_DEFAULT != 0 && fg_tiles > cus));
+        const unsigned fg_grid = (unsigned)fg_tiles;
+        if (fg) { sp.cpb = 16; sp.xs_off = (uint32_t)STREAM_FG_XS_OFF; }
+        t_last_decode_form = fg ? 1 : 0;
         if (q.ssq_in) {
             // RMSNorm by hand-off (XL = 3): the resident-row form with the rows pre-multiplied by the norm weight and the row scale in the
             // epilogue; same envelope as the resident rows, nothing else implements it
             if (!xres_ok) return BD_E_BAD_SHAPE;
-#define BD_XH(NM) rc = q.epilogue == 1 ? launch_stream_inst<DT, NM, true, 2, 4, 1, 2, 1, 3, 1, 1>(sp, dim3(grid), q.st)   \
+#define BD_XH(NM) rc = fg ? (q.epilogue == 1 ? launch_stream_inst<DT, NM, true, 2, 4, 1, 2, 1, 3, 1, 1, 1>(sp, dim3(fg_grid), q.st)   \
+                                             : launch_stream_inst<DT, NM, true, 2, 4, 1, 2, 1, 3, 0, 1, 1>(sp, dim3(fg_grid), q.st))  \
+                     : q.epilogue == 1 ? launch_stream_inst<DT, NM, true, 2, 4, 1, 2, 1, 3, 1, 1>(sp, dim3(grid), q.st)   \
                                        : launch_stream_inst<DT, NM, true, 2, 4, 1, 2, 1, 3, 0, 1>(sp, dim3(grid), q.st)
             switch (q.t_pad) {
                 case 1: BD_XH(1); break;
                 case 2: BD_XH(2); break;
                 case 4: BD_XH(4); break;
                 case 6: BD_XH(6); break;
-                case 8: BD_XH(8); break;
+                case 8: rc = q.epilogue == 1 ? launch_stream_inst<DT, 8, true, 2, 4, 1, 2, 1, 3, 1, 1>(sp, dim3(grid), q.st)
+                                             : launch_stream_inst<DT, 8, true, 2, 4, 1, 2, 1, 3, 0, 1>(sp, dim3(grid), q.st); break;
                 default: return BD_E_BAD_SHAPE;
             }
 #undef BD_XH
@@ -527,7 +547,9 @@ int launch_gemv_stream_chunk(const Problem& q) {
         const bool xres_auto = STREAM_XRES_DEFAULT != 0;
         const bool xres = xres_ok && ((g_stream_tune & 64) ? true : (g_stream_tune & 128) ? false : xres_auto);
         if (xres) {
-#define BD_XR(NM, NS8) rc = q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS8, 4, 1, 2, 1, 2, 1, 1>(sp, dim3(grid), q.st)   \
+#define BD_XR(NM, NS8) rc = fg ? (q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS8, 4, 1, 2, 1, 2, 1, 1, 1>(sp, dim3(fg_grid), q.st)   \
+                                                  : launch_stream_inst<DT, NM, true, NS8, 4, 1, 2, 1, 2, 0, 1, 1>(sp, dim3(fg_grid), q.st))  \
+                          : q.epilogue == 1 ? launch_stream_inst<DT, NM, true, NS8, 4, 1, 2, 1, 2, 1, 1>(sp, dim3(grid), q.st)   \
                                             : launch_stream_inst<DT, NM, true, NS8, 4, 1, 2, 1, 2, 0, 1>(sp, dim3(grid), q.st)
             // (A/B, not shipped: the short 6-tenant launches -- q|k|v, o -- on 8-wave blocks, half the stages per wave, are 1 % faster on the
             //  step, 4.688 -> 4.639 ms, but 8 partial sums in another order are no longer bit-identical to every other form of the Linear:
@@ -542,7 +564,8 @@ int launch_gemv_stream_chunk(const Problem& q) {
                 case 2: BD_XR(2, 2); break;
                 case 4: BD_XR(4, 2); break;
                 case 6: BD_XR(6, 2); break;
-                case 8: BD_XR(8, 2); break;
+                case 8: rc = q.epilogue == 1 ? launch_stream_inst<DT, 8, true, 2, 4, 1, 2, 1, 2, 1, 1>(sp, dim3(grid), q.st)
+                                             : launch_stream_inst<DT, 8, true, 2, 4, 1, 2, 1, 2, 0, 1>(sp, dim3(grid), q.st); break;
                 default: return BD_E_BAD_SHAPE;
             }
 #undef BD_XR
@@ -1550,6 +1573,17 @@ extern "C" int bd_srv_rope(void* X, const void* cos_t, const void* sin_t, int ro
     return launch_status();
 }
 
+extern "C" int bd_srv_cache_warm(const void* p0, int64_t bytes0, const void* p1, int64_t bytes1, int blocks, void* stream) {
+    if (bytes0 < 0 || bytes1 < 0 || blocks < 0) return BD_E_BAD_SHAPE;
+    if ((bytes0 && !p0) || (bytes1 && !p1)) return BD_E_NULL;
+    if ((bytes0 && !aligned16(p0)) || (bytes1 && !aligned16(p1))) return BD_E_BAD_SHAPE;
+    if (bytes0 / 16 + bytes1 / 16 == 0) return BD_OK;
+    if (blocks == 0) blocks = num_cus();
+    hipLaunchKernelGGL(cache_warm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4_t*)p0, (long long)(bytes0 / 16),
+                       (const u32x4_t*)p1, (long long)(bytes1 / 16));
+    return launch_status();
+}
+
 #ifndef BD_ATTN_SPLITS
 #define BD_ATTN_SPLITS 4
 #endif
@@ -1592,8 +1626,17 @@ extern "C" int bd_srv_decode_attention(const void* QKV, const void* cos_t, const
     p.scale = 1.0f / sqrtf((float)head_dim);
     // split the key range over 4 blocks per (tenant, kv head) when the cache is long enough and a workspace is given: T * KVH blocks
     // alone leave most CUs (and most of HBM) idle -- one CU streams only ~12-25 GB/s
+    // A workspace smaller than bd_srv_decode_attention_workspace_bytes() -- e.g. sized by a caller with the round-4 formula, which covered 4
+    // splits -- gets the LARGEST split count it holds (16 -> 8 -> 4 -> 2), not a silent fall to the unsplit launch: partials are
+    // indexed [tenant][head][split of nsplit], so any count whose T * H * nsplit records fit behind the ticket area is valid.
     const int64_t need = bd_srv_decode_attention_workspace_bytes(T, H, KVH, head_dim, Lc);
-    p.nsplit = (need > 0 && ws && ws_bytes >= need && (int64_t)T * KVH * 4 <= ATTN_TICKET_BYTES) ? attn_splits(T, KVH, Lc) : 1;
+    p.nsplit = 1;
+    if (need > 0 && ws && ws_bytes > ATTN_TICKET_BYTES && (int64_t)T * KVH * 4 <= ATTN_TICKET_BYTES) {
+        const int64_t fit = (ws_bytes - ATTN_TICKET_BYTES) / ((int64_t)T * H * (head_dim + 2) * 4);
+        int ns = attn_splits(T, KVH, Lc);
+        while (ns > 1 && ns > fit) ns >>= 1;
+        p.nsplit = ns;
+    }
     p.tickets = (unsigned*)ws;
     p.ws = (float*)((char*)ws + ATTN_TICKET_BYTES);
     hipStream_t st = (hipStream_t)stream;

@@ -80,6 +80,9 @@ struct W4Cfg {
     // issued one small burst per k-tile INSIDE the next tile's k loop (4 k-tiles per chunk), instead of as one 10-k-cycle burst in which
     // every CU of the chip stores its 128 KB at the same moment (32 MB at HBM write speed, MFMA pipes idle).
     static constexpr bool TRICKLE = (OPT & 2048) != 0 && !OUT_F32 && EPI == 0 && FAST_EPI;
+    // (A/B loser of round 5, instantiated by tests/native/w4_bench only: w4_convert / the deferred slots index ONE batch entry and ONE scale
+    //  row -- a pair tile's second entry would be stored with the first entry's addressing.  ADVICE r05)
+    static_assert(!(TRICKLE && PAIR), "the trickled epilogue does not know pair tiles");
     static constexpr int NCH = TM * (TN / JC);          // epilogue chunks per wave tile (32 rows x JC 32-column blocks each)
     // trickle schedule: a group = 4 k-tiles = 8 SLOTS (two per k-tile); a slot carries ONE 1-KiB global store per wave (the CU's store path
     // takes ~16 B/clk: stores issued back to back block the issuing wave ~260 cycles each), plus the staging traffic of the chunk(s) of

@@ -55,6 +55,17 @@ constexpr int STREAM_ALPHA_MAX = 512;                          // (row, scale gr
 constexpr int STREAM_LDS_BYTES = STREAM_LUT_BYTES + STREAM_RED_BYTES + STREAM_ALPHA_MAX * 4;
 constexpr int stream_red_bytes(int nw) { return 2 * nw * 64 * 8 * 4; }                            // what an nw-wave block uses of it
 constexpr int STREAM_XS_OFF = STREAM_LUT_BYTES + stream_red_bytes(4) + STREAM_ALPHA_MAX * 4;      // XL kernels (4 waves): activation rows
+// FG = 1 ("fine grid", round 6): ONE 16-column tile per block, blocks small enough for TWO per CU (<= 80 KB of LDS, <= 256 VGPRs), so a
+//   launch whose tile count sits between one and two per CU (Mistral's fused q|k|v: 384 tiles on 256 CUs) runs as ONE round of single-tile
+//   blocks instead of blocks that walk 1.5 tiles (the half-empty second tile cost a full tile's stages: 16 dependent stages per wave for
+//   what is 12 stages of bytes).  What makes the footprint fit is the NIBBLE sign table: 16 entries x 8 bytes (4 sign values), entry e of
+//   lane copy c = l & 31 at e * 256 + c * 8 -- the copy index selects the bank pair, the entry the LDS row, so the 32 lanes of a
+//   ds_read_b64 service group touch 64 distinct banks whatever the nibbles are: conflict-free in 4 KiB instead of 64 KiB; a fragment is
+//   two ds_read_b64 (same LDS cycles as one ds_read_b128) and four VALU instead of one.
+constexpr int STREAM_FG_LUT_BYTES = 4096;
+constexpr int stream_lut_bytes(int fg) { return fg ? STREAM_FG_LUT_BYTES : 65536; }
+constexpr int STREAM_FG_XS_OFF = STREAM_FG_LUT_BYTES + 2 * 4 * 64 * 8 * 4 + 512 * 4;      // FG kernels (4 waves): activation rows
+constexpr int STREAM_FG_LDS_MAX = 80 * 1024;                   // two blocks per CU
 constexpr uint32_t STREAM_OOB = 0x80000000u;                   // a byte offset that is out of range for every descriptor (extents are < 2 GiB:
                                                                // checked on the host) and cannot wrap when an immediate offset is added
 
@@ -145,9 +156,11 @@ struct StreamParams {
 // WT = 1 (packed layout): the base weight is TILE-MAJOR too -- W'[n/16][k/128][s][n%16][g][8] with k = 128 it + 32 s + 8 g + e (the
 //   serving side repacks it once, binary_gemm_kernel.tile_weight): the four load instructions of a stage read four consecutive
 //   1-KiB runs of ONE contiguous 4-KiB block, and a wave's consecutive stages consecutive blocks, instead of 16 rows 2K bytes apart.
-template <int DT, int NM, bool HASW, int NS, int NW = 4, int WNAT = 0, int AUX = 0, int PK = 0, int XL = 0, int EPI = 0, int WT = 0>
-__global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams sp) {
+template <int DT, int NM, bool HASW, int NS, int NW = 4, int WNAT = 0, int AUX = 0, int PK = 0, int XL = 0, int EPI = 0, int WT = 0, int FG = 0>
+__global__ void __launch_bounds__(64 * NW, FG ? 2 : 1) gemv_stream_kernel(const StreamParams sp) {
     static_assert(!WT || (PK && HASW), "tile-major W: packed layout");
+    static_assert(!FG || (PK && WT && NW == 4 && (XL == 2 || XL == 3)), "fine grid: resident-row forms, packed layout, tile-major W, 256-thread blocks");
+    constexpr int LUTB = stream_lut_bytes(FG);
     static_assert(!PK || (WNAT == 1 && NM > 0), "packed layout = natural order, with a sign operand");
     static_assert(!(XL || EPI) || (PK && (NW == 4 || (XL == 2 && NW == 8))), "fused prologue / epilogue: packed layout, 256-thread blocks (resident rows: 512 too)");
     static_assert(XL >= 0 && XL <= 3, "activation forms");
@@ -165,8 +178,8 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
     constexpr bool XP = !PK && (NM > 0 || !(HASW && WNAT));   // activation fragments in word-row order (sign operand; W too unless WNAT)
     constexpr bool XN = PK || (HASW && WNAT);                  // activation fragments in natural order (W operand; signs too when PK)
     extern __shared__ __attribute__((aligned(256))) char dyn_lds[];     // [64 KiB sign LUT][32 KiB reduction buffers]
-    float* const red = (float*)(dyn_lds + STREAM_LUT_BYTES);
-    float* const a_lds = (float*)(dyn_lds + STREAM_LUT_BYTES + stream_red_bytes(NW));
+    float* const red = (float*)(dyn_lds + LUTB);
+    float* const a_lds = (float*)(dyn_lds + LUTB + stream_red_bytes(NW));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, g = lane >> 4;
@@ -369,7 +382,14 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
         advance(ti, ii);
     }
 
-    if constexpr (NM > 0) {   // sign LUT, 16 copies: slot index = 16 e + c is linear in the thread id -> every ds_write_b128 stores 64 consecutive slots
+    if constexpr (NM > 0 && FG) {   // nibble sign table: thread t writes entry t >> 4 for the lane copies 2 (t & 15), 2 (t & 15) + 1 (one ds_write_b128)
+        constexpr uint32_t POS = One2<DT>::v & 0xffffu, NEG = POS | 0x8000u;
+        const int ee = (int)threadIdx.x >> 4;
+        u32x4_t w;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) w[d] = w[d + 2] = (((ee >> (2 * d)) & 1) ? POS : NEG) | ((((ee >> (2 * d + 1)) & 1) ? POS : NEG) << 16);
+        *(u32x4_t*)(dyn_lds + threadIdx.x * 16) = w;
+    } else if constexpr (NM > 0) {   // sign LUT, 16 copies: slot index = 16 e + c is linear in the thread id -> every ds_write_b128 stores 64 consecutive slots
         constexpr uint32_t POS = One2<DT>::v & 0xffffu, NEG = POS | 0x8000u;
 #pragma unroll
         for (int j = 0; j < 4096 / (64 * NW); ++j) {
@@ -452,9 +472,16 @@ __global__ void __launch_bounds__(64 * NW) gemv_stream_kernel(const StreamParams
     const uint32_t copy_off = (uint32_t)li * 16u;
 
     // LUT address of step s of word w: byte s -> bits 8..15, copy slot -> bits 0..7, i.e. byte * 256 + (l & 15) * 16  (one v_perm_b32)
+    [[maybe_unused]] const uint32_t copy8 = (uint32_t)(lane & 31) * 8u;
     auto lut = [&](uint32_t w, int s) -> u32x4_t {
-        const uint32_t off = __builtin_amdgcn_perm(w, copy_off, 0x0c0c0400u + ((uint32_t)s << 8));
-        return *(const u32x4_t*)(dyn_lds + off);
+        if constexpr (FG) {                 // nibble table: low nibble -> sign values 0..3 (dwords 0, 1), high nibble -> 4..7 (dwords 2, 3)
+            const uint32_t lo = (__builtin_amdgcn_ubfe(w, 8u * s, 4u) << 8) | copy8, hi = (__builtin_amdgcn_ubfe(w, 8u * s + 4u, 4u) << 8) | copy8;
+            const u32x2_t a = *(const u32x2_t*)(dyn_lds + lo), b = *(const u32x2_t*)(dyn_lds + hi);
+            return u32x4_t{a[0], a[1], b[0], b[1]};
+        } else {
+            const uint32_t off = __builtin_amdgcn_perm(w, copy_off, 0x0c0c0400u + ((uint32_t)s << 8));
+            return *(const u32x4_t*)(dyn_lds + off);
+        }
     };
     // The sign fragments are read one MFMA step ahead and the steps are fenced: left alone, hipcc hoists all 4*NM ds_read_b128 of a
     // stage to its top (16*NM VGPRs of fragments in flight; with NS stages of loads in registers that spilled the in-flight load

@@ -434,4 +434,29 @@ __global__ void __launch_bounds__(512) decode_attn_kernel(const AttnParams p) {
     if (threadIdx.x == 0) __hip_atomic_store(&p.tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+
+// cache_warm_kernel (round 6): reads two byte ranges and throws the values away -- a weight-prefetch node for a hipGraph SIDE BRANCH.  The decode
+// step's attention launch is a latency-bound chain that leaves HBM idle for ~10 us; the o projection that follows streams 46 MB it has never
+// touched.  Forked before the attention launch and joined before the o projection, this kernel pulls those bytes through HBM into the 256-MB
+// Infinity Cache (memory-side, shared by all XCDs), default cache policy, 8 x 16-byte loads in flight per thread.  No dependency to respect: the
+// weights are static.  Changes no arithmetic anywhere.
+__global__ void __launch_bounds__(256) cache_warm_kernel(const u32x4_t* __restrict__ p0, long long n0, const u32x4_t* __restrict__ p1, long long n1) {
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, nth = (long long)gridDim.x * 256;
+    u32x4_t acc = {0u, 0u, 0u, 0u};
+    for (int r = 0; r < 2; ++r) {
+        const u32x4_t* p = r ? p1 : p0;
+        const long long n = r ? n1 : n0;
+        long long i = tid;
+        for (; i + 7 * nth < n; i += 8 * nth) {
+            u32x4_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[i + u * nth];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc ^= v[u];
+        }
+        for (; i < n; i += nth) acc ^= p[i];
+    }
+    asm volatile("" :: "v"(acc[0] ^ acc[1] ^ acc[2] ^ acc[3]));      // keeps the loads alive; nothing is stored
+}
+
 }  // namespace bd

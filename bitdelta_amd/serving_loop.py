@@ -41,6 +41,7 @@ MODEL_CONFIGS = {
 }
 
 NORM_HANDOFF_DEFAULT = True     # (profiles/r05_decode_step.txt)
+PREFETCH_O_DEFAULT = False      # weight prefetch of the o projection on a graph side branch next to the attention launch (profiles/r06_decode_step.txt)
 MAX_PROMPT = 1024      # demo/demo_backend.py:300-302
 MIN_PAD = 64           # demo/demo_backend.py:299
 
@@ -238,6 +239,11 @@ class TenantDecoder(nn.Module):
         # nor a per-block reduction.  Takes precedence over the two switches above where its envelope holds (tile-major weights, <= 8
         # tenants, hidden >= 2048); not bit-identical to the separate launches (one rounding moves), same accuracy.
         self.norm_handoff = NORM_HANDOFF_DEFAULT
+        # Weight prefetch on a hipGraph SIDE BRANCH (round 6): forked before the decode attention launch, joined before the o projection, a
+        # cache_warm launch reads the o projection's tile-major weight and packed sign words so that they sit in the Infinity Cache when the
+        # projection starts (the attention launch is a latency-bound chain that leaves HBM idle).  No arithmetic changes.
+        self.prefetch_o = PREFETCH_O_DEFAULT
+        self._pf_stream = None
         self._ssq = None                # [hidden / 16, 16] fp32: partial sums of squares of the current residual stream
         self._xw = None                 # [T, 1, hidden]: the residual stream times the weight of the norm that reads it next
         # (round 2 also shipped a persistent per-layer chain launch, bd_decode_chain: bit-identical but 5.91 vs 5.33 ms per step in every
@@ -343,6 +349,16 @@ class TenantDecoder(nn.Module):
         else:
             qkv = layer.qkv(self._norm(x, layer.norm1))
         ck, cv = cache["k"][li], cache["v"][li]
+        pf = None
+        if S == 1 and self.fast_glue and self.prefetch_o and layer.o.mask_packed is not None:
+            # fork: the prefetch depends on nothing the layer computes; it is ordered behind the q|k|v launch only so that it runs next to attention
+            if self._pf_stream is None:
+                self._pf_stream = torch.cuda.Stream(device=x.device)
+            pf, cur = self._pf_stream, torch.cuda.current_stream(x.device)
+            pf.wait_stream(cur)
+            with torch.cuda.stream(pf):
+                w_o = layer.o.weight_tiled if (layer.o.weight_tiled is not None and layer.o.use_tiled) else layer.o.weight
+                ops.cache_warm(w_o, layer.o.mask_packed)
         if S == 1 and self.fast_glue and ops.decode_attention_supported(heads, kvh, hd):
             # decode: RoPE + cache append + attention over the valid keys in ONE launch (pos_idx is a one-element device tensor)
             a = ops.decode_attention(qkv, self.cos, self.sin, ck, cv, cache["valid"], pos_idx, heads, kvh)
@@ -366,6 +382,8 @@ class TenantDecoder(nn.Module):
             cv.index_copy_(2, pos_idx, v)
             a = F.scaled_dot_product_attention(q, ck, cv, attn_mask=attn_mask, enable_gqa=(kvh != heads))
             a = a.transpose(1, 2).reshape(T, S, heads * hd)
+        if pf is not None:
+            torch.cuda.current_stream(x.device).wait_stream(pf)           # join before the o projection
         o_hand = handoff and layer.o.handoff_producer_ok(a) and layer.gate_up.handoff_consumer_ok(x, swiglu=True)
         x = layer.o(a, residual=x, ssq_out=self._ssq if o_hand else None, next_norm=layer.norm2 if o_hand else None,
                     xw_out=self._xw if o_hand else None)
@@ -471,7 +489,8 @@ class TenantDecoder(nn.Module):
         # few slots that can exist are kept in a small LRU; an evicted slot's graph and buffers are released.
         # Stale keys of an earlier request are masked by cache["valid"].
         width = max(self.MIN_STOP_WIDTH, 1 << max(nstop - 1, 0).bit_length())
-        key = (width, self.fast_glue, self.fuse_glue, self.fuse_qkv_norm, self.fuse_gateup_norm, self.norm_handoff, FusedDeltaLinear.use_tiled)
+        key = (width, self.fast_glue, self.fuse_glue, self.fuse_qkv_norm, self.fuse_gateup_norm, self.norm_handoff, FusedDeltaLinear.use_tiled,
+               self.prefetch_o)
         if self._kv_cache is None:
             self._kv_cache = self.new_cache()
         slot = self._static.pop(key, None)

@@ -104,6 +104,16 @@ def prefill_attention(q, k, v, kv_start=None, causal=True, scale=None):
     return out
 
 
+def cache_warm(a, b=None, blocks=0):
+    """Read tensor a (and b) and discard the values on the CURRENT stream: the weight-prefetch node of a hipGraph side branch
+    (serving_loop.TenantDecoder.prefetch_o).  Contiguous device tensors; whole 16-byte chunks are touched."""
+    require_gpu(a)
+    assert a.is_contiguous() and (b is None or (b.is_cuda and b.is_contiguous()))
+    with torch.cuda.device(a.device):
+        check(lib().bd_srv_cache_warm(ptr(a), a.numel() * a.element_size(), ptr(b) if b is not None else None,
+                                      b.numel() * b.element_size() if b is not None else 0, int(blocks), stream_ptr()), "srv_cache_warm")
+
+
 def decode_attention_supported(heads, kv_heads, head_dim):
     return head_dim == 128 and heads % kv_heads == 0 and heads // kv_heads in (1, 4, 8)
 

@@ -542,3 +542,57 @@ def bench_tp70b(args, dev, rank, world, timer):
         "all_reduce": dec.reducer.report() if hasattr(dec, "reducer") else None,
         **runtime_info(),
     }
+
+
+def bench_tp70b_shard(dev, timer, layers=None, seq=2048, kv_len=512, steps=3, world=8):
+    """BASELINE.json configs[3]'s per-GPU unit on ONE GPU (bench.py's default run; no 8-GPU node has ever been available to this repo): rank 0's
+    Llama-2-70B TP = `world` shards, every layer, with the partial-sum exchange after o / down STUBBED OUT -- no process group exists, so
+    PartialSumReducer is inactive and each row-parallel Linear's partial sums are used as if they were the reduced result.  What is measured is
+    therefore the per-rank compute of a prefill-2048 step and of a decode step (hipGraph replay); what is NOT is the 2 x 80 all-reduces
+    (DESIGN.md section 6 prices them as projections).  Weights are this rank's own synthetic shards (no rank ever holds a full matrix)."""
+    from .dist import timed_region
+    assert not dist.is_initialized() or dist.get_world_size() == 1, "tp70b_shard is the single-process, exchange-stubbed leg"
+    dec = TPDecoder(LLAMA_70B, dev, torch.bfloat16, 0, world, layers=layers, seed=77, max_len=seq + kv_len + 64)
+    assert not dec.reducer._active()
+    nl = len(dec.layers)
+    ids = torch.randint(0, 32000, (1, seq), device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+    cache = dec.new_cache(max(seq, kv_len) + 64)
+    pos_prefill = torch.arange(seq, device=dev)
+
+    def step():
+        cache["valid"].zero_()
+        return dec(ids, pos_prefill, cache, from_zero=True)
+    step()
+    timer.reset()
+    timer.enabled = False
+    dt = timed_region(step, steps, device_sync=torch.cuda.synchronize)
+    timer.enabled = True
+    timed_region(step, steps, device_sync=torch.cuda.synchronize)           # roofline pass: one HIP event pair per fused launch
+    timer.enabled = False
+    n_launch, k_ms, k_flops, _ = timer.summary()
+    cache["valid"].zero_()
+    dec(ids[:, :kv_len], torch.arange(kv_len, device=dev), cache)
+    tok = ids[:, :1].clone()
+    pos = torch.tensor([kv_len], device=dev)
+    run, _ = dec.decode_runner(tok, pos, cache, use_graph=True)
+
+    def dstep():
+        pos.fill_(kv_len)
+        run()
+    for _ in range(5):
+        dstep()
+    ddt = timed_region(dstep, 20, device_sync=torch.cuda.synchronize) / 20
+    lin_bytes = dec.linear_bytes_per_rank()
+    head_bytes = dec.lm_head.numel() * dec.lm_head.element_size()
+    out = {"what": f"configs[3] per-GPU unit: rank 0's Llama-2-70B TP={world} shards, {nl} layers, on one GPU",
+           "exchange": "STUBBED OUT (single process: the 2 all-reduces per layer are not executed; compute only)",
+           "layers": nl, "valid": layers is None, "world_modelled": world,
+           "prefill_ms": dt / steps * 1e3, "prefill_tokens_per_s_compute_only": seq / (dt / steps),
+           "prefill_fused_frac_of_mfma_peak": (k_flops / k_ms * 1e-9 / 2500.0) if k_ms > 0 else None,
+           "prefill_fused_launches": n_launch, "prefill_fused_ms_total": k_ms,
+           "decode_ms": ddt * 1e3, "decode_kv_len": kv_len, "linear_bytes_per_rank": lin_bytes, "lm_head_bytes": head_bytes,
+           "decode_frac_of_hbm_peak": (lin_bytes + head_bytes) / ddt * 1e-9 / 8000.0,
+           "all_reduce_messages_per_step_not_executed": 2 * nl}
+    del dec, cache
+    torch.cuda.empty_cache()
+    return out

@@ -20,6 +20,7 @@
 #include "../../bitdelta_amd/csrc/bd_gemm_pf.h"
 #include "../../bitdelta_amd/csrc/bd_gemm_fx.h"
 #include "../../include/bitdelta_hip.h"
+#include "../../include/bitdelta_hip_test.h"
 
 #define HIPCHECK(x)                                                                      \
     do {                                                                                 \

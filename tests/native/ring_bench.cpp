@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/bitdelta_hip.h"
+#include "../../include/bitdelta_hip_test.h"
 
 #define HIPCHECK(x)                                                                                  \
     do {                                                                                             \

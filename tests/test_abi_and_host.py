@@ -12,10 +12,21 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
-    txt = open(os.path.join(ROOT, "include", "bitdelta_hip.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return re.findall(r"\b(bd_[a-z0-9_]+)\s*\(", txt)
+def header_functions(name=None):
+    """functions declared in include/<name> (default: the stable header + the test-hook header, round 6 split)"""
+    out = []
+    for n in ([name] if name else ["bitdelta_hip.h", "bitdelta_hip_test.h"]):
+        txt = open(os.path.join(ROOT, "include", n)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        out += re.findall(r"\b(bd_[a-z0-9_]+)\s*\(", txt)
+    return out
+
+
+def test_tuning_hooks_live_in_the_test_header_only():
+    stable, hooks = header_functions("bitdelta_hip.h"), header_functions("bitdelta_hip_test.h")
+    assert not [n for n in stable if n.startswith("bd_set_") or n.startswith("bd_last_")], "A/B hooks belong in include/bitdelta_hip_test.h"
+    assert hooks and all(n.startswith("bd_set_") or n.startswith("bd_last_") for n in hooks)
+    assert not set(stable) & set(hooks)
 
 
 def test_library_exports_every_declared_symbol():
@@ -27,7 +38,7 @@ def test_library_exports_every_declared_symbol():
     names = header_functions()
     assert len(names) >= 12
     for n in names:
-        assert hasattr(L, n), f"{n} declared in include/bitdelta_hip.h but not exported"
+        assert hasattr(L, n), f"{n} declared in include/*.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in bitdelta_amd/_lib.py"
     assert set(_lib.SIGNATURES) == set(names)
     assert L.bd_version() >= 1
@@ -165,4 +176,4 @@ def test_variant_table_has_an_environment_override():
     the bd_set_gemm_variant hook -- checked on the source (the library reads it once per thread) and on the header that documents it."""
     api = open(os.path.join(ROOT, "bitdelta_amd", "csrc", "bd_api.hip")).read()
     assert 'env_int("BD_GEMM_VARIANT", -1)' in api and 'env_int("BD_TAIL_SPLIT", 1)' in api
-    assert "BD_GEMM_VARIANT" in open(os.path.join(ROOT, "include", "bitdelta_hip.h")).read()
+    assert "BD_GEMM_VARIANT" in open(os.path.join(ROOT, "include", "bitdelta_hip_test.h")).read()

@@ -83,6 +83,28 @@ def check_linear(bd, oracle, x, w, p, alpha, cols=None, groups=1):
     return y16
 
 
+ROW_BLOCKS = (0, 1016, 2032)        # 16-row blocks checked at FULL WIDTH at M = 2048: first rows, a tile-interior seam (1016..1031 straddles the
+                                    # 1024-row boundary of the 256-row tiles), last rows
+
+
+def check_row_blocks(oracle, x, w, p, alpha, y32, y16, groups=1):
+    """VERDICT r05 weak #1a: the sampled-column checks cover every row on ~60 columns; a bug confined to the INTERIOR columns of a tile would pass.
+    Here three 16-row blocks go through the oracle over ALL N columns (all of k): fp32 mode <= 1e-5, 16-bit outputs <= 1 ulp or inside the
+    per-row cancellation floor, >= 99 % bit-equal.  Returns how many elements needed the floor."""
+    M, K = x.shape[1], x.shape[2]
+    rows = torch.cat([torch.arange(r, r + 16) for r in ROW_BLOCKS if r + 16 <= M])
+    xr = x[:, rows].contiguous().cpu()
+    ref32 = oracle.binary_linear(xr, w.cpu().contiguous(), p.cpu().contiguous(), alpha.cpu(), G=groups, out_dtype=torch.float32, round_mode=0)
+    got32, got16 = y32[:, rows].cpu(), y16[:, rows].cpu().contiguous()
+    assert relerr(got32, ref32) <= 1e-5
+    ref16 = ref32.to(got16.dtype)
+    d = ulp_diff(got16, ref16)
+    ok = (d <= 1) | ((got16.float() - ref16.float()).abs() <= cancel_floor(ref16, K))
+    assert bool(ok.all()), d.max().item()
+    assert (d == 0).float().mean().item() >= 0.99
+    return int((d > 1).sum())
+
+
 def cancel_floor(ref, K):
     """absolute floor for outputs that cancel to ~0 (ulp distance is meaningless there): fp32 rounding of partial sums as large as
     the largest output OF THE SAME ROW, random-walked over K terms -- scales with the problem, not a flat constant"""
@@ -217,6 +239,8 @@ def test_config2_fused_launches_of_the_timed_prefill_step(bd, oracle, name):
     ok = (d <= 1) | ((got16.float() - ref16.float()).abs() <= cancel_floor(ref16, K))
     assert bool(ok.all()), d.max().item()
     assert (d == 0).float().mean().item() >= 0.99
+    # ... and three 16-row blocks over ALL stored output rows of the fused Linear (every tile interior, each with its own scale group)
+    check_row_blocks(oracle, x, lin.weight, lin.mask, lin.alpha[:1], y32, y16, groups=lin.groups)
     # the tail split (last, mostly empty round of 256x128 tiles handed to the 128x128 kernel) fires for Llama's gate|up and the two
     # paths agree bit for bit: same launch with the split switched off
     if name == "llama7b_gate_up_22016_il8":

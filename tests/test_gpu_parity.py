@@ -637,6 +637,75 @@ def test_diff_pt_format_and_load_diff(bd, tmp_path):
         assert torch.equal(after[k].cpu().view(torch.int16), v.view(torch.int16)), k
 
 
+def _tiny_llama(transformers, gm):
+    cfg = transformers.LlamaConfig(**{k: v for k, v in gm["config"].items()
+                                      if k in ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers",
+                                               "num_attention_heads", "num_key_value_heads", "max_position_embeddings")})
+    m = transformers.LlamaForCausalLM(cfg).bfloat16()
+    m.load_state_dict(gm["base_state"])
+    return cfg, m
+
+
+def test_load_diff_takes_all_three_branches_like_the_reference(bd):
+    """G8 (tests/golden/make_golden_lowrank.py): a diff.pt with 1-bit `.mask` / `.coeff` entries, dense `.weight` replacements AND low-rank
+    `.A` / `.B` pairs -- bitdelta/diff.py:88-104.  Our load_diff (HIP merge for the 1-bit entries) on that file leaves bit for bit the weights
+    the reference's load_diff left (VERDICT r05 missing #3: the `.A/.B` branch was implemented but never executed)."""
+    transformers = pytest.importorskip("transformers")
+    import copy
+    gm = torch.load(os.path.join(GOLDEN, "tiny_llama_merged.pt"), weights_only=False)
+    g8 = torch.load(os.path.join(GOLDEN, "tiny_llama_lowrank.pt"), weights_only=False)
+    assert any(k.endswith(".A") for k in g8["diff"]) and any(k.endswith(".mask") for k in g8["diff"]) and "lm_head.weight" in g8["diff"]
+    _, base_m = _tiny_llama(transformers, gm)
+    eval_m = copy.deepcopy(base_m).half().cuda()
+    untouched = {k: v.detach().clone() for k, v in eval_m.state_dict().items() if k not in g8["after"]}
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "diff.pt")
+        torch.save(g8["diff"], path)
+        bd.load_diff(eval_m, path)
+    after = eval_m.state_dict()
+    for k, v in g8["after"].items():
+        assert after[k].dtype == v.dtype and torch.equal(after[k].cpu().view(torch.int16), v.view(torch.int16)), k
+    for k, v in untouched.items():                                   # nothing else moved
+        assert torch.equal(after[k], v), k
+    assert eval_m.config.vocab_size == eval_m.lm_head.weight.size(0)
+
+
+def test_save_full_model_writes_the_merged_checkpoint(bd, oracle, tmp_path):
+    """save_full_model (bitdelta/diff.py:108-116): base checkpoint + diff.pt -> a plain HF checkpoint + the fine-tune's tokenizer.  A tiny Llama
+    saved to disk stands in for the hub models; the reloaded checkpoint's projections equal the oracle's merge line on the bf16 base weights bit for
+    bit (G7 pins that line in bf16), every dense entry of the diff.pt replaced its tensor, and the tokenizer files are there."""
+    transformers = pytest.importorskip("transformers")
+    import json
+    gm = torch.load(os.path.join(GOLDEN, "tiny_llama_merged.pt"), weights_only=False)
+    diff = torch.load(os.path.join(GOLDEN, "tiny_llama_diff.pt"), weights_only=False)
+    _, base_m = _tiny_llama(transformers, gm)
+    base_dir, tok_dir, out_dir = tmp_path / "base", tmp_path / "tok", tmp_path / "out"
+    base_m.save_pretrained(str(base_dir))
+    tok_dir.mkdir()
+    vocab = {chr(97 + i): i for i in range(26)}
+    vocab["<|endoftext|>"] = 26
+    json.dump(vocab, open(tok_dir / "vocab.json", "w"))
+    open(tok_dir / "merges.txt", "w").write("#version: 0.2\n")
+    json.dump({"tokenizer_class": "GPT2Tokenizer", "eos_token": "<|endoftext|>", "unk_token": "<|endoftext|>", "bos_token": "<|endoftext|>"},
+              open(tok_dir / "tokenizer_config.json", "w"))
+    bd.save_full_model(str(base_dir), str(tok_dir), os.path.join(GOLDEN, "tiny_llama_diff.pt"), str(out_dir), "cuda")
+    assert (out_dir / "config.json").exists() and any(f.name.startswith("tokenizer") for f in out_dir.iterdir())
+    full = transformers.LlamaForCausalLM.from_pretrained(str(out_dir), torch_dtype=torch.bfloat16)
+    sd, n_proj = full.state_dict(), 0
+    for k, v in gm["base_state"].items():
+        mod = k.rsplit(".", 1)[0]
+        if mod + ".mask" in diff:
+            want = oracle.merge_delta(v.detach().clone().contiguous(), diff[mod + ".mask"].contiguous(), float(diff[mod + ".coeff"]))
+            assert torch.equal(sd[k].view(torch.int16), want.view(torch.int16)), k
+            n_proj += 1
+        elif k in diff:
+            assert torch.equal(sd[k], diff[k].detach().to(sd[k].dtype)), k
+        else:
+            assert torch.equal(sd[k], v), k
+    assert n_proj == 14                                              # 7 projections x 2 layers
+
+
 # ------------------------------------------------------------------ full-size properties (BASELINE configs)
 def test_full_size_linearity_and_sign_flip(bd):
     # 4096x4096 layer, M = 4096 rows: size-independent properties instead of an O(MNK) CPU reference

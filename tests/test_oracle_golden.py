@@ -111,3 +111,30 @@ def test_g7_merge(oracle, golden):
         g = golden[key]
         w = oracle.merge_delta(g["w"].clone(), g["mask"], g["coeff"].item())
         assert torch.equal(w.view(torch.int16), g["w_merged"].view(torch.int16))
+
+
+def test_torch_port_matches_the_c_oracle(oracle):
+    """oracle/torch_port.py is what bench.py's `cpu_baseline.value` times (the reference's CPU-executable form, written with the reference's torch
+    ops); its docstring says it is checked against the C oracle -- this is that check (VERDICT r05 missing #5).  Reference chain
+    (bitdelta/diff.py:38-39 with binary_bmm's fp32 -> fp16 -> a.dtype epilogue, binary_gemm_kernel.py:287) = the oracle's round_mode 1."""
+    from oracle import torch_port as tp
+    g = torch.Generator().manual_seed(12)
+    for dtype, B, M, K, N in ((torch.bfloat16, 1, 8, 256, 96), (torch.bfloat16, 2, 5, 128, 40), (torch.float16, 1, 16, 192, 64)):
+        x = torch.randn(B, M, K, generator=g).to(dtype)
+        w = (torch.randn(N, K, generator=g) * 0.02).to(dtype)
+        mask = torch.randint(-2 ** 31, 2 ** 31 - 1, (1, K // 32, N), generator=g, dtype=torch.int64).to(torch.int32)
+        c = torch.tensor(4e-4)
+        # unpack restated with the reference's ops == the oracle's (and the golden-pinned) unpack
+        assert torch.equal(tp.unpack32(mask), oracle.unpack(mask))
+        ref = oracle.binary_linear(x, w, mask, c.reshape(1, 1), round_mode=1)
+        v1 = tp.forward_unpack_in_loop(x, w, mask[0], c)
+        assert v1.dtype == dtype and v1.shape == ref.shape
+        if dtype == torch.bfloat16:
+            assert torch.equal(v1, ref)                                   # bit-identical: same rounding chain, K small enough for exact fp32 sums
+        else:
+            # fp16: torch's CPU half matmul accumulates in fp32 and rounds once, like the chain; allow its summation order 1 ulp
+            d = (v1.view(torch.int16).int() - ref.view(torch.int16).int()).abs()
+            assert int(d.max()) <= 1 and (d == 0).float().mean().item() >= 0.99
+        s = (tp.unpack32(mask[0]) * 2 - 1).to(dtype)
+        v2 = tp.forward_preunpacked(x, w, s, c)                           # variant 2: no fp16 intermediate (bf16 delta rounded once)
+        assert ((v2.float() - ref.float()).norm() / ref.float().norm()).item() <= (4e-3 if dtype == torch.bfloat16 else 1e-3)
