@@ -261,7 +261,7 @@ def handoff_ok(B, M, K):
 
 def binary_linear_decode(x, weight, mask, alpha, *, layout="tile", out_dtype=None, groups=1, residual=None,
                          norm_weight=None, eps=1e-5, swiglu=False, weight_tiled=False, out=None, ssq_in=None, ssq_out=None,
-                         xw_out=None):
+                         xw_out=None, ssq_scale=1.0):
     """binary_linear for decode shapes with repacked masks: one launch of the streaming kernel.
     x: (B, M, K), M <= 16; weight (N, K); alpha fp32 (B or 1, groups);
     layout "tile":   mask = tile_masks(...)        (B or 1, ceil(N/16), K/32, 16)
@@ -273,7 +273,8 @@ def binary_linear_decode(x, weight, mask, alpha, *, layout="tile", out_dtype=Non
     RMSNorm hand-off (bd_binary_linear_decode_handoff; packed layout, M == 1, B <= 8, tile-major weight):
       ssq_out: fp32 (N/16, 16) buffer -- the launch (a residual Linear: o_proj / down_proj) also writes its output's per-row sums of squares,
                16 columns at a time; with xw_out (B, M, N) and norm_weight = the weight of the RMSNorm that FOLLOWS, also the pre-multiplied
-               copy round(y * norm_weight);
+               copy round(y * norm_weight); ssq_scale multiplies the written sums (serving_loop.handoff_norm: norm_weight = nw / s, ssq_scale = 1 / s^2,
+               consumer eps / s^2 -- overflow-safe in fp16, same product);
       ssq_in:  the buffer the PREVIOUS launch filled -- x is that launch's xw_out, 1/rms scales the accumulators: no stand-alone norm launch,
                no per-block reduction, no multiply (`handoff_ok`); norm_weight must be None."""
     require_gpu(x, weight, mask, alpha, residual, norm_weight)
@@ -343,7 +344,9 @@ def binary_linear_decode(x, weight, mask, alpha, *, layout="tile", out_dtype=Non
             check(lib().bd_binary_linear_decode_handoff(ptr(x), ptr(weight), ptr(mask), t_pad, ptr(alpha), ptr(y), B, M, N, K,
                                                         x.stride(0), x.stride(1), ldw, sPb, sAlb, groups, y.stride(0),
                                                         y.stride(1), DTYPE_CODE[x.dtype], DTYPE_CODE[out_dtype],
-                                                        1 if residual is not None else 0, ptr(norm_weight), s_norm, float(eps),
+                                                        1 if residual is not None else 0, ptr(norm_weight), s_norm,
+                                                        # (producer launches: the eps slot carries the factor on the written sums of squares)
+                                                        float(ssq_scale) if ssq_out is not None else float(eps),
                                                         1 if swiglu else 0, ptr(ssq_in), ptr(ssq_out), ptr(xw_out), stream_ptr()),
                   "binary_linear_decode_handoff")
         return y

@@ -458,6 +458,7 @@ int launch_gemv_stream_chunk(const Problem& q) {
     sp.tp = (uint32_t)q.t_pad;
     sp.nw = (const unsigned short*)q.norm_w; sp.sNw = q.sNw; sp.eps = q.eps;
     sp.ssq_in = q.ssq_in; sp.ssq_out = q.ssq_out;
+    sp.ssq_scale = (q.ssq_out && q.eps > 0.f) ? q.eps : 1.f;      // producer launches: the `eps` slot of the entry point carries the factor (header)
     sp.nw_next = (const unsigned short*)q.nw_next; sp.sNwNext = q.sNwNext; sp.xw_out = (unsigned short*)q.xw_out;
     sp.no_res_prefetch = (g_stream_tune & 1024) ? 1 : 0;
     sp.n_bytes = q.norm_w ? (uint32_t)(((int64_t)(q.B - 1) * q.sNw + q.K) * 2) : 0u;

@@ -113,6 +113,10 @@ struct StreamParams {
     const unsigned short* nw_next;
     long long sNwNext;
     unsigned short* xw_out;
+    // ... and scale the sums of squares it writes (round 6): with nw_next = nw / s for a power of two s >= max |nw| (the host divides
+    // once; exact), xw_out = round16(x . nw / s) can never exceed |x| -- no fp16 overflow on massive-activation rows whatever the norm weight --
+    // and ssq_scale = 1 / s^2 together with eps / s^2 on the consumer makes its row scalar s . rsqrt(mean(x^2) + eps): the same product, exactly.
+    float ssq_scale;
 };
 
 // NW = waves per block (8: two per SIMD, 256 VGPRs each; 4: one per SIMD, the whole register file, deeper prefetch).
@@ -612,7 +616,7 @@ __global__ void __launch_bounds__(64 * NW, FG ? 2 : 1) gemv_stream_kernel(const 
                         // the row's 16 columns live in lanes li, li + 16, li + 32, li + 48: two fixed exchange steps, lane group 0 writes
                         sq += __shfl_xor(sq, 16, 64);
                         sq += __shfl_xor(sq, 32, 64);
-                        if (g == 0) sp.ssq_out[(long long)((c_lo >> 4) + tile) * 16 + li] = sq;
+                        if (g == 0) sp.ssq_out[(long long)((c_lo >> 4) + tile) * 16 + li] = sq * sp.ssq_scale;
                     }
                 }
             }

@@ -46,6 +46,17 @@ MAX_PROMPT = 1024      # demo/demo_backend.py:300-302
 MIN_PAD = 64           # demo/demo_backend.py:299
 
 
+def handoff_norm(nw):
+    """RMSNorm hand-off, overflow-safe form (round 6).  The producing launch stores round16(x_raw * nw) of the UN-normalised residual
+    stream; in fp16 that product could overflow on a massive-activation row with a large norm weight, where HF's order (normalise first) cannot.
+    Returns (nw / s, s) with s the power of two >= max |nw| (over every tenant): |nw / s| <= 1, so |x * nw / s| <= |x| never overflows, whatever
+    x is.  The producer is then given ssq_scale = 1 / s^2 and the consumer eps / s^2: its row scalar becomes s * rsqrt(mean(x^2) + eps), i.e. the
+    SAME product -- powers of two, so the same bits wherever the unscaled form did not overflow / underflow."""
+    m = float(nw.detach().abs().max())
+    s = 1.0 if not math.isfinite(m) or m <= 0.0 else 2.0 ** math.ceil(math.log2(m))
+    return (nw.float() / s).to(nw.dtype), s
+
+
 def padded_length(longest):
     """demo/demo_backend.py:297-299: next power of two, at least 64."""
     return max(1 << max(longest - 1, 0).bit_length(), MIN_PAD)
@@ -114,7 +125,7 @@ class FusedDeltaLinear(nn.Module):
 
     use_tiled = True              # (A/B switch)
 
-    def forward(self, x, residual=None, out_dtype=None, ssq_out=None, next_norm=None, xw_out=None, out=None):
+    def forward(self, x, residual=None, out_dtype=None, ssq_out=None, next_norm=None, xw_out=None, out=None, ssq_scale=1.0):
         """out_dtype=torch.float32: un-rounded partial sums (the row-parallel shards of tp.py reduce them across ranks).
         ssq_out (decode, with residual): RMSNorm hand-off, producer side -- the launch also leaves the per-row partial sums of squares of the
         updated residual stream for the next launch (`handoff_producer_ok`), and with next_norm [T, N] + xw_out [T, 1, N] the copy of it
@@ -123,7 +134,7 @@ class FusedDeltaLinear(nn.Module):
             w, wt = self._dec_weight(x)
             return binary_linear_decode(x, w, self.mask_packed, self.alpha, layout="packed", groups=self.groups,
                                         residual=residual, weight_tiled=wt, out_dtype=out_dtype, ssq_out=ssq_out,
-                                        norm_weight=next_norm if ssq_out is not None else None, xw_out=xw_out, out=out)
+                                        norm_weight=next_norm if ssq_out is not None else None, xw_out=xw_out, out=out, ssq_scale=ssq_scale)
         assert ssq_out is None and xw_out is None
         return binary_linear(x, self.weight, self.mask, self.alpha, groups=self.groups, residual=residual, out_dtype=out_dtype, out=out)
 
@@ -331,9 +342,18 @@ class TenantDecoder(nn.Module):
             return ops.rmsnorm_tenant(x if x.is_contiguous() else x.contiguous(), w, self.eps)
         return F.rms_norm(x, (x.shape[-1],), None, self.eps) * w[:, None, :]
 
-    def _layer(self, layer, x, cos, sin, cache, li, pos_idx, attn_mask, ssq_valid=False, next_norm1=None):
+    def _hn(self, layer, which):
+        """(nw / s, s) of a layer's norm for the hand-off (handoff_norm), computed once"""
+        key = "_hn_" + which
+        v = getattr(layer, key, None)
+        if v is None:
+            v = handoff_norm(getattr(layer, which))
+            setattr(layer, key, v)
+        return v
+
+    def _layer(self, layer, x, cos, sin, cache, li, pos_idx, attn_mask, ssq_valid=False, next_layer=None):
         """one decoder layer; returns (x, ssq_valid): whether self._ssq / self._xw hold the partial sums of squares of the returned x and its
-        copy pre-multiplied by next_norm1 (the NEXT layer's input norm weight; None after the last layer)"""
+        copy pre-multiplied by the NEXT layer's input norm weight (next_layer; None after the last layer) -- both in handoff_norm's scaled form"""
         T, S, hid = x.shape
         _, inter, _, heads, kvh, _ = self.cfg
         hd = self.hd
@@ -343,7 +363,8 @@ class TenantDecoder(nn.Module):
             self._ssq = torch.empty(hid // 16, 16, dtype=torch.float32, device=x.device)
             self._xw = torch.empty(T, 1, hid, dtype=x.dtype, device=x.device)
         if handoff and ssq_valid:
-            qkv = layer.qkv.forward_fused(self._xw, None, self.eps, ssq_in=self._ssq)    # rows already carry norm1's weight; 1/rms in the epilogue
+            s1 = self._hn(layer, "norm1")[1]
+            qkv = layer.qkv.forward_fused(self._xw, None, self.eps / (s1 * s1), ssq_in=self._ssq)    # rows already carry norm1's weight / s; s/rms in the epilogue
         elif fuse and self.fuse_qkv_norm and layer.qkv.fusable(x):
             qkv = layer.qkv.forward_fused(x, layer.norm1, self.eps)              # RMSNorm in the Linear's prologue: one launch
         else:
@@ -385,10 +406,11 @@ class TenantDecoder(nn.Module):
         if pf is not None:
             torch.cuda.current_stream(x.device).wait_stream(pf)           # join before the o projection
         o_hand = handoff and layer.o.handoff_producer_ok(a) and layer.gate_up.handoff_consumer_ok(x, swiglu=True)
-        x = layer.o(a, residual=x, ssq_out=self._ssq if o_hand else None, next_norm=layer.norm2 if o_hand else None,
-                    xw_out=self._xw if o_hand else None)
+        n2h, s2 = self._hn(layer, "norm2") if o_hand else (None, 1.0)
+        x = layer.o(a, residual=x, ssq_out=self._ssq if o_hand else None, next_norm=n2h, xw_out=self._xw if o_hand else None,
+                    ssq_scale=1.0 / (s2 * s2))
         if o_hand:
-            act = layer.gate_up.forward_fused(self._xw, None, self.eps, swiglu=True, ssq_in=self._ssq)   # (RMSNorm by hand-off) gate|up -> SwiGLU
+            act = layer.gate_up.forward_fused(self._xw, None, self.eps / (s2 * s2), swiglu=True, ssq_in=self._ssq)   # (RMSNorm by hand-off) gate|up -> SwiGLU
         elif fuse and self.fuse_gateup_norm and layer.gate_up.fusable(x, swiglu=True):
             act = layer.gate_up.forward_fused(x, layer.norm2, self.eps, swiglu=True)   # RMSNorm -> gate|up -> SwiGLU: one launch
         elif fuse and layer.gate_up.interleave8 and layer.gate_up._decode_ok(x):
@@ -403,9 +425,10 @@ class TenantDecoder(nn.Module):
             else:
                 g, u = layer.gate_up.split(gu)
                 act = F.silu(g) * u
-        d_hand = handoff and next_norm1 is not None and layer.down.handoff_producer_ok(act) and layer.qkv.handoff_consumer_ok(x)
-        x = layer.down(act, residual=x, ssq_out=self._ssq if d_hand else None, next_norm=next_norm1 if d_hand else None,
-                       xw_out=self._xw if d_hand else None)
+        d_hand = handoff and next_layer is not None and layer.down.handoff_producer_ok(act) and layer.qkv.handoff_consumer_ok(x)
+        n1h, s1n = self._hn(next_layer, "norm1") if d_hand else (None, 1.0)
+        x = layer.down(act, residual=x, ssq_out=self._ssq if d_hand else None, next_norm=n1h, xw_out=self._xw if d_hand else None,
+                       ssq_scale=1.0 / (s1n * s1n))
         return x, d_hand
 
     @torch.no_grad()
@@ -418,7 +441,7 @@ class TenantDecoder(nn.Module):
         x = self.embed[t_idx, ids]                                            # per-tenant embedding: one gather
         ssq_valid = False                                                     # (the embedding rows have no producer launch: layer 0 norms itself)
         for li, layer in enumerate(self.layers):
-            nxt = self.layers[li + 1].norm1 if li + 1 < len(self.layers) else None
+            nxt = self.layers[li + 1] if li + 1 < len(self.layers) else None
             x, ssq_valid = self._layer(layer, x, cos, sin, cache, li, pos_idx, attn_mask, ssq_valid, nxt)
         last = self._norm(x[:, -1:, :], self.final_norm)
         return tenant_linear(last, self.lm_head)[:, 0, :]                     # per-tenant lm_head: one launch

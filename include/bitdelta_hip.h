@@ -142,7 +142,10 @@ int bd_binary_linear_decode_fused(const void* X, const void* W, const int32_t* P
  *     scale moved across the contraction (one rounding of x * norm_w instead of two; not bit-identical to the separate bd_srv_rmsnorm launch,
  *     same accuracy).
  *   Needs the tile-major base weight (ldw = 0) on the consumer, K >= 1024, B * K <= 32768.  Both stand-alone rmsnorm launches of a layer
- *   disappear without any block re-reducing or re-normalising the rows.  BD_E_BAD_SHAPE outside the envelope (no fallback). */
+ *   disappear without any block re-reducing or re-normalising the rows.  BD_E_BAD_SHAPE outside the envelope (no fallback).  *   PRODUCER launches (ssq_out != NULL) do not normalise anything: there the `eps` argument is the FACTOR the written sums of squares are
+ *   multiplied by (<= 0: 1).  Intended use (round 6): pass norm_w = nw / s with s a power of two >= max |nw| and eps = 1 / s^2, and give the consumer
+ *   eps / s^2 -- xw_out = round16(x . nw / s) then never exceeds |x| (no fp16 overflow whatever the norm weight), and the consumer's row scalar
+ *   becomes s . rsqrt(mean(x^2) + eps): the same product exactly (bitdelta_amd.serving_loop.handoff_norm). */
 int bd_binary_linear_decode_handoff(const void* X, const void* W, const int32_t* P, int t_pad, const float* alpha, void* Y,
                                     int B, int M, int N, int K,
                                     int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb, int64_t sAlb, int G,

@@ -1038,6 +1038,7 @@ def test_fine_grid_decode_form_is_bit_identical(bd, oracle, dtype, T, K, N):
     res = torch.randn(T, 1, N, device="cuda", generator=g).to(dtype)
     nw = (1 + 0.1 * torch.randn(T, N, device="cuda", generator=g)).to(dtype)
     pk, wt = pack_decode_masks(mask), tile_weight(w)
+    sin = torch.rand(K // 16, 16, device="cuda", generator=g) * 8 + 1          # "partial sums of squares" of the hand-off consumer launches
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from canary import CanaryOut                         # poisoned margins around an output: a store outside [T, 1, N] is caught
     outs = {}
@@ -1059,7 +1060,6 @@ def test_fine_grid_decode_form_is_bit_identical(bd, oracle, dtype, T, K, N):
             o["prod"] = binary_linear_decode(x, wt, pk, a1, layout="packed", weight_tiled=True, residual=res.clone(), ssq_out=ssq, norm_weight=nw, xw_out=xw)
             o["ssq"], o["xw"] = ssq, xw
             if K % 16 == 0 and T <= 8 and K >= 2048:
-                sin = torch.rand(K // 16, 16, device="cuda", generator=g) * 8 + 1
                 o["cons"] = binary_linear_decode(x, wt, pk, a1, layout="packed", weight_tiled=True, ssq_in=sin, eps=1e-5)
                 o["cons_sw"] = binary_linear_decode(x, wt, pk, alpha, layout="packed", groups=2, swiglu=True, weight_tiled=True, ssq_in=sin, eps=1e-5)
             outs[flag] = o
@@ -1076,11 +1076,14 @@ def test_fine_grid_decode_form_is_bit_identical(bd, oracle, dtype, T, K, N):
 @pytest.mark.parametrize("row_scale,nw_scale", [(1e-3, 0.02), (1e-3, 5.0), (1.0, 0.02), (1e3, 0.02), (1e3, 5.0), (30.0, 1.0)])
 def test_rmsnorm_handoff_activation_range(bd, dtype, row_scale, nw_scale):
     """the hand-off stores round16(x_raw * norm_w) of the UN-normalised residual stream, where HF normalises first -- in fp16
-    that product could overflow on massive-activation rows or go subnormal on small rows.  Residual rows scaled by 1e-3 ... 1e+3 (plus a row with
-    ONE massive element, as real Llama / Mistral checkpoints have) and norm weights of about 0.02 ... 5: the hand-off launch pair must stay
-    finite and as accurate against the dense fp32 evaluation as the separate RMSNorm + Linear launches."""
+    that product can overflow on a massive-activation row with a large norm weight (row scale 1e3, weights ~5: 2e3 * 5 * 4 sigma > 65504) or go
+    subnormal on small rows.  serving_loop.handoff_norm removes the overflow by construction (norm weight / s with s = 2^k >= max |nw|, so
+    |xw| <= |x|; 1 / s^2 on the producer's sums of squares and eps / s^2 on the consumer give the same product).  Residual rows scaled by
+    1e-3 ... 1e+3, one massive element per row set (as real Llama / Mistral checkpoints have), norm weights of about 0.02 ... 5: the launch pair
+    stays finite and as accurate against the dense fp32 evaluation as the separate RMSNorm + Linear launches; the UNSCALED protocol does overflow
+    in the (1e3, 5) fp16 case, which is what the scaled one is for."""
     from bitdelta_amd import serving_ops as ops
-    from bitdelta_amd.serving_loop import FusedDeltaLinear
+    from bitdelta_amd.serving_loop import FusedDeltaLinear, handoff_norm
     T, hid, N2, K1 = 6, 4096, 6144, 2048
     g = torch.Generator(device="cuda").manual_seed(int(row_scale * 1000) + int(nw_scale * 100) + 7)
 
@@ -1091,13 +1094,17 @@ def test_rmsnorm_handoff_activation_range(bd, dtype, row_scale, nw_scale):
     prod, cons = lin(hid, K1), lin(N2, hid)
     a = (torch.randn(T, 1, K1, device="cuda", generator=g) * min(row_scale, 1.0)).to(dtype)
     resid = torch.randn(T, 1, hid, device="cuda", generator=g) * 2.0 * row_scale
-    resid[0, 0, 1415] = 60.0 * 2.0 * row_scale                       # one massive element (Llama-2-7B: dims 1415 / 2533 sit ~50-100 sigma out)
+    resid[0, 0, 1415] = min(60.0 * 2.0 * row_scale, 3.0e4)           # one massive element (Llama-2-7B: dims 1415 / 2533 sit 50-100 sigma out)
     resid = resid.to(dtype)
+    assert torch.isfinite(resid.float()).all()
     nw = (nw_scale * (1 + 0.3 * torch.randn(T, hid, device="cuda", generator=g))).to(dtype)
+    nwh, s = handoff_norm(nw)
+    assert float(nwh.float().abs().max()) <= 1.0 and s >= float(nw.float().abs().max()) and torch.equal((nwh.float() * s).to(dtype), nw)
     ssq = torch.zeros(hid // 16, 16, device="cuda")
     xw = torch.zeros(T, 1, hid, device="cuda", dtype=dtype)
-    x = prod(a, residual=resid.clone(), ssq_out=ssq, next_norm=nw, xw_out=xw)
-    got = cons.forward_fused(xw, None, 1e-5, ssq_in=ssq)
+    x = prod(a, residual=resid.clone(), ssq_out=ssq, next_norm=nwh, xw_out=xw, ssq_scale=1.0 / (s * s))
+    assert bool((xw.float().abs() <= x.float().abs()).all())         # |nw / s| <= 1: the pre-multiplied copy never exceeds the stream itself
+    got = cons.forward_fused(xw, None, 1e-5 / (s * s), ssq_in=ssq)
     sep = cons(ops.rmsnorm_tenant(x, nw, 1e-5))
     assert torch.isfinite(xw.float()).all() and torch.isfinite(got.float()).all() and torch.isfinite(sep.float()).all()
     S = bd.unpack(cons.mask).float() * 2 - 1
@@ -1108,6 +1115,17 @@ def test_rmsnorm_handoff_activation_range(bd, dtype, row_scale, nw_scale):
     tol = 2e-3 if dtype == torch.float16 else 1.2e-2
     assert rel(got) <= tol and rel(sep) <= tol, (rel(got), rel(sep))
     assert rel(got) <= 1.5 * rel(sep) + 2e-4, (rel(got), rel(sep))
+    # the scaled protocol is an exact reparametrisation of the unscaled one wherever that one stays in range (powers of two throughout)
+    ssq0 = torch.zeros_like(ssq)
+    xw0 = torch.zeros_like(xw)
+    prod(a, residual=resid.clone(), ssq_out=ssq0, next_norm=nw, xw_out=xw0)
+    if torch.isfinite(xw0.float()).all() and float(xw0.float().abs().min()) >= 0.0:
+        got0 = cons.forward_fused(xw0, None, 1e-5, ssq_in=ssq0)
+        normal = xw0.float().abs() >= (6.2e-5 if dtype == torch.float16 else 0.0)                  # fp16 subnormals round differently after the division
+        if bool(normal.all()) and bool((xw.float().abs() >= (6.2e-5 if dtype == torch.float16 else 0.0)).all()):
+            assert torch.equal(got0, got)
+    elif dtype == torch.float16:
+        assert row_scale >= 1e3 and nw_scale >= 5.0                  # the case the scaling exists for: the unscaled copy overflowed
 
 
 def test_norm_handoff_token_level_agreement_over_32_greedy_steps(bd):
