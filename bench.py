@@ -822,7 +822,10 @@ def main():
     detail = {"delta_gemm": mb, "vendor_gemm": vg, "mfma_ceiling": ceil, "published_shapes": published_shapes_block(dev)}
 
     def fr(x, nd=4):
-        return round(x, nd) if isinstance(x, (int, float)) else x
+        """numbers of the contract line: 4 decimals for O(1) values, 4 significant digits for small ones; bools / ints / strings untouched"""
+        if isinstance(x, bool) or not isinstance(x, float):
+            return x
+        return round(x, nd) if abs(x) >= 1e-2 or x == 0.0 else float(f"{x:.4g}")
 
     # The contract line stays SHORT (< 6 KB: the driver's record truncates long lines and keeps only `roofline` / `cpu_baseline` / `config` of the
     # non-contract keys): every figure the north star names sits inside `roofline`; the long blocks go to a "# bench detail" line printed BEFORE it.

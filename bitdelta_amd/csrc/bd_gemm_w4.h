@@ -143,6 +143,13 @@ __device__ __forceinline__ void w4_dma4_m0(uint32_t voff, const void* sbase) {
 template <class Cfg>
 __device__ __forceinline__ void w4_epilogue(const GemmParams& p, f32x16_t (&acc)[4][Cfg::TM], char* stg, int m0, int n0, int wm, int wn,
                                             int b, int lane, int wave, int b_alpha = -1) {
+    // OPT & 16384 (round 6 A/B, harness only): per-wave STAGGER of the store burst -- wave w starts its epilogue w x 64 cycles late, so that the four
+    // waves' 1-KiB stores reach the CU's store path one every ~75 cycles instead of four at once (profiles/r06_w4_cycles.txt)
+    if constexpr (Cfg::OPT & 16384) {
+        if (wave == 1) __builtin_amdgcn_s_sleep(1);
+        else if (wave == 2) __builtin_amdgcn_s_sleep(2);
+        else if (wave == 3) __builtin_amdgcn_s_sleep(3);
+    }
     constexpr int DT = Cfg::DT, WM = Cfg::WM, WN = Cfg::WN, TM = Cfg::TM, TN = Cfg::TN, JC = Cfg::JC, ESZ = Cfg::ESZ;
     constexpr int ROWB = Cfg::STG_ROWB;
     constexpr bool FUSED = Cfg::FUSED;

@@ -2,7 +2,11 @@
 // CPU softmax, event-timed launches.
 //   hipcc --offload-arch=gfx950 -O3 -I bitdelta_amd/csrc tests/native/attn_bench.hip -o tests/native/attn_bench
 //   tests/native/attn_bench [S=2048] [H=32] [KVH=32] [B=1] [causal=1] [pad=0] [iters=50]
+#ifdef KS2
+#include "ab/bd_attn_prefill_ks2.h"      // the key-split A/B kernel (round 6: measured equal or slower)
+#else
 #include "bd_attn_prefill.h"
+#endif
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -10,6 +14,13 @@
 #include <random>
 #include <vector>
 using namespace bd;
+#ifdef KS2
+#define KERN prefill_attn_ks2_kernel<DT_BF16>
+#define NTHR 512
+#else
+#define KERN prefill_attn_kernel<DT_BF16>
+#define NTHR 256
+#endif
 static float bf2f(unsigned short h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
 static unsigned short f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
@@ -48,9 +59,9 @@ int main(int argc, char** argv) {
     p.B = B; p.S = S; p.H = H; p.KVH = KVH; p.nqb = (S + 127) / 128;
     const float scale = 1.f / sqrtf((float)HD);
     p.c = scale * 1.4426950408889634f; p.causal = causal;
-    CK(hipFuncSetAttribute((const void*)prefill_attn_kernel<DT_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, PREFILL_ATTN_LDS));
+    CK(hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, PREFILL_ATTN_LDS));
     const dim3 grid(p.nqb * H * B);
-    prefill_attn_kernel<DT_BF16><<<grid, 256, PREFILL_ATTN_LDS>>>(p);
+    KERN<<<grid, NTHR, PREFILL_ATTN_LDS>>>(p);
     CK(hipDeviceSynchronize());
     std::vector<unsigned short> out((size_t)B * S * H * HD);
     CK(hipMemcpy(out.data(), dout, out.size() * 2, hipMemcpyDeviceToHost));
@@ -91,9 +102,9 @@ int main(int argc, char** argv) {
     printf("S=%d H=%d KVH=%d B=%d causal=%d pad=%d: %d sampled rows, max abs err %.3e, worst row rel-L2 %.3e, mismatches %d -> %s\n",
            S, H, KVH, B, causal, pad, nrows, worst, worst_rel, bad, bad ? "FAIL" : "ok");
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 20; ++i) prefill_attn_kernel<DT_BF16><<<grid, 256, PREFILL_ATTN_LDS>>>(p);
+    for (int i = 0; i < 20; ++i) KERN<<<grid, NTHR, PREFILL_ATTN_LDS>>>(p);
     hipEventRecord(e0);
-    for (int i = 0; i < iters; ++i) prefill_attn_kernel<DT_BF16><<<grid, 256, PREFILL_ATTN_LDS>>>(p);
+    for (int i = 0; i < iters; ++i) KERN<<<grid, NTHR, PREFILL_ATTN_LDS>>>(p);
     hipEventRecord(e1); CK(hipEventSynchronize(e1));
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double us = ms * 1e3 / iters;

@@ -184,7 +184,7 @@ int main(int argc, char** argv) {
     if (what.rfind("soak", 0) == 0) {      // soak<variant>: run one kernel back to back for `reps` x 0.1 s (power / clock sampling from outside)
         const int M = Ms[0];
         const int v = atoi(what.c_str() + (what.rfind("soakn", 0) == 0 ? 5 : 4));
-        GemmParams p0 = params(M, N, (v >= 10 && v < 20) || v == 31 || v == 33, C0);   // (fused variants: 10, 11, 12, 13)
+        GemmParams p0 = params(M, N, (v >= 10 && v < 20) || v == 31 || v == 33 || v == 35, C0);   // (fused variants: 10, 11, 12, 13)
         using OldD = GemmCfg<DT_BF16, 256, 256, 2, 4, 4, false, false, 1>;
         using OldF = FxCfg<DT_BF16, 256, 128, 3, false, 1>;
         auto one = [&] {
@@ -205,6 +205,8 @@ int main(int argc, char** argv) {
             else if (v == 31) launch_w4<W4Cfg<DT_BF16, 256, 128, true, false, 1 | 2048>>(p0, 1, 0);   // trickled epilogue, fused
             else if (v == 32) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 8192>>(p0, 1, 0);  // k loop unrolled by four, no trickle
             else if (v == 33) launch_w4<W4Cfg<DT_BF16, 256, 128, true, false, 1 | 8192>>(p0, 1, 0);   // same, fused
+            else if (v == 34) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 8192 | 16384>>(p0, 1, 0);  // + per-wave store stagger (round 6 A/B)
+            else if (v == 35) launch_w4<W4Cfg<DT_BF16, 256, 128, true, false, 1 | 8192 | 16384>>(p0, 1, 0);   // same, fused
             else if (v == 3) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 64>>(p0, 1, 0);    // split-form DMA
             else if (v == 12) launch_w4<W4Cfg<DT_BF16, 256, 128, true, false, 0>>(p0, 1, 0);         // fused, VALU sign expansion (A/B)
             else if (v == 4) launch_w4<W4Cfg<DT_BF16, 256, 256, false, false, 1 | 4>>(p0, 1, 0);     // energy A/B: sign fragment in the first MFMA slot (results wrong)
@@ -225,7 +227,7 @@ int main(int argc, char** argv) {
             n += 50;
             CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&total, e0, e1));
         }
-        const double fl = ((v >= 10 && v < 20) || v == 31 || v == 33 ? 4.0 : 2.0) * M * N * K;
+        const double fl = ((v >= 10 && v < 20) || v == 31 || v == 33 || v == 35 ? 4.0 : 2.0) * M * N * K;
         printf("soak variant %d M=%d: %lld launches in %.1f ms -> %.2f us each, %.1f TF\n", v, M, n, total, total * 1e3 / n, fl * n / (total * 1e-3) / 1e12);
         return 0;
     }

@@ -8,6 +8,8 @@
 #   libs    <libA.so> <libB.so> [tenants ...]      same-box A/B of two library BUILDS on the decode step (BD_HIP_LIB)
 #   bench   [bench args]                           python bench.py ..., both output lines kept
 #   prefill <libA.so> <libB.so>                    tools/ab_lib.sh (prefill step, fused roofline, delta-GEMM rows; A B A B)
+#   final                                          what the driver runs at round end: smoke(), pytest -m gpu, the default bench line (wall-clocked)
+# Earlier rounds' sessions (tools/gpu_r4*.sh, gpu_r5*.sh: one script per question) are in the git history; their results are the profiles/ files.
 # Several "mode args" groups may be chained with `--`:  tools/ab.sh r6a tests -k decode -- decode "base:0 fg_off:256"
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; TAG=$1; shift; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
@@ -43,6 +45,11 @@ run_mode() {
       tail -1 $OUT/bench.out > $OUT/bench.json; wc -c $OUT/bench.json | tee -a $OUT/bench.txt; tail -3 $OUT/bench.err ;;
     prefill)
       bash tools/ab_lib.sh "$1" "$2" $TAG 2>&1 | tee -a $OUT/prefill.txt ;;
+    final)
+      python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; echo "smoke rc=$?" | tee -a $OUT/final.txt; tail -1 $OUT/smoke.txt
+      timeout 1500 python -m pytest tests -m gpu -q -x > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc=$?" | tee -a $OUT/final.txt; tail -3 $OUT/pytest_gpu.txt | tee -a $OUT/final.txt
+      t0=$(date +%s.%N); timeout 900 python bench.py > $OUT/bench.out 2> $OUT/bench.err; rc=$?; t1=$(date +%s.%N)
+      echo "bench rc=$rc wall $(echo "$t1 - $t0" | bc) s" | tee -a $OUT/final.txt; tail -1 $OUT/bench.out > $OUT/bench.json; wc -c $OUT/bench.json | tee -a $OUT/final.txt ;;
     *) echo "unknown mode $mode"; return 2 ;;
   esac
 }
