@@ -339,11 +339,11 @@ def committed_traffic():
     """HBM/fabric-side bytes per launch of the dominant kernels, from the committed rocprofv3 PMC passes over THIS command
     (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE x 2 per MI355X_MICROARCH.md; tools/prof_bench.sh).  A bench run cannot
     read PMC counters in-process, so the line carries the committed figure and names its source."""
-    path = os.path.join(ROOT, "profiles", "r05_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r06_traffic.json")
     try:
         with open(path) as fh:
             d = json.load(fh)
-        d["_source"] = "profiles/r05_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `python bench.py`, tools/prof_bench.sh)"
+        d["_source"] = "profiles/r06_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `python bench.py`, tools/prof_bench.sh)"
         return d
     except Exception:
         return None
@@ -831,7 +831,7 @@ def main():
     # non-contract keys): every figure the north star names sits inside `roofline`; the long blocks go to a "# bench detail" line printed BEFORE it.
     roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
             "traffic": traffic.get("fused_gemm", {}).get("traffic_bytes_per_launch") if traffic else None,
-            "traffic_source": "profiles/r05_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE passes over this command)" if traffic else "none",
+            "traffic_source": "profiles/r06_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE passes over this command)" if traffic else "none",
             "traffic_over_algorithmic": fr(traffic["fused_gemm"]["traffic_bytes_per_launch"] / (k_bytes / n_launch), 3)
                                         if traffic and n_launch and traffic.get("fused_gemm") else None,
             "algorithmic_bytes_per_launch": k_bytes / n_launch if n_launch else None,

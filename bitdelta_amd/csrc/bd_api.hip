@@ -1503,8 +1503,16 @@ extern "C" int bd_tenant_linear(const void* X, const void* W, void* Y, int T, in
     sp.cpb = cpb;
     dim3 grid((unsigned)((N + cpb - 1) / cpb), (unsigned)T);
     hipStream_t st = (hipStream_t)stream;
-    const int rc = dtype == BD_BF16 ? launch_stream_tuned<DT_BF16, 0, true, 8>(sp, grid, st)
-                                    : launch_stream_tuned<DT_F16, 0, true, 8>(sp, grid, st);      // (NS 6 / 4 measured equal or slower here)
+    // A/B (round 6; bd_set_stream_tuning bits 11 / 12): natural-order weight loads (a load instruction = 16 rows x 64 contiguous bytes) with / without the
+    // non-temporal policy, against the shipped word-row order.  profiles/r06_decode_step.txt has the outcome.
+    int rc;
+    if (g_stream_tune & 2048)
+        rc = dtype == BD_BF16 ? launch_stream_inst<DT_BF16, 0, true, 8, 4, 1, 2>(sp, grid, st) : launch_stream_inst<DT_F16, 0, true, 8, 4, 1, 2>(sp, grid, st);
+    else if (g_stream_tune & 4096)
+        rc = dtype == BD_BF16 ? launch_stream_inst<DT_BF16, 0, true, 8, 4, 1, 0>(sp, grid, st) : launch_stream_inst<DT_F16, 0, true, 8, 4, 1, 0>(sp, grid, st);
+    else
+        rc = dtype == BD_BF16 ? launch_stream_tuned<DT_BF16, 0, true, 8>(sp, grid, st)
+                              : launch_stream_tuned<DT_F16, 0, true, 8>(sp, grid, st);      // (NS 6 / 4 measured equal or slower here)
     if (rc != BD_OK) return rc;
     return launch_status();
 }

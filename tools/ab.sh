@@ -49,7 +49,7 @@ run_mode() {
       python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; echo "smoke rc=$?" | tee -a $OUT/final.txt; tail -1 $OUT/smoke.txt
       timeout 1500 python -m pytest tests -m gpu -q -x > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc=$?" | tee -a $OUT/final.txt; tail -3 $OUT/pytest_gpu.txt | tee -a $OUT/final.txt
       t0=$(date +%s.%N); timeout 900 python bench.py > $OUT/bench.out 2> $OUT/bench.err; rc=$?; t1=$(date +%s.%N)
-      echo "bench rc=$rc wall $(echo "$t1 - $t0" | bc) s" | tee -a $OUT/final.txt; tail -1 $OUT/bench.out > $OUT/bench.json; wc -c $OUT/bench.json | tee -a $OUT/final.txt ;;
+      echo "bench rc=$rc wall $(python3 -c "print(round($t1 - $t0, 1))") s" | tee -a $OUT/final.txt; tail -1 $OUT/bench.out > $OUT/bench.json; wc -c $OUT/bench.json | tee -a $OUT/final.txt ;;
     *) echo "unknown mode $mode"; return 2 ;;
   esac
 }

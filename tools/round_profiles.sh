@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-5 evidence under rocprofv3 (separate passes: kernel-trace / each --pmc set; never combined with sys or hip tracing):
+# Per-round evidence under rocprofv3 (tools/round_profiles.sh gpurun_out/r06_profiles; copy the summaries to profiles/rNN_*) (separate passes: kernel-trace / each --pmc set; never combined with sys or hip tracing):
 #   1. the bench command itself            -> <out>/bench_kernel_stats.csv, bench_under_rocprof.json, traffic.json
 #   2. the 6-tenant decode step (hipGraph) -> <out>/decode_step_kernel_stats.csv
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-OUT=${1:-gpurun_out/r05_profiles}
+OUT=${1:-gpurun_out/round_profiles}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 bash tools/prof_bench.sh "$OUT/bench" > "$OUT/prof_bench.log" 2>&1
