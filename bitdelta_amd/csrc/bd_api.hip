@@ -364,8 +364,8 @@ int launch_stream_inst(const StreamParams& sp, dim3 grid, hipStream_t st) {
     static std::atomic<uint64_t> lds_done{0};
     constexpr int base = FG ? STREAM_FG_XS_OFF : STREAM_LDS_BYTES;
     const int lds = XL ? std::max((int)(sp.xs_off + (uint32_t)sp.g.R * sp.xrow), base) : base;
-    if (lds > (FG ? STREAM_FG_LDS_MAX : STREAM_LDS_MAX)) return BD_E_BAD_SHAPE;
-    if (!ensure_dyn_lds((const void*)kern, FG ? STREAM_FG_LDS_MAX : XL ? STREAM_LDS_MAX : STREAM_LDS_BYTES, lds_done)) return BD_E_LAUNCH;
+    if (lds > (FG == 1 ? STREAM_FG_LDS_MAX : STREAM_LDS_MAX)) return BD_E_BAD_SHAPE;
+    if (!ensure_dyn_lds((const void*)kern, FG == 1 ? STREAM_FG_LDS_MAX : XL ? STREAM_LDS_MAX : STREAM_LDS_BYTES, lds_done)) return BD_E_LAUNCH;
     hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, sp);
     return BD_OK;
 }
@@ -521,6 +521,29 @@ int launch_gemv_stream_chunk(const Problem& q) {
         const unsigned fg_grid = (unsigned)fg_tiles;
         if (fg) { sp.cpb = 16; sp.xs_off = (uint32_t)STREAM_FG_XS_OFF; }
         t_last_decode_form = fg ? 1 : 0;
+        // Two-pass resident rows (FG = 2, round 6; gemv_stream_kernel): rows that do not fit LDS at once -- the down projection of a multi-tenant
+        // step, 6 x 14336 -- with ONE tile per block, every wave's k quarter cut in two halves.  Bit-identical to the per-stage-load form and
+        // SLOWER (down 33.0 -> 37.1 us at 2 stages of prefetch, 40.0 at 4; step +4 ... +6 %: profiles/r06_decode_step.txt), so like every A/B
+        // loser it exists in harness builds only (-DBD_AB_VARIANTS; bd_set_stream_tuning 8192 = on, + 16384 = 2 stages instead of 4).
+#ifdef BD_AB_VARIANTS
+        const bool fg2 = (g_stream_tune & 8192) && q.w_tiled && !q.norm_w && !q.ssq_in && q.epilogue == 0 && q.M == 1 && q.t_pad <= 8 && q.N % 16 == 0 &&
+                         fg_tiles <= cus && q.K % 1024 == 0 && q.K >= 8192 && (int64_t)q.B * q.K > 16 * 2048 && (int64_t)q.B * (q.K / 2) <= 24 * 2048 &&
+                         (int64_t)STREAM_FG_XS_OFF + (int64_t)q.B * ((int64_t)q.K + 16) <= STREAM_LDS_MAX;
+        if (fg2) {
+            sp.cpb = 16; sp.xs_off = (uint32_t)STREAM_FG_XS_OFF; sp.xrow = (uint32_t)q.K + 16u;
+            t_last_decode_form = 2;
+#define BD_X2(NM) rc = (g_stream_tune & 16384) ? launch_stream_inst<DT, NM, true, 2, 4, 1, 2, 1, 2, 0, 1, 2>(sp, dim3(fg_grid), q.st) \
+                                              : launch_stream_inst<DT, NM, true, 4, 4, 1, 2, 1, 2, 0, 1, 2>(sp, dim3(fg_grid), q.st)
+            switch (q.t_pad) {
+                case 4: BD_X2(4); break;
+                case 6: BD_X2(6); break;
+                default: return BD_E_BAD_SHAPE;
+            }
+#undef BD_X2
+            if (rc != BD_OK) return rc;
+            return launch_status();
+        }
+#endif
         if (q.ssq_in) {
             // RMSNorm by hand-off (XL = 3): the resident-row form with the rows pre-multiplied by the norm weight and the row scale in the
             // epilogue; same envelope as the resident rows, nothing else implements it

@@ -62,6 +62,13 @@ constexpr int STREAM_XS_OFF = STREAM_LUT_BYTES + stream_red_bytes(4) + STREAM_AL
 //   lane copy c = l & 31 at e * 256 + c * 8 -- the copy index selects the bank pair, the entry the LDS row, so the 32 lanes of a
 //   ds_read_b64 service group touch 64 distinct banks whatever the nibbles are: conflict-free in 4 KiB instead of 64 KiB; a fragment is
 //   two ds_read_b64 (same LDS cycles as one ds_read_b128) and four VALU instead of one.
+// FG = 2 (round 6): TWO-PASS resident rows for launches whose activation rows do not fit LDS at once -- the down projection of a multi-tenant
+//   step (6 x 14336 x 2 B = 172 KB).  One block per CU (512 registers), ONE tile per block, the nibble table (which is what makes room: 4 KiB
+//   instead of 64), and each wave's contiguous k quarter cut in two halves: LDS holds, per row, the first halves of the four quarters, then --
+//   after one pair of barriers in the middle of the stream -- the second halves.  The rows of BOTH passes are fetched at kernel start (the second
+//   set waits in 96 registers), so the switch needs no memory wait and the weight prefetch runs straight through it.  A stage is then 4 W + 2
+//   sign loads instead of 10 loads (no per-stage activation loads), as in the single-pass form.  Every wave accumulates exactly the k
+//   iterations, in exactly the order, of the one-pass forms: bit-identical to them.
 constexpr int STREAM_FG_LUT_BYTES = 4096;
 constexpr int stream_lut_bytes(int fg) { return fg ? STREAM_FG_LUT_BYTES : 65536; }
 constexpr int STREAM_FG_XS_OFF = STREAM_FG_LUT_BYTES + 2 * 4 * 64 * 8 * 4 + 512 * 4;      // FG kernels (4 waves): activation rows
@@ -161,9 +168,10 @@ struct StreamParams {
 //   serving side repacks it once, binary_gemm_kernel.tile_weight): the four load instructions of a stage read four consecutive
 //   1-KiB runs of ONE contiguous 4-KiB block, and a wave's consecutive stages consecutive blocks, instead of 16 rows 2K bytes apart.
 template <int DT, int NM, bool HASW, int NS, int NW = 4, int WNAT = 0, int AUX = 0, int PK = 0, int XL = 0, int EPI = 0, int WT = 0, int FG = 0>
-__global__ void __launch_bounds__(64 * NW, FG ? 2 : 1) gemv_stream_kernel(const StreamParams sp) {
+__global__ void __launch_bounds__(64 * NW, FG == 1 ? 2 : 1) gemv_stream_kernel(const StreamParams sp) {
     static_assert(!WT || (PK && HASW), "tile-major W: packed layout");
     static_assert(!FG || (PK && WT && NW == 4 && (XL == 2 || XL == 3)), "fine grid: resident-row forms, packed layout, tile-major W, 256-thread blocks");
+    static_assert(FG != 2 || XL == 2, "two-pass rows: the plain resident-row form");
     constexpr int LUTB = stream_lut_bytes(FG);
     static_assert(!PK || (WNAT == 1 && NM > 0), "packed layout = natural order, with a sign operand");
     static_assert(!(XL || EPI) || (PK && (NW == 4 || (XL == 2 && NW == 8))), "fused prologue / epilogue: packed layout, 256-thread blocks (resident rows: 512 too)");
@@ -255,9 +263,10 @@ __global__ void __launch_bounds__(64 * NW, FG ? 2 : 1) gemv_stream_kernel(const 
 
     // XL: the R raw rows (and their norm weights) are the OLDEST loads of the wave -- like the scales above, consuming them never
     // waits for a weight stage.  Thread t owns the 16-byte chunks c = 8 t + 2048 i of every row: rmsnorm_tenant_kernel's mapping.
-    constexpr int XCH = NW == 8 ? 8 : 16;                                // chunks per thread: R * K <= 16 * 2048 (host-checked)
+    constexpr int XCH = FG == 2 ? 24 : NW == 8 ? 8 : 16;                 // chunks per thread: R * K <= 16 * 2048 (FG = 2: R * K / 2 <= 24 * 2048; host-checked)
     constexpr int XNT = 64 * NW;                                         // threads that share the copy
     [[maybe_unused]] u32x4_t xraw[XL ? XCH : 1], graw[XL == 1 ? XCH : 1];
+    [[maybe_unused]] u32x4_t xraw1[FG == 2 ? XCH : 1];                   // FG = 2: the second pass's rows, fetched now, written to LDS at the switch
     // XL = 3: this thread's share of the producer's partial sums of squares, rows 0..7 (host-checked: R <= 8); tiles t, t + 256, ...
     // Raw loads only, NO arithmetic here: a sum inside a loop makes the compiler wait for each load where it is issued -- a full memory
     // round trip (the partials were just written by another launch, from other XCDs) in front of the first weight load: +5 us on the
@@ -281,6 +290,28 @@ __global__ void __launch_bounds__(64 * NW, FG ? 2 : 1) gemv_stream_kernel(const 
         // front of the first weight load of the launch (read in the ISA, round 5)
         [[maybe_unused]] const int kc = p.K >> 3;
         [[maybe_unused]] int xr_ = (int)threadIdx.x / kc, xc_ = (int)threadIdx.x - xr_ * kc;
+        if constexpr (FG == 2) {
+            // chunk q = thread + 256 j of the flat [R][4 wave quarters][K / 64 chunks of one half quarter]; pass 1 = the same chunk, K / 8 elements on
+            const int khc = p.K >> 6;                                    // 16-byte chunks of a half quarter (>= 128: host-checked)
+            int off = (int)threadIdx.x, seg = 0, r = 0;
+            while (off >= khc) { off -= khc; ++seg; }                    // (thread < 256 <= 2 khc: at most two steps)
+#pragma unroll
+            for (int j = 0; j < XCH; ++j) {
+                const bool ok = r < p.R;
+                const uint32_t e = ok ? (uint32_t)(((long long)r * p.sXb + (long long)seg * (p.K >> 2) + off * 8) * 2) : STREAM_OOB;
+                xraw[j] = buf_load16<0>(rx, e);
+                off += XNT;
+#pragma unroll
+                for (int w_ = 0; w_ < 2; ++w_) {
+                    const bool wrap = off >= khc;
+                    off -= wrap ? khc : 0;
+                    seg += wrap ? 1 : 0;
+                }
+                const bool wr = seg >= 4;
+                seg -= wr ? 4 : 0;
+                r += wr ? 1 : 0;
+            }
+        } else
 #pragma unroll
         for (int j = 0; j < XCH; ++j) {
             // XL = 1: K = 2048 << jsh, a thread's chunks of one row are consecutive j (the row sums need that).  XL = 2: any K % 8 == 0 --
@@ -385,6 +416,29 @@ __global__ void __launch_bounds__(64 * NW, FG ? 2 : 1) gemv_stream_kernel(const 
         issue(st[u], ti, ii);
         advance(ti, ii);
     }
+    if constexpr (FG == 2) {
+        // the SECOND pass's rows go out behind the prologue's weight stages: they are not needed before the middle of the stream, and in front of
+        // the weight loads (returns are in issue order) their 24 L2 round trips per thread delayed the first weight byte of the launch
+        const __amdgpu_buffer_rsrc_t rx1 = make_rsrc(p.X, sp.x_bytes);
+        const int khc = p.K >> 6;
+        int off = (int)threadIdx.x, seg = 0, r = 0;
+        while (off >= khc) { off -= khc; ++seg; }
+#pragma unroll
+        for (int j = 0; j < XCH; ++j) {
+            xraw1[j] = buf_load16<0>(rx1, r < p.R ? (uint32_t)(((long long)r * p.sXb + (long long)seg * (p.K >> 2) + (p.K >> 3) + off * 8) * 2) : STREAM_OOB);
+            off += XNT;
+#pragma unroll
+            for (int w_ = 0; w_ < 2; ++w_) {
+                const bool wrap = off >= khc;
+                off -= wrap ? khc : 0;
+                seg += wrap ? 1 : 0;
+            }
+            const bool wr = seg >= 4;
+            seg -= wr ? 4 : 0;
+            r += wr ? 1 : 0;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
     if constexpr (NM > 0 && FG) {   // nibble sign table: thread t writes entry t >> 4 for the lane copies 2 (t & 15), 2 (t & 15) + 1 (one ds_write_b128)
         constexpr uint32_t POS = One2<DT>::v & 0xffffu, NEG = POS | 0x8000u;
@@ -404,7 +458,30 @@ __global__ void __launch_bounds__(64 * NW, FG ? 2 : 1) gemv_stream_kernel(const 
             *(u32x4_t*)(dyn_lds + slot * 16) = w;
         }
     }
-    if constexpr (XL == 2 || XL == 3) {           // rows -> LDS (same thread mapping as the norm form)
+    // FG = 2: (row, quarter, chunk) -> LDS byte offset of this thread's chunk j; the same positions serve both passes
+    [[maybe_unused]] auto rows_to_lds2 = [&](const u32x4_t (&src)[FG == 2 ? XCH : 1]) {
+        if constexpr (FG == 2) {
+            const int khc = p.K >> 6;
+            int off = (int)threadIdx.x, seg = 0, r = 0;
+            while (off >= khc) { off -= khc; ++seg; }
+#pragma unroll
+            for (int j = 0; j < XCH; ++j) {
+                if (r < p.R) *(u32x4_t*)(dyn_lds + sp.xs_off + (uint32_t)r * sp.xrow + (uint32_t)(seg * khc + off) * 16u) = src[j];
+                off += XNT;
+#pragma unroll
+                for (int w_ = 0; w_ < 2; ++w_) {
+                    const bool wrap = off >= khc;
+                    off -= wrap ? khc : 0;
+                    seg += wrap ? 1 : 0;
+                }
+                const bool wr = seg >= 4;
+                seg -= wr ? 4 : 0;
+                r += wr ? 1 : 0;
+            }
+        }
+    };
+    if constexpr (FG == 2) rows_to_lds2(xraw);
+    else if constexpr (XL == 2 || XL == 3) {           // rows -> LDS (same thread mapping as the norm form)
         const int kc = p.K >> 3;
         int r = (int)threadIdx.x / kc, cq = (int)threadIdx.x - r * kc;       // (incremental, as in the load loop above)
 #pragma unroll
@@ -500,7 +577,14 @@ __global__ void __launch_bounds__(64 * NW, FG ? 2 : 1) gemv_stream_kernel(const 
     [[maybe_unused]] u32x4_t xq[XL ? 2 : 1][XL ? 4 : 1];
     auto read_xq = [&](int set, int it) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) xq[XL ? set : 0][XL ? s : 0] = lds16(xl_base + (uint32_t)min(it, nit - 1) * 256u + 64u * s);   // (run-ahead stages: any row)
+        for (int s = 0; s < 4; ++s) {
+            uint32_t idx = (uint32_t)min(it, nit - 1);
+            if constexpr (FG == 2) {                      // position inside the resident half: quarter `wave`, iteration modulo the half quarter
+                const int rel = min(max(it - it_lo, 0), per - 1), hp = per >> 1;
+                idx = (uint32_t)(wave * hp + (rel >= hp ? rel - hp : rel));
+            }
+            xq[XL ? set : 0][XL ? s : 0] = lds16(xl_base + idx * 256u + 64u * s);   // (run-ahead stages: any row)
+        }
     };
     auto compute = [&](const Stage& cur, [[maybe_unused]] int par, [[maybe_unused]] int it_next) {
         constexpr bool SFDB = !(WNAT && NW == 8);
@@ -646,6 +730,20 @@ __global__ void __launch_bounds__(64 * NW, FG ? 2 : 1) gemv_stream_kernel(const 
             __builtin_amdgcn_sched_barrier(0);
             issue(st[u], ti, ii);
             advance(ti, ii);
+            if constexpr (FG == 2) {
+                // the switch: every wave has consumed the first half of its quarter (equal counts: host-checked), nobody reads the first-half
+                // rows any more -> overwrite them with the second halves (registers since kernel start: no memory wait), and re-read the
+                // activation fragments of the next stage, which the step above prefetched from the old rows
+                if (ic + 1 - it_lo == (per >> 1) && tc == 0) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    rows_to_lds2(xraw1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    read_xq((u & 1) ^ 1, ic + 1);
+                }
+            }
             if (++ic >= it_hi && tc < ntile) {
                 finish_tile(tc);
                 ic = it_lo;

@@ -65,7 +65,10 @@ int bd_set_decode_wave_spec(int on);
 int bd_set_stream_tuning(int flags);
 /* ... bits 8 / 9 (round 6): 256 = never run the FINE-GRID form of the resident-row decode launches (single-tile blocks, two per CU, nibble
  * sign table), 512 = run it on every eligible launch of at most two 16-column tiles per CU (default: only between one and two tiles per CU). */
-/* which form the LAST streaming decode launch of this thread took: 0 = one block per CU, 1 = fine grid */
+/* ... bits 13 / 14 (round 6; -DBD_AB_VARIANTS harness builds only, the shipped library ignores them): 8192 = run the TWO-PASS resident-row form where
+ * the rows do not fit LDS at once (the multi-tenant down projection; measured slower, profiles/r06_decode_step.txt), 16384 = with 2 stages of prefetch;
+ * bits 11 / 12: bd_tenant_linear's weight loads in natural order with (2048) / without (4096) the non-temporal policy (A/B: no difference). */
+/* which form the LAST streaming decode launch of this thread took: 0 = one block per CU, 1 = fine grid, 2 = two-pass resident rows (harness builds) */
 int bd_last_decode_form(void);
 /* A/B hook, sign LUT of the no-split-k decode kernel: -1 (default) automatic, 1 = single 4-KiB table, 0 = 16-copy conflict-free
  * 64-KiB table whenever it fits in LDS */
