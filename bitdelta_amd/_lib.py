@@ -35,6 +35,7 @@ SIGNATURES = {
                                         _i64, _i64, _ci, _ci, _vp, _i64, _vp]),
     "bd_tenant_linear": (_ci, [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _i64, _ci, _ci, _vp]),
     "bd_srv_rmsnorm": (_ci, [_vp, _vp, _vp, _ci, _ci, _i64, _i64, _i64, _ci, ctypes.c_float, _ci, _vp]),
+    "bd_srv_add_rmsnorm": (_ci, [_vp, _vp, _vp, _vp, _vp, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _ci, ctypes.c_float, _ci, _vp]),
     "bd_srv_swiglu": (_ci, [_vp, _vp, _vp, _ci, _ci, _i64, _i64, _i64, _ci, _ci, _vp]),
     "bd_binary_linear_decode_fused": (_ci, [_vp, _vp, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _ci,
                                             _i64, _i64, _ci, _ci, _ci, _vp, _i64, ctypes.c_float, _ci, _vp]),

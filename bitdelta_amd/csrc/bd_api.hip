@@ -1569,6 +1569,27 @@ extern "C" int bd_srv_rmsnorm(const void* X, const void* Wt, void* Y, int rows, 
     return launch_status();
 }
 
+extern "C" int bd_srv_add_rmsnorm(const void* resid, const float* y32, const void* Wt, void* x_out, void* h_out, int rows, int H, int64_t s_r,
+                                  int64_t s_y, int64_t s_x, int64_t s_h, int64_t sw, int rows_per_tenant, float eps, int dtype, void* stream) {
+    if (rows < 0 || H < 0 || rows_per_tenant < 1) return BD_E_BAD_SHAPE;
+    if (dtype != BD_F16 && dtype != BD_BF16) return BD_E_BAD_DTYPE;
+    if (rows == 0 || H == 0) return BD_OK;
+    if (!resid || !y32 || !Wt || !x_out || !h_out) return BD_E_NULL;
+    if (H % 8 || H > 8192 || s_r % 8 || s_y % 4 || s_x % 8 || s_h % 8 || sw % 8 || !aligned16(resid) || !aligned16(y32) || !aligned16(Wt) ||
+        !aligned16(x_out) || !aligned16(h_out))
+        return BD_E_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == BD_BF16)
+        hipLaunchKernelGGL((add_rmsnorm_kernel<DT_BF16>), dim3(rows), dim3(256), 0, st, (const unsigned short*)resid, y32, (const unsigned short*)Wt,
+                           (unsigned short*)x_out, (unsigned short*)h_out, H, (long long)s_r, (long long)s_y, (long long)s_x, (long long)s_h,
+                           (long long)sw, rows_per_tenant, eps);
+    else
+        hipLaunchKernelGGL((add_rmsnorm_kernel<DT_F16>), dim3(rows), dim3(256), 0, st, (const unsigned short*)resid, y32, (const unsigned short*)Wt,
+                           (unsigned short*)x_out, (unsigned short*)h_out, H, (long long)s_r, (long long)s_y, (long long)s_x, (long long)s_h,
+                           (long long)sw, rows_per_tenant, eps);
+    return launch_status();
+}
+
 extern "C" int bd_srv_swiglu(const void* G, const void* U, void* Y, int rows, int I, int64_t sg, int64_t su, int64_t sy,
                              int interleaved8, int dtype, void* stream) {
     if (rows < 0 || I < 0 || rows > 65535) return BD_E_BAD_SHAPE;

@@ -88,6 +88,50 @@ __global__ void __launch_bounds__(256) rmsnorm_tenant_kernel(const unsigned shor
         *(u32x4_t*)(yr + c) = norm8<DT>(*(const u32x4_t*)(xr + c), *(const u32x4_t*)(wr + c), rs);
 }
 
+// residual add + RMSNorm in ONE launch (round 6; the tensor-parallel decoder: `x = residual + all_reduce(partial).to(dtype); h = norm(x)` was a cast, an
+// add and a norm launch -- three ~5-us launches around every row-parallel Linear of a per-rank step whose Linears are 10-25 us).  Same arithmetic and
+// roundings as the three ops: v = round16(y32), x = round16(residual + v) (torch's 16-bit add), then rmsnorm_tenant_kernel's two passes on x, which stays
+// in registers.  One 256-thread block per row, H % 8 == 0, H <= 8192.
+template <int DT>
+__global__ void __launch_bounds__(256) add_rmsnorm_kernel(const unsigned short* __restrict__ resid, const float* __restrict__ y32,
+                                                          const unsigned short* __restrict__ w, unsigned short* __restrict__ x_out,
+                                                          unsigned short* __restrict__ h_out, int H, long long s_r, long long s_y, long long s_x,
+                                                          long long s_h, long long sw, int rows_per_tenant, float eps) {
+    __shared__ float part[4];
+    const int r = blockIdx.x, t = r / rows_per_tenant;
+    const unsigned short* rr = resid + (long long)r * s_r;
+    const float* yr = y32 + (long long)r * s_y;
+    const unsigned short* wr = w + (long long)t * sw;
+    u32x4_t xs[4];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = threadIdx.x * 8 + 2048 * i;
+        xs[i] = u32x4_t{0u, 0u, 0u, 0u};
+        if (c < H) {
+            const u32x4_t rv = *(const u32x4_t*)(rr + c);
+            const f32x4_t ya = *(const f32x4_t*)(yr + c), yb = *(const f32x4_t*)(yr + c + 4);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const float y0 = d < 2 ? ya[2 * d] : yb[2 * d - 4], y1 = d < 2 ? ya[2 * d + 1] : yb[2 * d - 3];
+                const float lo = half_bits_to_f32<DT>(rv[d] & 0xffffu) + round16<DT>(y0), hi = half_bits_to_f32<DT>(rv[d] >> 16) + round16<DT>(y1);
+                xs[i][d] = f32_to_half_bits<DT>(lo) | (f32_to_half_bits<DT>(hi) << 16);
+            }
+            *(u32x4_t*)(x_out + (long long)r * s_x + c) = xs[i];
+            ss = sumsq8<DT>(xs[i], ss);
+        }
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float rs = rms_scale(part[0], part[1], part[2], part[3], H, eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = threadIdx.x * 8 + 2048 * i;
+        if (c < H) *(u32x4_t*)(h_out + (long long)r * s_h + c) = norm8<DT>(xs[i], *(const u32x4_t*)(wr + c), rs);
+    }
+}
+
 // The same norm for MANY rows (prefill: hundreds to thousands of rows): ONE WAVE per row, four rows per block, the row held in registers between
 // the two passes -- no block barrier, no second read of x.  Bit-identical to rmsnorm_tenant_kernel: lane l plays that kernel's threads l, l + 64,
 // l + 128, l + 192 (its four waves), so the four per-wave sums are formed by the same lanes in the same order and meet in rms_scale as before.

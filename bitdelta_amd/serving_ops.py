@@ -19,6 +19,22 @@ def rmsnorm_tenant(x, w, eps):
     return y
 
 
+def add_rmsnorm(resid, y32, w, eps):
+    """(x, h) with x = resid + y32.to(resid.dtype) and h = rmsnorm_tenant(x, w, eps), in ONE launch and with exactly those ops' roundings.
+    resid [T, M, H] 16-bit, y32 [T, M, H] fp32 (a row-parallel Linear's reduced partial sums), w [T, H]."""
+    require_gpu(resid, y32, w)
+    T, M, H = resid.shape
+    assert y32.shape == resid.shape and y32.dtype == torch.float32 and w.shape == (T, H) and w.dtype == resid.dtype
+    assert resid.stride(2) == 1 and y32.stride(2) == 1 and w.stride(1) == 1 and H % 8 == 0 and H <= 8192
+    assert T == 1 or (resid.stride(0) == M * resid.stride(1) and y32.stride(0) == M * y32.stride(1)), "rows must be evenly strided"
+    x = torch.empty((T, M, H), device=resid.device, dtype=resid.dtype)
+    h = torch.empty((T, M, H), device=resid.device, dtype=resid.dtype)
+    with torch.cuda.device(resid.device):
+        check(lib().bd_srv_add_rmsnorm(ptr(resid), ptr(y32), ptr(w), ptr(x), ptr(h), T * M, H, resid.stride(1), y32.stride(1), H, H, w.stride(0), M,
+                                       float(eps), DTYPE_CODE[resid.dtype], stream_ptr()), "srv_add_rmsnorm")
+    return x, h
+
+
 def swiglu(gu, inter):
     """gu [T, M, 2*inter] (gate columns, then up columns) -> round(silu(gate)) * up, [T, M, inter]"""
     assert gu.shape[2] == 2 * inter

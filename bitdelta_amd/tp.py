@@ -301,6 +301,15 @@ class TPDecoderLayer(nn.Module):
             return ops.rmsnorm_tenant(x if x.is_contiguous() else x.contiguous(), w, self.eps)
         return F.rms_norm(x, (x.shape[-1],), w[0], self.eps)
 
+    def _row_parallel_sum(self, lin, x):
+        """all-reduce(x_r . W_r^T + coeff * (x_r . S_r)) in fp32, WITHOUT the residual add (decode: the caller folds the add and the next RMSNorm into
+        one launch, serving_ops.add_rmsnorm)"""
+        buf = self.reduce.buffer((*x.shape[:-1], lin.weight.shape[0]), torch.float32, x.device)
+        if buf is not None:
+            lin(x, out_dtype=torch.float32, out=buf)
+            return self.reduce.reduce_buffer(buf)
+        return self.reduce(lin(x, out_dtype=torch.float32))
+
     def _row_parallel(self, lin, x, residual):
         """residual + all-reduce(x_r . W_r^T + coeff * (x_r . S_r)): fp32 partials for decode-sized messages, the activation dtype for
         prefill-sized ones (half the bytes on the wire; one extra rounding per partial)"""
@@ -330,12 +339,21 @@ class TPDecoderLayer(nn.Module):
         return bool(ops.prefill_attention_supported(qkv[..., :nq].view(B, S, self.h_loc, hd), qkv[..., nq:nq + nk].view(B, S, self.kv_loc, hd),
                                                     qkv[..., nq + nk:].view(B, S, self.kv_loc, hd)))
 
-    def forward(self, x, cos, sin, cache, pos_idx, attn_mask, from_zero=False):
+    def forward(self, x, cos, sin, cache, pos_idx, attn_mask, from_zero=False, pending=None):
         """x [1, S, hidden] (replicated); cache = (k [1, kv_loc, L, hd], v, valid [1, L]); pos_idx [S] device positions;
-        from_zero: the caller knows pos_idx == arange(S) (a prompt prefilled from position 0 into an empty cache)"""
+        from_zero: the caller knows pos_idx == arange(S) (a prompt prefilled from position 0 into an empty cache).
+        Returns (x, pending): at decode `pending` = this layer's reduced down-projection sums (fp32), which the NEXT layer (or the final norm) adds to x
+        together with its RMSNorm; otherwise None and x is complete."""
         B, S, hid = x.shape
         hd = self.hd
-        qkv = self.qkv(self._norm(x, self.n1))
+        # decode: the residual add after each all-reduce and the RMSNorm that follows it are ONE launch (round 6: cast + add + norm were three ~5-us
+        # launches around Linears of 10-25 us); `pending` = the previous layer's reduced down-projection sums, not yet added to x
+        fuse = S == 1 and B * S <= 16 and hid % 8 == 0 and hid <= 8192 and x.is_contiguous()
+        if pending is not None:
+            x, h1 = ops.add_rmsnorm(x, pending, self.n1, self.eps)
+        else:
+            h1 = self._norm(x, self.n1)
+        qkv = self.qkv(h1)
         ck, cv, valid = cache
         nq, nk = self.h_loc * hd, self.kv_loc * hd
         if S == 1 and ops.decode_attention_supported(self.h_loc, self.kv_loc, hd):
@@ -364,8 +382,11 @@ class TPDecoderLayer(nn.Module):
                 attn_mask = (keypos[None, :] <= pos_idx[:, None])[None, None] & valid[:, None, None, :]
             a = F.scaled_dot_product_attention(q, ck, cv, attn_mask=attn_mask, enable_gqa=(self.kv_loc != self.h_loc))
             a = a.transpose(1, 2).reshape(B, S, self.h_loc * hd)
-        x = self._row_parallel(self.o, a, x)
-        h = self._norm(x, self.n2)
+        if fuse:
+            x, h = ops.add_rmsnorm(x, self._row_parallel_sum(self.o, a), self.n2, self.eps)
+        else:
+            x = self._row_parallel(self.o, a, x)
+            h = self._norm(x, self.n2)
         if S == 1 and self.gate_up.interleave8 and self.gate_up._decode_ok(h):
             act = self.gate_up.forward_fused(h, None, self.eps, swiglu=True)                                # gate|up -> SwiGLU: one launch
         else:
@@ -375,7 +396,9 @@ class TPDecoderLayer(nn.Module):
             else:
                 g, u = self.gate_up.split(gu)
                 act = F.silu(g) * u
-        return self._row_parallel(self.down, act, x)
+        if fuse:
+            return x, self._row_parallel_sum(self.down, act)
+        return self._row_parallel(self.down, act, x), None
 
 
 class TPDecoder(nn.Module):
@@ -442,8 +465,13 @@ class TPDecoder(nn.Module):
             keypos = torch.arange(Lc, device=self.dev)
             mask = (keypos[None, :] <= pos_idx[:, None])[None, None] & cache["valid"][:, None, None, :]
         x = self.embed[ids]
+        pending = None
         for li, layer in enumerate(self.layers):
-            x = layer(x, self.cos, self.sin, (cache["k"][li], cache["v"][li], cache["valid"]), pos_idx, mask, from_zero=from_zero)
+            x, pending = layer(x, self.cos, self.sin, (cache["k"][li], cache["v"][li], cache["valid"]), pos_idx, mask, from_zero=from_zero,
+                               pending=pending)
+        if pending is not None:                      # decode: the last layer's down-projection sums + the final norm in one launch
+            _, last = ops.add_rmsnorm(x, pending, self.norm, 1e-5)
+            return last @ self.lm_head.T
         last = x[:, -1:, :]
         last = ops.rmsnorm_tenant(last.contiguous(), self.norm, 1e-5) if last.shape[-1] % 8 == 0 else F.rms_norm(last, (last.shape[-1],), self.norm[0], 1e-5)
         return last @ self.lm_head.T

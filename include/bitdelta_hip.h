@@ -186,6 +186,11 @@ int bd_tenant_linear(const void* X, const void* W, void* Y, int T, int M, int N,
  *   fused q+k+v Linear's output; out [T, H*128].  `pos` is a DEVICE scalar so the step replays inside a hipGraph. */
 int bd_srv_rmsnorm(const void* X, const void* Wt, void* Y, int rows, int H, int64_t sx, int64_t sy, int64_t sw,
                    int rows_per_tenant, float eps, int dtype, void* stream);
+/* bd_srv_add_rmsnorm (round 6): x_out = round16(resid + round16(y32)); h_out = HF RMSNorm(x_out) with tenant t's weight -- the cast, the residual add
+ * and the norm that follow a row-parallel Linear's all-reduce (bitdelta_amd/tp.py) in ONE launch, same roundings as the three ops.  resid / x_out /
+ * h_out [rows, H] 16-bit, y32 [rows, H] fp32, row strides in elements; H % 8 == 0, H <= 8192.  No reference counterpart (the reference has no TP). */
+int bd_srv_add_rmsnorm(const void* resid, const float* y32, const void* Wt, void* x_out, void* h_out, int rows, int H, int64_t s_r, int64_t s_y,
+                       int64_t s_x, int64_t s_h, int64_t sw, int rows_per_tenant, float eps, int dtype, void* stream);
 int bd_srv_swiglu(const void* G, const void* U, void* Y, int rows, int I, int64_t sg, int64_t su, int64_t sy, int interleaved8,
                   int dtype, void* stream);
 /* bd_srv_rope: in-place rotary embedding of X [rows, heads*128] (row stride sx), position of row r = pos0 + r % seq, tables as for

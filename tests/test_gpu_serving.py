@@ -1171,3 +1171,23 @@ def test_norm_handoff_token_level_agreement_over_32_greedy_steps(bd):
         n_tie += int((~same).sum())
     assert n_tie <= 2                                                # near-ties are rare; a systematic disagreement is a bug
     assert torch.equal(l_off[0], l_on[0])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T,M,H", [(1, 1, 8192), (1, 1, 4096), (6, 1, 4096), (2, 3, 2056), (1, 16, 8192), (3, 1, 264)])
+def test_add_rmsnorm_is_bit_identical_to_cast_add_norm(bd, dtype, T, M, H):
+    """bd_srv_add_rmsnorm (round 6: what follows every row-parallel Linear's all-reduce in the tensor-parallel decoder, tp.py) == the three launches it
+    replaces -- `y32.to(dtype)`, the 16-bit residual add, rmsnorm_tenant -- bit for bit, on strided inputs too, and HF's RMSNorm within rounding."""
+    from bitdelta_amd import serving_ops as ops
+    g = torch.Generator(device="cuda").manual_seed(T * 100 + M * 10 + H)
+    resid_full = (torch.randn(T, M, H + 64, device="cuda", generator=g) * 2).to(dtype)
+    resid = resid_full[..., :H]                               # row stride H + 64
+    y32 = torch.randn(T, M, H, device="cuda", generator=g) * 0.7
+    w = (1 + 0.1 * torch.randn(T, H, device="cuda", generator=g)).to(dtype)
+    x, h = ops.add_rmsnorm(resid, y32, w, 1e-5)
+    x_ref = resid + y32.to(dtype)
+    h_ref = ops.rmsnorm_tenant(x_ref.contiguous(), w, 1e-5)
+    assert x.dtype == dtype and torch.equal(x, x_ref) and torch.equal(h, h_ref)
+    v = x_ref.float()
+    hf = (v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + 1e-5)).to(dtype) * w[:, None, :]
+    assert torch.allclose(h.float(), hf.float(), rtol=2 ** -7 if dtype == torch.bfloat16 else 2 ** -10, atol=1e-3)
