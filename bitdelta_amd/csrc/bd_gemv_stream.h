@@ -84,6 +84,14 @@ __device__ __forceinline__ float scale_then_add(float d, float a, float b) {
     return m + b;
 }
 
+#ifdef BD_STREAM_TRACE
+// s_memtime stamps (harness builds only: tests/native/stream_tl.hip): [block][0] kernel entry, [1] prologue loads issued, [2] first barrier passed,
+// [3] first stage consumed, [4] main loop done, [5] kernel exit; wave 0 of every block
+__device__ unsigned long long g_stream_trace[1024][8];
+#define BD_ST_STAMP(i) do { if (threadIdx.x == 0) g_stream_trace[blockIdx.x & 1023][i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define BD_ST_STAMP(i) do { } while (0)
+#endif
 struct StreamParams {
     GemvParams g;
     int cpb;                 // columns per block (multiple of 4)
@@ -178,6 +186,7 @@ __global__ void __launch_bounds__(64 * NW, FG == 1 ? 2 : 1) gemv_stream_kernel(c
     static_assert(XL >= 0 && XL <= 3, "activation forms");
     static_assert(!XL || NS % 2 == 0, "stage parity selects the activation fragment set");
     constexpr int AUXW = AUX & 2, AUXP = (AUX & 4) ? 2 : 0;
+    BD_ST_STAMP(0);
     GemvParams p = sp.g;
     if constexpr (XL != 0) p.M = 1;         // the resident / normalised-row forms are decode launches with one row per tenant (host-checked): a constant
                                             // lets the compiler fold the ~8 run-time divisions by M out of the prologue (row -> (tenant, row) maps)
@@ -440,6 +449,7 @@ __global__ void __launch_bounds__(64 * NW, FG == 1 ? 2 : 1) gemv_stream_kernel(c
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    BD_ST_STAMP(1);
     if constexpr (NM > 0 && FG) {   // nibble sign table: thread t writes entry t >> 4 for the lane copies 2 (t & 15), 2 (t & 15) + 1 (one ds_write_b128)
         constexpr uint32_t POS = One2<DT>::v & 0xffffu, NEG = POS | 0x8000u;
         const int ee = (int)threadIdx.x >> 4;
@@ -547,6 +557,7 @@ __global__ void __launch_bounds__(64 * NW, FG == 1 ? 2 : 1) gemv_stream_kernel(c
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
+    BD_ST_STAMP(2);
     f32x4_t accB = {0.f, 0.f, 0.f, 0.f}, accD[NMA];
 #pragma unroll
     for (int t = 0; t < NM; ++t) accD[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -727,6 +738,9 @@ __global__ void __launch_bounds__(64 * NW, FG == 1 ? 2 : 1) gemv_stream_kernel(c
 #pragma unroll
         for (int u = 0; u < NS; ++u) {
             compute(st[u], u & 1, ic + 1 >= it_hi ? it_lo : ic + 1);
+#ifdef BD_STREAM_TRACE
+            if (f == 0 && u == 0) BD_ST_STAMP(3);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             issue(st[u], ti, ii);
             advance(ti, ii);
@@ -752,7 +766,9 @@ __global__ void __launch_bounds__(64 * NW, FG == 1 ? 2 : 1) gemv_stream_kernel(c
         }
         f += NS;
     } while (f < total);
+    BD_ST_STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the run-ahead (out-of-range) loads of the last round
+    BD_ST_STAMP(5);
 }
 
 }  // namespace bd
