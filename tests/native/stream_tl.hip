@@ -70,10 +70,11 @@ int main(int argc, char** argv) {
     static unsigned long long tr[1024][8];
     CK(hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_stream_trace), sizeof(tr)));
     // (the counters of different XCDs are not synchronised: every block is measured against ITS OWN entry stamp)
-    double s[6] = {0, 0, 0, 0, 0, 0}, mx5 = 0;
-    for (unsigned b = 0; b < grid && b < 1024; ++b) for (int i = 0; i < 6; ++i) s[i] += (double)(tr[b][i] - tr[b][0]);
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mx5 = 0;
+    for (unsigned b = 0; b < grid && b < 1024; ++b) for (int i = 0; i < 8; ++i) s[i] += (double)(tr[b][i] - tr[b][0]);
     for (unsigned b = 0; b < grid && b < 1024; ++b) mx5 = std::max(mx5, (double)(tr[b][5] - tr[b][0]));
     const double nb = std::min(grid, 1024u);
+    if (s[6] > 0) printf("  sub-stamps: [6] %.0f  [7] %.0f\n", s[6] / nb, s[7] / nb);
     printf("  shader cycles since the block's own entry, mean over %g blocks (last launch): prologue loads issued %.0f | first barrier %.0f | first stage "
            "consumed %.0f | loop done %.0f | exit %.0f (slowest block %.0f)\n", nb, s[1] / nb, s[2] / nb, s[3] / nb, s[4] / nb, s[5] / nb, mx5);
 #endif
