@@ -33,6 +33,8 @@ SIGNATURES = {
                                       _i64, _i64, _ci, _ci, _ci, _vp]),
     "bd_binary_linear_residual": (_ci, [_vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _ci,
                                         _i64, _i64, _ci, _ci, _vp, _i64, _vp]),
+    "bd_binary_linear_residual_norm": (_ci, [_vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _ci,
+                                             _i64, _i64, _ci, _vp, _i64, ctypes.c_float, _vp, _i64, _i64, _vp, _i64, _vp]),
     "bd_tenant_linear": (_ci, [_vp, _vp, _vp, _ci, _ci, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _i64, _ci, _ci, _vp]),
     "bd_srv_rmsnorm": (_ci, [_vp, _vp, _vp, _ci, _ci, _i64, _i64, _i64, _ci, ctypes.c_float, _ci, _vp]),
     "bd_srv_add_rmsnorm": (_ci, [_vp, _vp, _vp, _vp, _vp, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _ci, ctypes.c_float, _ci, _vp]),
@@ -42,6 +44,7 @@ SIGNATURES = {
     "bd_binary_linear_decode_handoff": (_ci, [_vp, _vp, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _ci,
                                               _i64, _i64, _ci, _ci, _ci, _vp, _i64, ctypes.c_float, _ci, _vp, _vp, _vp, _vp]),
     "bd_srv_cache_warm": (_ci, [_vp, _i64, _vp, _i64, _ci, _vp]),
+    "bd_srv_rope_kv_append": (_ci, [_vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _i64, _ci, _ci, _ci, _vp]),
     "bd_srv_rope": (_ci, [_vp, _vp, _vp, _ci, _ci, _ci, _i64, _ci, _ci, _ci, _vp]),
     "bd_srv_decode_attention": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _i64, _i64, _ci, _vp, _i64, _vp]),
     "bd_srv_decode_attention_workspace_bytes": (_i64, [_ci, _ci, _ci, _ci, _ci]),

@@ -16,7 +16,7 @@ import torch
 from . import _lib
 from ._lib import DTYPE_CODE, WORD_DTYPE, check, lib, ptr, require_gpu, stream_ptr, workspace
 
-__all__ = ["pack", "unpack", "binary_matmul", "binary_bmm", "delta_bmm", "binary_linear", "tenant_linear", "tile_masks",
+__all__ = ["pack", "unpack", "binary_matmul", "binary_bmm", "delta_bmm", "binary_linear", "binary_linear_residual_norm", "tenant_linear", "tile_masks",
            "pack_decode_masks", "binary_linear_decode", "decode_shape_ok"]
 
 
@@ -163,6 +163,39 @@ def binary_linear(x, weight, mask, alpha, *, out_dtype=None, groups=1, residual=
         residual += y
         return residual
     return y
+
+
+def binary_linear_residual_norm(x, weight, mask, alpha, residual, norm_weight, eps, *, groups=1):
+    """binary_linear(..., residual=residual) at prefill size (M > 16) TOGETHER WITH the per-tenant RMSNorm that follows it in the decoder
+    layer: returns (residual, h) -- residual updated in place to residual + Linear(x), h = rmsnorm_tenant(residual, norm_weight, eps) --
+    bit-identical to the two calls.  One launch fewer when the Linear is split over k (several tenants of <= 64 rows: the o / down projections
+    of a short-prompt request), where the norm rides on the split-k reduce.  norm_weight [B, N].  Raises BitDeltaHipError(BD_E_BAD_SHAPE)
+    outside the envelope (M > 16, N % 8 == 0, N <= 8192, contiguous residual)."""
+    require_gpu(x, weight, mask, alpha, residual, norm_weight)
+    assert x.dim() == 3 and mask.dim() == 3 and weight.dim() == 2
+    B, M, K = x.shape
+    N = weight.shape[0]
+    assert weight.shape[1] == K and weight.stride(1) == 1 and weight.dtype == x.dtype
+    assert mask.dtype == torch.int32 and mask.is_contiguous() and mask.shape[1] * 32 == K and mask.shape[2] == N
+    assert mask.shape[0] in (1, B) and x.stride(2) == 1
+    assert residual.shape == (B, M, N) and residual.dtype == x.dtype and residual.is_contiguous()
+    assert norm_weight.shape == (B, N) and norm_weight.dtype == x.dtype and norm_weight.stride(1) == 1
+    alpha = alpha.detach()
+    if alpha.dtype != torch.float32 or not alpha.is_contiguous():
+        alpha = alpha.float().contiguous()
+    alpha = alpha.reshape(-1, groups)
+    assert alpha.shape[0] in (1, B)
+    sPb = 0 if (mask.shape[0] == 1 and B > 1) else mask.stride(0)
+    sAlb = 0 if alpha.shape[0] == 1 else groups
+    L = lib()
+    h = torch.empty_like(residual)
+    ws, ws_bytes = workspace(L.bd_gemm_workspace_bytes(B, M, N, K), x.device, zeroed=True)
+    with torch.cuda.device(x.device):
+        check(L.bd_binary_linear_residual_norm(ptr(x), ptr(weight), ptr(mask), ptr(alpha), ptr(residual), B, M, N, K, x.stride(0), x.stride(1),
+                                               weight.stride(0), sPb, sAlb, groups, residual.stride(0), residual.stride(1), DTYPE_CODE[x.dtype],
+                                               ptr(norm_weight), norm_weight.stride(0), float(eps), ptr(h), h.stride(0), h.stride(1),
+                                               ptr(ws), ws_bytes, stream_ptr()), "binary_linear_residual_norm")
+    return residual, h
 
 
 def binary_linear_swiglu(x, weight, mask, alpha):

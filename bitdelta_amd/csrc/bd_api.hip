@@ -163,10 +163,16 @@ struct Problem {
     const void* nw_next;      // ... producer with xw_out: the NEXT RMSNorm's weight [B or 1, N] (stride sNwNext) and the pre-multiplied copy
     int64_t sNwNext;
     void* xw_out;
+    const void* pn_w;         // bd_binary_linear_residual_norm: the RMSNorm that FOLLOWS this Linear -- weight [B or 1, N] (stride s_pnw), output pn_h
+    int64_t s_pnw;            // [B, M, N] (strides sHb / sHm).  A split-k reduce launch takes it along (splitk_reduce_norm_kernel) and sets
+    float pn_eps;             // t_post_norm_done; otherwise the entry point launches the norm after the Linear.
+    void* pn_h;
+    int64_t sHb, sHm;
     void* ws;
     int64_t ws_bytes;
     hipStream_t st;
 };
+static thread_local int t_post_norm_done = 0;
 
 constexpr int MAX_DEVICES = 64;
 inline int current_device() {
@@ -961,6 +967,23 @@ inline int splitk_factor(int B, int M, int N, int K) {
     return ks < 2 ? 1 : (int)ks;
 }
 
+// the reduce launch of the split-k tile kernels: partial slabs [B][KS][M][N] -> C.  A pending post-norm (Problem::pn_w) rides on it when the rows
+// are whole 16-byte chunks of at most 8192 columns: one launch instead of reduce + RMSNorm.
+template <int DT>
+inline void launch_splitk_reduce(const Problem& q, const float* part, int KS, int accumulate) {
+    if (q.pn_w && q.out_dtype != BD_F32 && q.N % 8 == 0 && q.N <= 8192 && aligned16(q.C) && q.sCm % 8 == 0 && q.sCb % 8 == 0) {
+        hipLaunchKernelGGL((splitk_reduce_norm_kernel<DT>), dim3((unsigned)(q.B * q.M)), dim3(256), 0, q.st, part, (unsigned short*)q.C,
+                           (const unsigned short*)q.pn_w, (unsigned short*)q.pn_h, KS, q.M, q.N, (long long)q.sCb, (long long)q.sCm,
+                           (long long)q.sHb, (long long)q.sHm, (long long)q.s_pnw, accumulate, q.pn_eps);
+        t_post_norm_done = 1;
+        return;
+    }
+    const long long per = (long long)q.M * q.N / 4;
+    dim3 g2((unsigned)((per + 255) / 256), (unsigned)q.B);
+    hipLaunchKernelGGL((splitk_reduce_kernel<DT>), g2, dim3(256), 0, q.st, part, q.C, q.B, KS, q.M, q.N,
+                       (long long)q.sCb, (int)q.sCm, q.out_dtype == BD_F32 ? 1 : 0, accumulate);
+}
+
 template <int DT, int BM>
 int launch_fused_splitk_bm(const Problem& q, int KS) {
     const int64_t need = GEMV_TICKET_BYTES + (int64_t)q.B * KS * q.M * q.N * 4;
@@ -976,10 +999,7 @@ int launch_fused_splitk_bm(const Problem& q, int KS) {
     if (!ensure_dyn_lds((const void*)kern, Cfg::LDS_BYTES, lds_done)) return BD_E_LAUNCH;
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)(q.B * KS));
     hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, q.st, p);
-    const long long per = (long long)q.M * q.N / 4;
-    dim3 g2((unsigned)((per + 255) / 256), (unsigned)q.B);
-    hipLaunchKernelGGL((splitk_reduce_kernel<DT>), g2, dim3(256), 0, q.st, (const float*)part, q.C, q.B, KS, q.M, q.N,
-                       (long long)q.sCb, (int)q.sCm, q.out_dtype == BD_F32 ? 1 : 0);
+    launch_splitk_reduce<DT>(q, part, KS, 0);
     return launch_status();
 }
 // up to 64 rows per mask: 64-row tiles (half the MFMA / LDS work of a padded 128-row tile)
@@ -1029,17 +1049,14 @@ int launch_pair_splitk(const Problem& q, int KS) {
     if (!ensure_dyn_lds((const void*)kern, Cfg::LDS_BYTES, lds_done)) return BD_E_LAUNCH;
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)(((q.B + 1) / 2) * KS));
     hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, q.st, p);
-    const long long per = (long long)q.M * q.N / 4;
-    dim3 g2((unsigned)((per + 255) / 256), (unsigned)q.B);
-    hipLaunchKernelGGL((splitk_reduce_kernel<DT>), g2, dim3(256), 0, q.st, (const float*)part, q.C, q.B, KS, q.M, q.N,
-                       (long long)q.sCb, (int)q.sCm, q.out_dtype == BD_F32 ? 1 : 0, q.accumulate);
+    launch_splitk_reduce<DT>(q, part, KS, q.accumulate);
     return launch_status();
 }
 
 // four-wave PAIR tiles (W4Cfg PAIR = 1): two batch entries of <= 64 rows per 128 x 128 tile, persistent over (pair, column tile)
-template <int DT, bool OUT_F32>
+template <int DT, bool OUT_F32, int EPI = 0>
 int launch_w4_pair(const Problem& q) {
-    using Cfg = W4Cfg<DT, 128, 128, true, OUT_F32, 1 | 8192, 0, 1>;
+    using Cfg = W4Cfg<DT, 128, 128, true, OUT_F32, 1 | 8192, EPI, 1>;
     GemmParams p = make_params(q, Cfg::BM, Cfg::BN);          // tiles_m = 1: the tile's two wave rows are two batch entries
     p.nent = q.B; p.nbatch = (q.B + 1) / 2;
     auto kern = delta_gemm_w4_kernel<Cfg>;
@@ -1071,10 +1088,7 @@ int launch_w4_pair_splitk(const Problem& q, int KS) {
     const long long total = (long long)p.tiles_n * p.nbatch, cus = num_cus();
     dim3 grid((unsigned)(total < cus ? total : cus));
     hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, q.st, p);
-    const long long per = (long long)q.M * q.N / 4;
-    dim3 g2((unsigned)((per + 255) / 256), (unsigned)q.B);
-    hipLaunchKernelGGL((splitk_reduce_kernel<DT>), g2, dim3(256), 0, q.st, (const float*)part, q.C, q.B, KS, q.M, q.N,
-                       (long long)q.sCb, (int)q.sCm, q.out_dtype == BD_F32 ? 1 : 0, q.accumulate);
+    launch_splitk_reduce<DT>(q, part, KS, q.accumulate);
     return launch_status();
 }
 
@@ -1091,9 +1105,9 @@ int dispatch3(const Problem& q) {
         if (q.mask_tiled != 2 || !q.W) return BD_E_BAD_SHAPE;     // stream path picks it up (launch_gemv_stream_chunk, ring_wanted)
         v = 600;
     }
-    if (q.epilogue == 1 && q.M > GEMV_MAX_M) {        // prefill-size SwiGLU launch (bd_binary_linear_swiglu): one kernel can do it
-        if (v >= 0 && v != 15) return BD_E_BAD_SHAPE;
-        v = 15;
+    if (q.epilogue == 1 && q.M > GEMV_MAX_M) {        // prefill-size SwiGLU launch (bd_binary_linear_swiglu): the four-wave kernel's 256 x 128 tile,
+        if (v >= 0 && v != 15 && v != 21) return BD_E_BAD_SHAPE;                  // or its pair tile for several entries of <= 64 rows (round 6)
+        if (v < 0) v = (FUSED && q.M <= 64 && q.B >= 2 && pair_ok(q)) ? 21 : 15;
     }
     if (v < 0) {
         if (gemv_ok(q)) v = 200;
@@ -1200,6 +1214,9 @@ int dispatch3(const Problem& q) {
         }
         case 18:     // FOUR-WAVE pair tiles (bd_gemm_w4.h PAIR): one wave per SIMD, wave tile 64 x 64, persistent over (pair, column tile)
             if constexpr (FUSED) { if (!pair_ok(q)) return BD_E_BAD_SHAPE; return launch_w4_pair<DT, OUT_F32>(q); }
+            else return BD_E_BAD_SHAPE;
+        case 21:     // 18 with the SwiGLU epilogue: the gate|up projection of a multi-tenant request of short prompts (6 x 64 rows), no [M, 2 I] round trip
+            if constexpr (FUSED && !OUT_F32) { if (!pair_ok(q) || q.epilogue != 1) return BD_E_BAD_SHAPE; return launch_w4_pair<DT, false, 1>(q); }
             else return BD_E_BAD_SHAPE;
         case 20:     // four-wave fused 128x128 tile, ONE batch entry per tile (prompts of 65 .. 128 rows per tenant; W4Cfg TM = 2, PAIR = 0)
             if constexpr (FUSED) return launch_w4<W4Cfg<DT, 128, 128, true, OUT_F32, 1 | 8192, 0, 0>>(q);
@@ -1366,7 +1383,8 @@ static int binary_linear_impl(const void* X, const void* W, const int32_t* P, co
                               int64_t sYb, int64_t sYm, int dtype, int out_dtype, int accumulate, int mask_tiled, int t_pad,
                               void* ws, int64_t ws_bytes, void* stream, const void* norm_w = nullptr, int64_t sNw = 0,
                               float eps = 0.f, int epilogue = 0, const float* ssq_in = nullptr, float* ssq_out = nullptr,
-                              void* xw_out = nullptr) {
+                              void* xw_out = nullptr, const void* pn_w = nullptr, int64_t s_pnw = 0, float pn_eps = 0.f, void* pn_h = nullptr,
+                              int64_t sHb = 0, int64_t sHm = 0) {
     if (B > 0 && M > 0 && N > 0 && !W) return BD_E_NULL;
     Problem q{};
     q.A = X; q.P = P; q.C = Y; q.W = W; q.alpha = alpha;
@@ -1381,6 +1399,7 @@ static int binary_linear_impl(const void* X, const void* W, const int32_t* P, co
         q.ldw = K;            // (extent checks below; the kernel does not use it)
     }
     q.norm_w = norm_w; q.sNw = sNw; q.eps = eps; q.epilogue = epilogue;
+    q.pn_w = pn_w; q.s_pnw = s_pnw; q.pn_eps = pn_eps; q.pn_h = pn_h; q.sHb = sHb; q.sHm = sHm;
     q.ssq_in = ssq_in; q.ssq_out = ssq_out;
     if (ssq_in || ssq_out || xw_out) {
         // RMSNorm hand-off (gemv_stream_kernel, StreamParams::ssq_in / ssq_out / xw_out): packed layout, one row per tenant, <= 8 tenants
@@ -1491,6 +1510,28 @@ extern "C" int bd_binary_linear_residual(const void* X, const void* W, const int
                                          int64_t ws_bytes, void* stream) {
     return binary_linear_impl(X, W, P, alpha, Y, B, M, N, K, sXb, sXm, ldw, sPb, sAlb, G, sYb, sYm, dtype, out_dtype, 1, 0, 0, ws,
                               ws_bytes, stream);
+}
+
+// residual Linear + the RMSNorm that follows it (prefill sizes: the o / down projections of a decoder layer and the norm in front of the next
+// Linear).  The norm rides on the split-k reduce launch when the dispatcher splits (the multi-tenant request of short prompts); otherwise it is
+// the ordinary per-tenant norm launch behind the Linear -- the same arithmetic either way.
+extern "C" int bd_binary_linear_residual_norm(const void* X, const void* W, const int32_t* P, const float* alpha, void* Y, int B, int M, int N,
+                                              int K, int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb, int64_t sAlb, int G, int64_t sYb,
+                                              int64_t sYm, int dtype, const void* norm_w, int64_t s_nw, float eps, void* H, int64_t sHb,
+                                              int64_t sHm, void* ws, int64_t ws_bytes, void* stream) {
+    if (B < 0 || M < 0 || N < 0) return BD_E_BAD_SHAPE;
+    if (dtype != BD_F16 && dtype != BD_BF16) return BD_E_BAD_DTYPE;
+    if (B == 0 || M == 0 || N == 0) return BD_OK;
+    if (!norm_w || !H || !Y) return BD_E_NULL;
+    // the norm kernels' envelope: whole 16-byte chunks, rows of at most 8192 columns (both norm forms), dense [B, M] row grid for the fallback launch
+    if (M <= GEMV_MAX_M || N % 8 || N > 8192 || sYm % 8 || sYb % 8 || sHm % 8 || sHb % 8 || s_nw % 8 || s_nw < 0 || !aligned16(Y) || !aligned16(H) ||
+        !aligned16(norm_w) || sYb != (int64_t)M * sYm || sHb != (int64_t)M * sHm)
+        return BD_E_BAD_SHAPE;
+    t_post_norm_done = 0;
+    const int rc = binary_linear_impl(X, W, P, alpha, Y, B, M, N, K, sXb, sXm, ldw, sPb, sAlb, G, sYb, sYm, dtype, dtype, 1, 0, 0, ws, ws_bytes,
+                                      stream, nullptr, 0, 0.f, 0, nullptr, nullptr, nullptr, norm_w, s_nw, eps, H, sHb, sHm);
+    if (rc != BD_OK || t_post_norm_done) return rc;
+    return bd_srv_rmsnorm(Y, norm_w, H, B * M, N, sYm, sHm, s_nw, M, eps, dtype, stream);
 }
 
 // ------------------------------------------------------------------ per-tenant dense Linear (serving: lm_head per tenant)
@@ -1623,6 +1664,27 @@ extern "C" int bd_srv_rope(void* X, const void* cos_t, const void* sin_t, int ro
     else
         hipLaunchKernelGGL((rope_kernel<DT_F16>), dim3(rows), dim3(256), 0, st, (unsigned short*)X, (const unsigned short*)cos_t,
                            (const unsigned short*)sin_t, heads, (long long)sx, seq, pos0);
+    return launch_status();
+}
+
+extern "C" int bd_srv_rope_kv_append(void* QKV, const void* cos_t, const void* sin_t, void* kcache, void* vcache, int T, int S, int H, int KVH,
+                                     int head_dim, int64_t sx, int Lc, int pos0, int dtype, void* stream) {
+    if (T < 0 || S < 0 || H < 1 || KVH < 1 || pos0 < 0 || Lc < 1) return BD_E_BAD_SHAPE;
+    if (dtype != BD_F16 && dtype != BD_BF16) return BD_E_BAD_DTYPE;
+    if (T == 0 || S == 0) return BD_OK;
+    if (!QKV || !cos_t || !sin_t || !kcache || !vcache) return BD_E_NULL;
+    if (head_dim != 128 || sx % 8 || sx < (int64_t)(H + 2 * KVH) * 128 || (int64_t)pos0 + S > Lc || (int64_t)T * S >= (1ll << 31) ||
+        !aligned16(QKV) || !aligned16(cos_t) || !aligned16(sin_t) || !aligned16(kcache) || !aligned16(vcache))
+        return BD_E_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == BD_BF16)
+        hipLaunchKernelGGL((rope_kv_append_kernel<DT_BF16>), dim3((unsigned)(T * S)), dim3(256), 0, st, (unsigned short*)QKV,
+                           (const unsigned short*)cos_t, (const unsigned short*)sin_t, (unsigned short*)kcache, (unsigned short*)vcache, H, KVH,
+                           (long long)sx, S, pos0, Lc);
+    else
+        hipLaunchKernelGGL((rope_kv_append_kernel<DT_F16>), dim3((unsigned)(T * S)), dim3(256), 0, st, (unsigned short*)QKV,
+                           (const unsigned short*)cos_t, (const unsigned short*)sin_t, (unsigned short*)kcache, (unsigned short*)vcache, H, KVH,
+                           (long long)sx, S, pos0, Lc);
     return launch_status();
 }
 

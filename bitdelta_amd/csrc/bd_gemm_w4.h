@@ -52,7 +52,7 @@ struct W4Cfg {
     static constexpr int WAVES_M = 2, WAVES_N = 2, NW = 4, NT = 256;
     static constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     static constexpr int NB = 4;                                   // B-operand fragments per k-step (delta: 4 S; fused: W0 S0 W1 S1)
-    static_assert((TM == 4 || (TM == 2 && FUSED && EPI_ == 0)) && (!PAIR || TM == 2) && (FUSED ? TN == 2 : TN == 4), "wave tile: 4 B fragments x 4 row blocks (128-row fused tiles: 2)");
+    static_assert((TM == 4 || (TM == 2 && FUSED && (EPI_ == 0 || PAIR_))) && (!PAIR || TM == 2) && (FUSED ? TN == 2 : TN == 4), "wave tile: 4 B fragments x 4 row blocks (128-row fused tiles: 2)");
     static constexpr int NENT = PAIR ? 2 : 1;                      // batch entries per tile (one per wave row)
     static constexpr int A_BYTES = BM * 128, W_BYTES = FUSED ? BN * 128 : 0, BW_BYTES = BN * 8 * NENT;
     static constexpr int BW_OFF = A_BYTES + W_BYTES;

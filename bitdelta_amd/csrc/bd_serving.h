@@ -132,6 +132,70 @@ __global__ void __launch_bounds__(256) add_rmsnorm_kernel(const unsigned short* 
     }
 }
 
+// Split-k reduce + residual + the NEXT RMSNorm in ONE launch (round 6; the multi-tenant prefill of short prompts: the o / down pair tiles of a
+// 6 x 64-row request are split over k, and the layer ran splitk_reduce_kernel (5.7 us) and then rmsnorm_rows_kernel (7.5 us) on the same 384 rows).
+// Arithmetic of the two launches, in their order: s = ((0 + part[0]) + part[1]) + ... in slice order, x = round16(round16(s) + residual) (or
+// round16(s) without a residual), then rmsnorm_tenant_kernel's two passes on x, which stays in registers.  ws [B][KS][M][N] fp32; C (residual in,
+// x out) [B][M][N] with strides sCb / sCm; h [B][M][N] with strides sHb / sHm; w [B][N] (stride sw).  One 256-thread block per row; N % 8 == 0,
+// N <= 8192.
+template <int DT>
+__global__ void __launch_bounds__(256) splitk_reduce_norm_kernel(const float* __restrict__ ws, unsigned short* __restrict__ C,
+                                                                 const unsigned short* __restrict__ w, unsigned short* __restrict__ h_out, int KS,
+                                                                 int M, int N, long long sCb, long long sCm, long long sHb, long long sHm,
+                                                                 long long sw, int accumulate, float eps) {
+    __shared__ float part[4];
+    const int b = blockIdx.x / M, m = blockIdx.x - b * M;
+    const float* slab = ws + ((long long)b * KS * M + m) * N;           // slice k of this row: slab + k * M * N
+    unsigned short* cr = C + (long long)b * sCb + (long long)m * sCm;
+    const unsigned short* wr = w + (long long)b * sw;
+    u32x4_t xs[4];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = threadIdx.x * 8 + 2048 * i;
+        xs[i] = u32x4_t{0u, 0u, 0u, 0u};
+        if (c < N) {
+            f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+            for (int k0 = 0; k0 < KS; k0 += 4) {                        // four slices' loads in flight, then their adds in slice order
+                f32x4_t va[4], vb[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float* q = slab + (long long)min(k0 + j, KS - 1) * M * N + c;
+                    va[j] = *(const f32x4_t*)q;
+                    vb[j] = *(const f32x4_t*)(q + 4);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (k0 + j < KS) { sa += va[j]; sb += vb[j]; }
+            }
+            u32x4_t rv = {0u, 0u, 0u, 0u};
+            if (accumulate) rv = *(const u32x4_t*)(cr + c);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const float y0 = d < 2 ? sa[2 * d] : sb[2 * d - 4], y1 = d < 2 ? sa[2 * d + 1] : sb[2 * d - 3];
+                uint32_t lo = f32_to_half_bits<DT>(y0), hi = f32_to_half_bits<DT>(y1);
+                if (accumulate) {
+                    lo = f32_to_half_bits<DT>(half_bits_to_f32<DT>(lo) + half_bits_to_f32<DT>(rv[d] & 0xffffu));
+                    hi = f32_to_half_bits<DT>(half_bits_to_f32<DT>(hi) + half_bits_to_f32<DT>(rv[d] >> 16));
+                }
+                xs[i][d] = lo | (hi << 16);
+            }
+            *(u32x4_t*)(cr + c) = xs[i];
+            ss = sumsq8<DT>(xs[i], ss);
+        }
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float rs = rms_scale(part[0], part[1], part[2], part[3], N, eps);
+    unsigned short* hr = h_out + (long long)b * sHb + (long long)m * sHm;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = threadIdx.x * 8 + 2048 * i;
+        if (c < N) *(u32x4_t*)(hr + c) = norm8<DT>(xs[i], *(const u32x4_t*)(wr + c), rs);
+    }
+}
+
 // The same norm for MANY rows (prefill: hundreds to thousands of rows): ONE WAVE per row, four rows per block, the row held in registers between
 // the two passes -- no block barrier, no second read of x.  Bit-identical to rmsnorm_tenant_kernel: lane l plays that kernel's threads l, l + 64,
 // l + 128, l + 192 (its four waves), so the four per-wave sums are formed by the same lanes in the same order and meet in rms_scale as before.
@@ -228,6 +292,57 @@ __global__ void __launch_bounds__(256) rope_kernel(unsigned short* __restrict__ 
         }
         *(u32x4_t*)(px + d0) = ol;
         *(u32x4_t*)(px + 64 + d0) = oh;
+    }
+}
+
+// Prefill RoPE + KV-cache append in ONE launch (round 6): rope_kernel on the q and k heads of the fused q|k|v projection output [T * S, (H + 2 KVH) *
+// 128] (in place -- the prefill attention kernel reads q / k / v from that buffer), and the rotated k rows and the v rows of every token also go to
+// the caches [T, KVH, Lc, 128] at positions pos0 .. pos0 + S - 1: the two strided torch copies `cache[:, :, :S] = k.transpose(1, 2)` (6.3 + 5.6 us
+// per layer on a 6 x 64-token request) ride on a launch that already has the rows in registers.  One block per token row.
+template <int DT>
+__global__ void __launch_bounds__(256) rope_kv_append_kernel(unsigned short* __restrict__ x, const unsigned short* __restrict__ cos_t,
+                                                             const unsigned short* __restrict__ sin_t, unsigned short* __restrict__ kc,
+                                                             unsigned short* __restrict__ vc, int H, int KVH, long long sx, int seq, int pos0,
+                                                             int Lc) {
+    const int r = blockIdx.x, t = r / seq;
+    const long long pos = pos0 + (r - t * seq);
+    const unsigned short* cs = cos_t + pos * 128;
+    const unsigned short* sn = sin_t + pos * 128;
+    unsigned short* row = x + (long long)r * sx;
+    const int nrope = (H + KVH) * 8, ntot = nrope + KVH * 16;
+    for (int i = threadIdx.x; i < ntot; i += 256) {
+        if (i >= nrope) {                                               // v head (i - nrope) / 16, 16-byte chunk (i - nrope) % 16: copy
+            const int j = i - nrope, hv = j >> 4, d0 = (j & 15) * 8;
+            *(u32x4_t*)(vc + (((long long)t * KVH + hv) * Lc + pos) * 128 + d0) = *(const u32x4_t*)(row + (long long)(H + KVH + hv) * 128 + d0);
+            continue;
+        }
+        const int h = i >> 3, d0 = (i & 7) * 8;
+        unsigned short* px = row + h * 128;
+        const u32x4_t lo = *(const u32x4_t*)(px + d0), hi = *(const u32x4_t*)(px + 64 + d0);
+        const u32x4_t cl = *(const u32x4_t*)(cs + d0), ch = *(const u32x4_t*)(cs + 64 + d0);
+        const u32x4_t sl = *(const u32x4_t*)(sn + d0), sh = *(const u32x4_t*)(sn + 64 + d0);
+        u32x4_t ol, oh;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            uint32_t rl = 0, rh = 0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int shf = 16 * e;
+                const float a = half_bits_to_f32<DT>((lo[d] >> shf) & 0xffffu), b = half_bits_to_f32<DT>((hi[d] >> shf) & 0xffffu);
+                const float c0 = half_bits_to_f32<DT>((cl[d] >> shf) & 0xffffu), c1 = half_bits_to_f32<DT>((ch[d] >> shf) & 0xffffu);
+                const float s0 = half_bits_to_f32<DT>((sl[d] >> shf) & 0xffffu), s1 = half_bits_to_f32<DT>((sh[d] >> shf) & 0xffffu);
+                rl |= f32_to_half_bits<DT>(round16<DT>(a * c0) + b * s0) << shf;
+                rh |= f32_to_half_bits<DT>(round16<DT>(b * c1) + a * s1) << shf;
+            }
+            ol[d] = rl; oh[d] = rh;
+        }
+        *(u32x4_t*)(px + d0) = ol;
+        *(u32x4_t*)(px + 64 + d0) = oh;
+        if (h >= H) {
+            unsigned short* pk = kc + (((long long)t * KVH + (h - H)) * Lc + pos) * 128;
+            *(u32x4_t*)(pk + d0) = ol;
+            *(u32x4_t*)(pk + 64 + d0) = oh;
+        }
     }
 }
 

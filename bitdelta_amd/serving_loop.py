@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .binary_gemm_kernel import (binary_linear, binary_linear_swiglu, binary_linear_decode, decode_shape_ok, fused_norm_ok, handoff_ok,
+from .binary_gemm_kernel import (binary_linear, binary_linear_residual_norm, binary_linear_swiglu, binary_linear_decode, decode_shape_ok, fused_norm_ok, handoff_ok,
                                  pack_decode_masks, tenant_linear, tile_weight)
 from .diff import binarize
 from . import serving_ops as ops
@@ -138,6 +138,19 @@ class FusedDeltaLinear(nn.Module):
         assert ssq_out is None and xw_out is None
         return binary_linear(x, self.weight, self.mask, self.alpha, groups=self.groups, residual=residual, out_dtype=out_dtype, out=out)
 
+    def residual_norm_ok(self, x, residual):
+        """forward_residual_norm can take this input: prefill rows on the fused GEMM's fast path, the residual stream contiguous, rows the norm
+        kernels take whole (N % 8 == 0, N <= 8192)"""
+        B, M, K = x.shape
+        N = self.weight.shape[0]
+        return (M > 16 and K % 64 == 0 and N % 8 == 0 and N <= 8192 and x.stride(2) == 1 and x.data_ptr() % 16 == 0 and x.stride(0) % 8 == 0 and
+                x.stride(1) % 8 == 0 and residual.is_contiguous() and self.mask.shape[0] in (1, B))
+
+    def forward_residual_norm(self, x, residual, norm_weight, eps):
+        """(residual + Linear(x), rmsnorm_tenant(of that, norm_weight)): the residual Linear of a decoder layer and the norm in front of the next
+        Linear, one launch fewer when the Linear is split over k (bd_binary_linear_residual_norm); bit-identical to the two calls"""
+        return binary_linear_residual_norm(x, self.weight, self.mask, self.alpha, residual, norm_weight, eps, groups=self.groups)
+
     def handoff_producer_ok(self, x):
         """this (residual) Linear can leave the sums of squares of its output behind: decode shape, one row per tenant, tile-major weight"""
         return (self._decode_ok(x) and x.shape[1] == 1 and x.shape[0] <= 8 and self.weight.shape[0] % 16 == 0 and
@@ -227,7 +240,10 @@ class TenantDecoder(nn.Module):
         self.register_buffer("sin", sin, persistent=False)
         self._graph = None
         self.fast_glue = True       # decode steps use the HIP glue kernels (serving_ops); False = stock torch ops everywhere
-        self.swiglu_epilogue = False  # prefill: SwiGLU inside the gate|up GEMM (256-row tiles only; measured slower than GEMM + one pass)
+        self.swiglu_epilogue = False  # prefill: SwiGLU inside the gate|up GEMM (256-row tiles from 256 rows per tenant, pair tiles for <= 64-row
+                                      # prompts): measured slower than GEMM + one pass both times (6 x 64 rows: gate|up 162 -> 186 us against a 9-us pass)
+        self.short_prompt_fusions = True   # multi-tenant prefill of short prompts (round 6): RoPE + KV-cache append in one launch; <= 64 rows per
+                                           # tenant: the norms ride on the split-k reduce launches of o / down
         self.hip_prefill_attention = True      # prefill: RoPE + flash-style attention kernels instead of torch SDPA over a [L, Lc] mask
         self.fuse_glue = True       # ... and fold RMSNorm / SwiGLU into the Linear launches where the shapes allow (bit-identical)
         # Which glue is folded where, by same-process A/B of the whole step (ms per step, Mistral-7B x 6, tile-major weights).  Round 2
@@ -351,9 +367,11 @@ class TenantDecoder(nn.Module):
             setattr(layer, key, v)
         return v
 
-    def _layer(self, layer, x, cos, sin, cache, li, pos_idx, attn_mask, ssq_valid=False, next_layer=None):
+    def _layer(self, layer, x, cos, sin, cache, li, pos_idx, attn_mask, ssq_valid=False, next_layer=None, h_in=None):
         """one decoder layer; returns (x, ssq_valid): whether self._ssq / self._xw hold the partial sums of squares of the returned x and its
-        copy pre-multiplied by the NEXT layer's input norm weight (next_layer; None after the last layer) -- both in handoff_norm's scaled form"""
+        copy pre-multiplied by the NEXT layer's input norm weight (next_layer; None after the last layer) -- both in handoff_norm's scaled form.
+        h_in: norm1 of x when the previous layer's down projection already produced it (prefill, forward_residual_norm); the third return value is
+        that tensor for the next layer (or None)."""
         T, S, hid = x.shape
         _, inter, _, heads, kvh, _ = self.cfg
         hd = self.hd
@@ -368,8 +386,10 @@ class TenantDecoder(nn.Module):
         elif fuse and self.fuse_qkv_norm and layer.qkv.fusable(x):
             qkv = layer.qkv.forward_fused(x, layer.norm1, self.eps)              # RMSNorm in the Linear's prologue: one launch
         else:
-            qkv = layer.qkv(self._norm(x, layer.norm1))
+            qkv = layer.qkv(h_in if h_in is not None else self._norm(x, layer.norm1))
         ck, cv = cache["k"][li], cache["v"][li]
+        short = S > 1 and self.fast_glue and self.short_prompt_fusions
+        pairs = short and S <= 64 and T >= 2                                 # the request runs on pair tiles (two tenants per 128-row tile)
         pf = None
         if S == 1 and self.fast_glue and self.prefetch_o and layer.o.mask_packed is not None:
             # fork: the prefetch depends on nothing the layer computes; it is ordered behind the q|k|v launch only so that it runs next to attention
@@ -389,11 +409,15 @@ class TenantDecoder(nn.Module):
             # left-padded prompts (keys kv_start[t] .. query position), then the K / V rows go into the cache
             nq, nk = heads * hd, kvh * hd
             qf, kf, vf = qkv[..., :nq], qkv[..., nq:nq + nk], qkv[..., nq + nk:]
-            ops.rope_(qkv[..., :nq + nk], self.cos, self.sin, heads + kvh, S, 0)          # q and k heads: one launch
             k4, v4 = kf.view(T, S, kvh, hd), vf.view(T, S, kvh, hd)
-            a = ops.prefill_attention(qf.view(T, S, heads, hd), k4, v4, kv_start=cache["kv_start"], causal=True)
-            ck[:, :, :S] = k4.transpose(1, 2)
-            cv[:, :, :S] = v4.transpose(1, 2)
+            if short and ck.is_contiguous() and cv.is_contiguous():
+                ops.rope_kv_append_(qkv, self.cos, self.sin, ck, cv, heads, kvh, 0)       # RoPE of q and k + both cache writes: one launch
+                a = ops.prefill_attention(qf.view(T, S, heads, hd), k4, v4, kv_start=cache["kv_start"], causal=True)
+            else:
+                ops.rope_(qkv[..., :nq + nk], self.cos, self.sin, heads + kvh, S, 0)      # q and k heads: one launch
+                a = ops.prefill_attention(qf.view(T, S, heads, hd), k4, v4, kv_start=cache["kv_start"], causal=True)
+                ck[:, :, :S] = k4.transpose(1, 2)
+                cv[:, :, :S] = v4.transpose(1, 2)
         else:
             q, k, v = layer.qkv.split(qkv)
             q = _rope(q.view(T, S, heads, hd).transpose(1, 2), cos, sin)
@@ -407,9 +431,18 @@ class TenantDecoder(nn.Module):
             torch.cuda.current_stream(x.device).wait_stream(pf)           # join before the o projection
         o_hand = handoff and layer.o.handoff_producer_ok(a) and layer.gate_up.handoff_consumer_ok(x, swiglu=True)
         n2h, s2 = self._hn(layer, "norm2") if o_hand else (None, 1.0)
-        x = layer.o(a, residual=x, ssq_out=self._ssq if o_hand else None, next_norm=n2h, xw_out=self._xw if o_hand else None,
-                    ssq_scale=1.0 / (s2 * s2))
-        if o_hand:
+        h2 = None
+        if pairs and layer.o.residual_norm_ok(a, x):
+            x, h2 = layer.o.forward_residual_norm(a, x, layer.norm2, self.eps)    # o + residual, norm2 on its split-k reduce launch
+        else:
+            x = layer.o(a, residual=x, ssq_out=self._ssq if o_hand else None, next_norm=n2h, xw_out=self._xw if o_hand else None,
+                        ssq_scale=1.0 / (s2 * s2))
+        if h2 is not None:
+            if self.swiglu_epilogue and layer.gate_up.swiglu_ok(h2):
+                act = layer.gate_up.forward_swiglu(h2)                            # gate|up -> SwiGLU in the pair tile's epilogue (A/B: slower)
+            else:
+                act = ops.swiglu_interleaved8(layer.gate_up(h2)) if layer.gate_up.interleave8 else ops.swiglu(layer.gate_up(h2), inter)
+        elif o_hand:
             act = layer.gate_up.forward_fused(self._xw, None, self.eps / (s2 * s2), swiglu=True, ssq_in=self._ssq)   # (RMSNorm by hand-off) gate|up -> SwiGLU
         elif fuse and self.fuse_gateup_norm and layer.gate_up.fusable(x, swiglu=True):
             act = layer.gate_up.forward_fused(x, layer.norm2, self.eps, swiglu=True)   # RMSNorm -> gate|up -> SwiGLU: one launch
@@ -427,9 +460,12 @@ class TenantDecoder(nn.Module):
                 act = F.silu(g) * u
         d_hand = handoff and next_layer is not None and layer.down.handoff_producer_ok(act) and layer.qkv.handoff_consumer_ok(x)
         n1h, s1n = self._hn(next_layer, "norm1") if d_hand else (None, 1.0)
+        if h2 is not None and next_layer is not None and layer.down.residual_norm_ok(act, x):
+            x, h_next = layer.down.forward_residual_norm(act, x, next_layer.norm1, self.eps)   # down + residual, the NEXT layer's norm1 on its reduce
+            return x, False, h_next
         x = layer.down(act, residual=x, ssq_out=self._ssq if d_hand else None, next_norm=n1h, xw_out=self._xw if d_hand else None,
                        ssq_scale=1.0 / (s1n * s1n))
-        return x, d_hand
+        return x, d_hand, None
 
     @torch.no_grad()
     def forward(self, ids, pos_idx, cache, attn_mask):
@@ -440,9 +476,10 @@ class TenantDecoder(nn.Module):
         t_idx = torch.arange(T, device=ids.device).view(T, 1)
         x = self.embed[t_idx, ids]                                            # per-tenant embedding: one gather
         ssq_valid = False                                                     # (the embedding rows have no producer launch: layer 0 norms itself)
+        h_in = None
         for li, layer in enumerate(self.layers):
             nxt = self.layers[li + 1] if li + 1 < len(self.layers) else None
-            x, ssq_valid = self._layer(layer, x, cos, sin, cache, li, pos_idx, attn_mask, ssq_valid, nxt)
+            x, ssq_valid, h_in = self._layer(layer, x, cos, sin, cache, li, pos_idx, attn_mask, ssq_valid, nxt, h_in)
         last = self._norm(x[:, -1:, :], self.final_norm)
         return tenant_linear(last, self.lm_head)[:, 0, :]                     # per-tenant lm_head: one launch
 

@@ -145,3 +145,20 @@ def rope_(x, cos, sin, heads, seq, pos0=0):
         check(lib().bd_srv_rope(ptr(x), ptr(cos), ptr(sin), x.shape[0] * x.shape[1], heads, 128, x.stride(1), seq, pos0,
                                 DTYPE_CODE[x.dtype], stream_ptr()), "srv_rope")
     return x
+
+
+def rope_kv_append_(qkv, cos, sin, kcache, vcache, heads, kvh, pos0=0):
+    """Prefill from position pos0: rope_ on the q and k heads of the fused projection output qkv [T, S, (heads + 2 kvh) * 128] (in place) and, in the
+    same launch, the rotated k rows and the v rows into the caches [T, kvh, Lc, 128] at positions pos0 .. pos0 + S - 1 (what
+    `kcache[:, :, pos0:pos0 + S] = k.transpose(1, 2)` and its v twin do after rope_).  Returns qkv."""
+    require_gpu(qkv, cos, sin, kcache, vcache)
+    T, S, W = qkv.shape
+    assert W == (heads + 2 * kvh) * 128 and qkv.stride(2) == 1 and (T == 1 or qkv.stride(0) == S * qkv.stride(1))
+    assert cos.is_contiguous() and sin.is_contiguous() and cos.dtype == qkv.dtype and cos.shape[0] >= pos0 + S
+    Lc = kcache.shape[2]
+    assert kcache.shape == (T, kvh, Lc, 128) and vcache.shape == kcache.shape and kcache.is_contiguous() and vcache.is_contiguous()
+    assert kcache.dtype == qkv.dtype and vcache.dtype == qkv.dtype and pos0 + S <= Lc
+    with torch.cuda.device(qkv.device):
+        check(lib().bd_srv_rope_kv_append(ptr(qkv), ptr(cos), ptr(sin), ptr(kcache), ptr(vcache), T, S, heads, kvh, 128, qkv.stride(1), Lc, pos0,
+                                          DTYPE_CODE[qkv.dtype], stream_ptr()), "srv_rope_kv_append")
+    return qkv

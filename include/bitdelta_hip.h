@@ -165,6 +165,21 @@ int bd_binary_linear_residual(const void* X, const void* W, const int32_t* P, co
                               int64_t sYb, int64_t sYm, int dtype, int out_dtype,
                               void* ws, int64_t ws_bytes, void* stream);
 
+/* bd_binary_linear_residual at prefill sizes (M > 16) TOGETHER WITH the RMSNorm that follows it in the decoder layer (round 6):
+ *   Y[b] = Y_in[b] + Linear(X[b]);   H[b] = norm_w[b] * round(Y[b] * rsqrt(mean(Y[b]^2) + eps))     (bd_srv_rmsnorm's arithmetic, tenant b's weight)
+ * -- `hidden = residual + o_proj(attn); h = post_attention_layernorm(hidden)` (and down_proj + the next layer's input_layernorm) of the HF decoder
+ * layers whose Linears are the reference's BinaryDiff modules (bitdelta/diff.py:38-39) and whose norms are DataParallelModule-wrapped
+ * (demo/demo_backend.py:62-79).  When the dispatcher splits the Linear over k (several tenants of <= 64 rows: the o / down projections of a
+ * short-prompt request) the norm rides on the reduce launch; otherwise it is one norm launch behind the Linear.  Bit-identical to
+ * bd_binary_linear_residual followed by bd_srv_rmsnorm either way.  Y, H [B, M, N] dense in M (sYb = M sYm, sHb = M sHm), N % 8 == 0,
+ * N <= 8192, 16-byte aligned rows; norm_w [B, N] (stride s_nw; 0 = one weight for all).  Anything else: BD_E_BAD_SHAPE. */
+int bd_binary_linear_residual_norm(const void* X, const void* W, const int32_t* P, const float* alpha, void* Y,
+                                   int B, int M, int N, int K,
+                                   int64_t sXb, int64_t sXm, int64_t ldw, int64_t sPb, int64_t sAlb, int G,
+                                   int64_t sYb, int64_t sYm, int dtype,
+                                   const void* norm_w, int64_t s_nw, float eps, void* H, int64_t sHb, int64_t sHm,
+                                   void* ws, int64_t ws_bytes, void* stream);
+
 /* per-tenant dense Linear at decode: replaces the weight-swapping loop of DataParallelModule.forward
  * (demo/demo_backend.py:62-79) for nn.Linear leaves (lm_head): row block t runs through tenant t's OWN weight matrix,
  *   Y[t] = X[t] . W[t]^T,   X [T, M, K] (strides sXt, sXm), W [T, N, K] (strides sWt, ldw), Y [T, M, N] (strides sYt, sYm),
@@ -197,6 +212,12 @@ int bd_srv_swiglu(const void* G, const void* U, void* Y, int rows, int I, int64_
  * bd_srv_decode_attention; rounds where `torch.addcmul(x * cos, rotate_half(x), sin)` rounds. */
 int bd_srv_rope(void* X, const void* cos_t, const void* sin_t, int rows, int heads, int head_dim, int64_t sx, int seq, int pos0,
                 int dtype, void* stream);
+/* bd_srv_rope_kv_append (round 6): the prefill of a request from position pos0 -- bd_srv_rope on the q and k heads of the fused q|k|v projection
+ * output QKV [T * S, (H + 2 KVH) * 128] (row stride sx; in place: bd_srv_prefill_attention reads q / k / v from it), and in the same launch the
+ * rotated k rows and the v rows are written to the caches [T, KVH, Lc, 128] at positions pos0 .. pos0 + S - 1 (the `past_key_values` update of
+ * the HF attention module the reference's Linears sit in; demo/demo_backend.py:297-315 prefills through it).  pos0 + S <= Lc. */
+int bd_srv_rope_kv_append(void* QKV, const void* cos_t, const void* sin_t, void* kcache, void* vcache, int T, int S, int H, int KVH,
+                          int head_dim, int64_t sx, int Lc, int pos0, int dtype, void* stream);
 /* bd_srv_cache_warm (round 6): reads [p0, p0 + bytes0) and [p1, p1 + bytes1) (16-byte aligned; whole 16-byte chunks) and discards the values:
  * a weight-prefetch launch for a hipGraph side branch (the serving loop forks it next to the decode attention launch so that the o projection's
  * weight and sign words sit in the Infinity Cache when it starts).  blocks = 0: one 256-thread block per CU.  No reference counterpart (the

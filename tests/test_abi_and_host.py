@@ -121,6 +121,39 @@ def test_no_cpu_fallback():
         bd.BinaryDiff(torch.zeros(8, 32, dtype=torch.bfloat16), torch.zeros(8, 32, dtype=torch.bfloat16))
 
 
+def test_round6_entries_validate_their_arguments_before_any_device_work():
+    """bd_srv_rope_kv_append / bd_binary_linear_residual_norm return their error codes from the host-side checks (no launch, no GPU needed):
+    geometry, alignment, the cache bound pos0 + S <= Lc, decode-size rows, rows wider than the norm kernels take"""
+    import ctypes
+    from bitdelta_amd import _lib
+    L = _lib.lib()
+    buf = ctypes.create_string_buffer(1 << 16)
+    base = (ctypes.addressof(buf) + 255) & ~255                # an aligned, non-null host address: never dereferenced by the checks
+    BAD_SHAPE, BAD_DTYPE, NULL = (L.bd_srv_rope(None, None, None, -1, 1, 128, 0, 1, 0, 0, None),
+                                  L.bd_srv_rope(None, None, None, 1, 1, 128, 0, 1, 0, 7, None), L.bd_srv_rope(None, None, None, 1, 1, 128, 0, 1, 0, 0, None))
+    assert len({BAD_SHAPE, BAD_DTYPE, NULL, 0}) == 4
+    rk = L.bd_srv_rope_kv_append
+    W = (8 + 2 * 2) * 128
+    assert rk(base, base, base, base, base, 0, 64, 8, 2, 128, W, 64, 0, 1, None) == 0                  # empty request
+    assert rk(None, base, base, base, base, 2, 64, 8, 2, 128, W, 64, 0, 1, None) == NULL
+    assert rk(base, base, base, base, base, 2, 64, 8, 2, 64, W, 64, 0, 1, None) == BAD_SHAPE           # head_dim != 128
+    assert rk(base, base, base, base, base, 2, 64, 8, 2, 128, W - 128, 64, 0, 1, None) == BAD_SHAPE    # rows narrower than q|k|v
+    assert rk(base, base, base, base, base, 2, 64, 8, 2, 128, W, 64, 1, 1, None) == BAD_SHAPE          # pos0 + S > Lc
+    assert rk(base + 2, base, base, base, base, 2, 64, 8, 2, 128, W, 64, 0, 1, None) == BAD_SHAPE      # unaligned
+    assert rk(base, base, base, base, base, 2, 64, 8, 2, 128, W, 64, 0, 2, None) == BAD_DTYPE          # fp32
+    rn = L.bd_binary_linear_residual_norm
+    def call(B=2, M=64, N=4096, K=512, dtype=1, nw=base, h=base, sYm=None, sYb=None):
+        sYm = N if sYm is None else sYm
+        sYb = M * sYm if sYb is None else sYb
+        return rn(base, base, base, base, base, B, M, N, K, M * K, K, K, (K // 32) * N, 1, 1, sYb, sYm, dtype, nw, N, 1e-5, h, M * N, N, None, 0, None)
+    assert call(B=0) == 0
+    assert call(dtype=2) == BAD_DTYPE
+    assert call(nw=None) == NULL and call(h=None) == NULL
+    assert call(M=1) == BAD_SHAPE and call(M=16) == BAD_SHAPE                                          # decode rows: the hand-off entry's business
+    assert call(N=8200) == BAD_SHAPE and call(N=16384) == BAD_SHAPE                                    # wider than the norm kernels' rows
+    assert call(sYm=4100) == BAD_SHAPE and call(sYb=64 * 4096 + 8) == BAD_SHAPE                        # ragged / gapped residual rows
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "bitdelta_amd")
     for dirpath, _, files in os.walk(pkg):

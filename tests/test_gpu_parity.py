@@ -483,7 +483,8 @@ def test_prefill_swiglu_epilogue_is_the_two_launches(bd, oracle):
             f = FusedDeltaLinear(ws, ms, cs, interleave8=True, decode_copies=False)
             assert f.swiglu_ok(x.cuda())
             got = f.forward_swiglu(x.cuda())
-            assert L.bd_last_gemm_variant() == 15 and got.shape == (B, M, inter)
+            # (several entries of <= 64 rows: the pair tile with the same epilogue, round 6)
+            assert L.bd_last_gemm_variant() == (21 if (B >= 2 and M <= 64) else 15) and got.shape == (B, M, inter)
             two = ops.swiglu_interleaved8(f(x.cuda()))
             assert torch.equal(got, two)
             # oracle: the two projections separately, then round(silu(round(g))) * round(u)

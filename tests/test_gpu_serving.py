@@ -1191,3 +1191,136 @@ def test_add_rmsnorm_is_bit_identical_to_cast_add_norm(bd, dtype, T, M, H):
     v = x_ref.float()
     hf = (v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + 1e-5)).to(dtype) * w[:, None, :]
     assert torch.allclose(h.float(), hf.float(), rtol=2 ** -7 if dtype == torch.bfloat16 else 2 ** -10, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------ short-prompt prefill fusions (round 6)
+def _mt_linear(T, N, K, dtype, g, interleave8=False):
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.02).to(dtype)
+    mask = torch.randint(-2 ** 31, 2 ** 31 - 1, (T, K // 32, N), device="cuda", generator=g, dtype=torch.int64).to(torch.int32)
+    return w, mask
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T,M,N,K", [(6, 64, 4096, 4096), (6, 64, 4096, 14336), (5, 40, 4096, 4096), (2, 64, 2048, 2048), (6, 17, 1024, 512),
+                                     (3, 128, 4096, 4096), (6, 64, 8192, 1024), (1, 64, 4096, 4096)])
+def test_residual_linear_with_following_norm_is_bit_identical_to_the_two_launches(bd, oracle, dtype, T, M, N, K):
+    """bd_binary_linear_residual_norm: (residual + Linear(x), per-tenant RMSNorm of it) == bd_binary_linear_residual then bd_srv_rmsnorm, bit for
+    bit -- on the shapes whose Linear is split over k (the o / down projections of a 6-tenant request of <= 64-row prompts: the norm rides on the
+    reduce launch) and on shapes that are not split (the norm is its own launch behind the Linear); and the oracle's Linear on sampled columns."""
+    from bitdelta_amd import serving_ops as ops
+    from bitdelta_amd.binary_gemm_kernel import binary_linear_residual_norm
+    g = torch.Generator(device="cuda").manual_seed(T * 1000 + M + N + K)
+    x = torch.randn(T, M, K, device="cuda", generator=g).to(dtype)
+    w, mask = _mt_linear(T, N, K, dtype, g)
+    alpha = (torch.rand(T, 1, device="cuda", generator=g) * 1e-3 + 2e-4)
+    resid = torch.randn(T, M, N, device="cuda", generator=g).to(dtype)
+    nw = (1 + 0.1 * torch.randn(T, N, device="cuda", generator=g)).to(dtype)
+    r_ref = resid.clone()
+    bd.binary_linear(x, w, mask, alpha, residual=r_ref)
+    from bitdelta_amd import _lib
+    used_plain = _lib.lib().bd_last_gemm_variant()
+    h_ref = ops.rmsnorm_tenant(r_ref, nw, 1e-5)
+    r = resid.clone()
+    r2, h = binary_linear_residual_norm(x, w, mask, alpha, r, nw, 1e-5)
+    assert r2.data_ptr() == r.data_ptr()
+    assert torch.equal(r, r_ref), (used_plain, (r.float() - r_ref.float()).abs().max().item())
+    assert torch.equal(h, h_ref)
+    # the Linear itself against the oracle on a few columns of tenant 0 and the last tenant
+    cols = torch.tensor([0, 1, N // 2, N - 1])
+    ref = oracle.binary_linear(x.cpu(), w.cpu()[cols].contiguous(), mask.cpu()[:, :, cols].contiguous(), alpha.cpu(), out_dtype=torch.float32)
+    want = (resid.cpu()[:, :, cols].float() + ref.to(dtype).float()).to(dtype)           # the two roundings of `hidden = residual + proj(x)`
+    got = r.cpu()[:, :, cols]
+    assert relerr(got, want) < (1e-2 if dtype == torch.bfloat16 else 2e-3), relerr(got, want)
+
+
+def test_residual_norm_entry_refuses_what_it_cannot_run(bd):
+    from bitdelta_amd.binary_gemm_kernel import binary_linear_residual_norm
+    from bitdelta_amd._lib import BitDeltaHipError
+    g = torch.Generator(device="cuda").manual_seed(3)
+    dtype = torch.bfloat16
+    for (T, M, N, K) in [(6, 1, 4096, 4096), (2, 64, 8200, 512), (2, 64, 16384, 512)]:        # decode rows; N % 8 != 0 is impossible with int32 masks -> N > 8192
+        x = torch.randn(T, M, K, device="cuda", generator=g).to(dtype)
+        w, mask = _mt_linear(T, N, K, dtype, g)
+        resid = torch.zeros(T, M, N, device="cuda", dtype=dtype)
+        nw = torch.ones(T, N, device="cuda", dtype=dtype)
+        with pytest.raises(BitDeltaHipError):
+            binary_linear_residual_norm(x, w, mask, torch.full((T, 1), 1e-3, device="cuda"), resid, nw, 1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T,S,H,KVH,Lc,pos0", [(6, 64, 32, 8, 320, 0), (2, 128, 32, 32, 128, 0), (3, 17, 8, 2, 64, 5), (1, 64, 4, 4, 96, 32)])
+def test_rope_kv_append_is_bit_identical_to_rope_and_two_copies(bd, dtype, T, S, H, KVH, Lc, pos0):
+    """bd_srv_rope_kv_append == bd_srv_rope on the q and k heads + `kcache[:, :, pos0:pos0 + S] = k.transpose(1, 2)` + the v twin; cache rows outside
+    the written positions are untouched"""
+    from bitdelta_amd import serving_ops as ops
+    g = torch.Generator(device="cuda").manual_seed(T + S + H)
+    W = (H + 2 * KVH) * 128
+    full = torch.randn(T, S, W + 64, device="cuda", generator=g).to(dtype)
+    qkv = full[..., :W]                                                          # padded rows (row stride W + 64)
+    pos = torch.arange(Lc, device="cuda", dtype=torch.float32)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, 128, 2, device="cuda", dtype=torch.float32) / 128))
+    f = torch.outer(pos, inv)
+    emb = torch.cat([f, f], -1)
+    cos = emb.cos().to(dtype).contiguous()
+    sin = (emb.sin() * torch.cat([-torch.ones(64, device="cuda"), torch.ones(64, device="cuda")])).to(dtype).contiguous()
+    kc = torch.randn(T, KVH, Lc, 128, device="cuda", generator=g).to(dtype)
+    vc = torch.randn(T, KVH, Lc, 128, device="cuda", generator=g).to(dtype)
+    ref_full = full.clone()
+    ref = ref_full[..., :W]
+    ops.rope_(ref[..., :(H + KVH) * 128], cos, sin, H + KVH, S, pos0)
+    kc_ref, vc_ref = kc.clone(), vc.clone()
+    kc_ref[:, :, pos0:pos0 + S] = ref[..., H * 128:(H + KVH) * 128].reshape(T, S, KVH, 128).transpose(1, 2)
+    vc_ref[:, :, pos0:pos0 + S] = ref[..., (H + KVH) * 128:].reshape(T, S, KVH, 128).transpose(1, 2)
+    ops.rope_kv_append_(qkv, cos, sin, kc, vc, H, KVH, pos0)
+    assert torch.equal(full, ref_full)                                           # (the padding columns too: untouched)
+    assert torch.equal(kc, kc_ref) and torch.equal(vc, vc_ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T,M,I,K", [(6, 64, 14336, 4096), (5, 33, 1024, 512), (2, 64, 11008, 4096), (3, 17, 512, 1024)])
+def test_pair_tile_swiglu_epilogue_is_bit_identical_to_linear_plus_swiglu(bd, dtype, T, M, I, K):
+    """bd_binary_linear_swiglu on several tenants of <= 64 rows (round 6: the four-wave PAIR tile with the SwiGLU epilogue, variant 21) == the
+    interleaved gate|up Linear followed by the SwiGLU pass"""
+    from bitdelta_amd import serving_ops as ops
+    from bitdelta_amd.binary_gemm_kernel import binary_linear_swiglu
+    from bitdelta_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(T + M + I + K)
+    x = torch.randn(T, M, K, device="cuda", generator=g).to(dtype)
+    w, mask = _mt_linear(T, 2 * I, K, dtype, g)
+    alpha = torch.rand(T, 2, device="cuda", generator=g) * 1e-3 + 2e-4
+    y = binary_linear_swiglu(x, w, mask, alpha)
+    assert L.bd_last_gemm_variant() == 21
+    L.bd_set_gemm_variant(18)                        # the unsplit pair tile: a split-k launch sums k in another order (1-ulp differences on narrow N)
+    try:
+        gu = bd.binary_linear(x, w, mask, alpha.repeat(1, I // 8).contiguous(), groups=2 * I // 8)  # columns in blocks of 8: gate, up, gate, up, ...
+    finally:
+        L.bd_set_gemm_variant(-1)
+    ref = ops.swiglu_interleaved8(gu)
+    assert y.shape == (T, M, I) and torch.equal(y, ref)
+
+
+@pytest.mark.parametrize("epi", [False, True])
+def test_short_prompt_prefill_fusions_change_no_bit(bd, epi):
+    """the serving loop's prefill of a 6-tenant request of short prompts with the round-6 fusions (RoPE + cache append in one launch, the norms on
+    the split-k reduce launches; epi: SwiGLU in the pair-tile epilogue too) == the same request without them: logits, every cached K / V row"""
+    from bitdelta_amd.serving_loop import TenantDecoder
+    lens = (9, 64, 33, 50, 17, 64)
+    dec = TenantDecoder.synthetic("mistral-1layer", len(lens), "cuda", dtype=torch.bfloat16, seed=11, max_len=128, shared_heads=True)
+    g = torch.Generator().manual_seed(2)
+    prompts = [torch.randint(1, 500, (n,), generator=g).tolist() for n in lens]
+    ids, am = dec.prepare(prompts)
+    assert ids.shape[1] == 64
+    out = {}
+    for flag in (True, False):
+        dec.short_prompt_fusions = flag
+        dec.swiglu_epilogue = flag and epi
+        cache = dec.new_cache(128)
+        logits = dec.prefill(ids, am, cache)
+        out[flag] = (logits.clone(), [k.clone() for k in cache["k"]], [v.clone() for v in cache["v"]])
+    a, b = out[True], out[False]
+    assert torch.equal(a[0], b[0])
+    for ka, kb_ in zip(a[1], b[1]):
+        assert torch.equal(ka, kb_)
+    for va, vb in zip(a[2], b[2]):
+        assert torch.equal(va, vb)

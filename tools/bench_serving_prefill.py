@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--layers", type=int, default=None)
     ap.add_argument("--lens", default="64,256,1024")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--modes", default="torch,hip,fused", help="torch = rope + SDPA(mask); hip = HIP RoPE + attention; fused = + the round-6 short-prompt fusions")
     args = ap.parse_args()
     from bitdelta_amd.serving_loop import TenantDecoder
     dec = TenantDecoder.synthetic(args.model, args.tenants, "cuda", dtype=torch.bfloat16, seed=1, layers=args.layers, shared_heads=True)
@@ -28,8 +29,13 @@ def main():
         prompts = [torch.randint(1, 30000, (n,), generator=g).tolist() for n in lens]
         ids, am = dec.prepare(prompts)
         row = []
-        for flag in (False, True):
+        modes = args.modes.split(",")
+        for flag, fus in ((False, True), (True, False), (True, True)):
+            if ("torch", "hip", "fused")[flag + (flag and fus)] not in modes:
+                row.append(float("nan"))
+                continue
             dec.hip_prefill_attention = flag
+            dec.short_prompt_fusions = fus
             cache = dec.new_cache(ids.shape[1] + 8)
             for _ in range(2):
                 dec.prefill(ids, am, cache)
@@ -43,7 +49,8 @@ def main():
             row.append(e0.elapsed_time(e1) / args.reps)
         toks = sum(lens)
         print(f"{args.model}, {args.tenants} tenants, prompts padded to {ids.shape[1]} ({toks} real tokens): prefill {row[0]:.2f} ms with torch "
-              f"rope + SDPA(mask), {row[1]:.2f} ms with the HIP RoPE + attention kernels ({toks / row[1] * 1e3:.0f} prompt tokens/s)")
+              f"rope + SDPA(mask), {row[1]:.2f} ms with the HIP RoPE + attention kernels, {row[2]:.2f} ms with the round-6 short-prompt fusions too "
+              f"(RoPE + cache append, norm on the split-k reduce, SwiGLU in the pair-tile epilogue; {toks / row[2] * 1e3:.0f} prompt tokens/s)")
 
 
 if __name__ == "__main__":
