@@ -1012,10 +1012,12 @@ int launch_fused_splitk(const Problem& q, int KS) {
 inline bool pair_ok(const Problem& q) {
     return q.W && q.B >= 2 && q.M >= 1 && q.M <= 64 && fast_ok(q) && q.sAb >= 0 && q.sAb < (1ll << 30) && q.sPb >= 0 && q.sPb < (1ll << 29);
 }
+static const int g_pair_ks_env = env_int("BD_PAIR_SPLITK", 0);       // A/B: force the k-slice count of the split pair tiles (0 = the rule)
 inline int pair_splitk_dims(int B, int N, int K) {    // k slices so that pairs x column tiles x slices ~ fills the CUs (>= 512 k per slice)
     const long long cus = num_cus();
     const long long tiles = (long long)((B + 1) / 2) * ((N + 127) / 128);
     if (K % 64 || N % 8 || tiles * 2 > cus) return 1;
+    if (g_pair_ks_env > 1) { int f = g_pair_ks_env; while (f > 1 && (K / f < 512 || (K / 64) % f)) --f; return f; }
     long long ks = cus / tiles;
     if (ks > 8) ks = 8;
     while (ks > 1 && K / ks < 512) --ks;

@@ -27,7 +27,8 @@ extern "C" {
  * 13 delta-only on 256x256 tiles (automatic once those tiles fill >= 80 % of the CU-rounds), 14 fused on 256x128 tiles (automatic
  * wherever 8 was; with fp32 output only its general-form epilogue); 15 = 14 with the SwiGLU epilogue (bd_binary_linear_swiglu only).
  * 16 / 17 = 8-wave PAIR tiles (two batch entries of <= 64 rows per 128x128 tile; 17 + split-k); 18 / 19 = the same on the four-wave schedule
- * (automatic since round 5); 20 = four-wave fused 128x128 tile, one entry per tile (automatic wherever 9 was, 16-bit outputs).
+ * (automatic since round 5); 20 = four-wave fused 128x128 tile, one entry per tile (automatic wherever 9 was, 16-bit outputs); 21 = 18 with the
+ * SwiGLU epilogue (bd_binary_linear_swiglu with several entries of <= 64 rows; round 6).
  * 800 = delta_rows_kernel (bd_gemv_rows.h): delta only, reference sign layout, M <= 16, no scale -- the reference's published binary_bmm /
  * binary_matmul decode shapes: 64- or 32-column super-tiles x (1 / 2 masks per block x M rows each, or one mask shared by all B * M <= 16 rows),
  * the whole batch in one launch (automatic when those blocks occupy at least half of the chip: per-entry masks from 4 rows on, a shared mask
@@ -37,7 +38,8 @@ extern "C" {
  * Further A/B hooks read once per thread from the environment (none is needed in production): BD_ROWS_TUNE (delta_rows_kernel: bits 1-2 masks per
  * block, bit 4 never automatic, bit 5 / 6 force 64- / 32-column super-tiles), BD_ROWS_SHARED_MIN (rows from which a shared-mask launch takes it),
  * BD_ATTN_DEPTH (decode attention K / V ring: 2 / 4), BD_ATTN_SPLITS_MAX (key-range splits: 4 = fixed, 16 = by tenants x kv heads),
- * BD_NORM_ROWS_MIN (rows from which bd_srv_rmsnorm runs its wave-per-row kernel).
+ * BD_NORM_ROWS_MIN (rows from which bd_srv_rmsnorm runs its wave-per-row kernel), BD_PAIR_SPLITK (k slices of the split pair tiles, variant 19:
+ * 0 = the rule; read once per process).
  * The bd_set_* entry points below are TUNING / TEST HOOKS: thread-local, not part of the stable interface a reference-side binding
  * needs (INTEGRATION.md binds none of them), and free to change between versions. */
 int bd_set_gemm_variant(int variant);

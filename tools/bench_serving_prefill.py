@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--layers", type=int, default=None)
     ap.add_argument("--lens", default="64,256,1024")
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--modes", default="torch,hip,fused", help="torch = rope + SDPA(mask); hip = HIP RoPE + attention; fused = + the round-6 short-prompt fusions")
+    ap.add_argument("--modes", default="torch,hip,fused", help="torch = rope + SDPA(mask); hip = HIP RoPE + attention; fused = + the round-6 short-prompt fusions; BD_SWIGLU_EPI=1: SwiGLU in the pair-tile epilogue too")
     args = ap.parse_args()
     from bitdelta_amd.serving_loop import TenantDecoder
     dec = TenantDecoder.synthetic(args.model, args.tenants, "cuda", dtype=torch.bfloat16, seed=1, layers=args.layers, shared_heads=True)
@@ -36,6 +36,7 @@ def main():
                 continue
             dec.hip_prefill_attention = flag
             dec.short_prompt_fusions = fus
+            dec.swiglu_epilogue = fus and os.environ.get("BD_SWIGLU_EPI", "0") == "1"
             cache = dec.new_cache(ids.shape[1] + 8)
             for _ in range(2):
                 dec.prefill(ids, am, cache)
@@ -50,7 +51,7 @@ def main():
         toks = sum(lens)
         print(f"{args.model}, {args.tenants} tenants, prompts padded to {ids.shape[1]} ({toks} real tokens): prefill {row[0]:.2f} ms with torch "
               f"rope + SDPA(mask), {row[1]:.2f} ms with the HIP RoPE + attention kernels, {row[2]:.2f} ms with the round-6 short-prompt fusions too "
-              f"(RoPE + cache append, norm on the split-k reduce, SwiGLU in the pair-tile epilogue; {toks / row[2] * 1e3:.0f} prompt tokens/s)")
+              f"(RoPE + cache append in one launch, the norms on the split-k reduce launches; {toks / row[2] * 1e3:.0f} prompt tokens/s)")
 
 
 if __name__ == "__main__":
