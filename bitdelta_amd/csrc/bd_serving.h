@@ -102,8 +102,14 @@ __global__ void __launch_bounds__(256) add_rmsnorm_kernel(const unsigned short* 
     const unsigned short* rr = resid + (long long)r * s_r;
     const float* yr = y32 + (long long)r * s_y;
     const unsigned short* wr = w + (long long)t * sw;
-    u32x4_t xs[4];
+    u32x4_t xs[4], wv[4];
     float ss = 0.f;
+    // the norm weights are fetched with the row, not after the barrier: a one-row launch (the decode step of tp.py) is a chain of memory round trips
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = threadIdx.x * 8 + 2048 * i;
+        wv[i] = c < H ? *(const u32x4_t*)(wr + c) : u32x4_t{0u, 0u, 0u, 0u};
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = threadIdx.x * 8 + 2048 * i;
@@ -128,7 +134,7 @@ __global__ void __launch_bounds__(256) add_rmsnorm_kernel(const unsigned short* 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = threadIdx.x * 8 + 2048 * i;
-        if (c < H) *(u32x4_t*)(h_out + (long long)r * s_h + c) = norm8<DT>(xs[i], *(const u32x4_t*)(wr + c), rs);
+        if (c < H) *(u32x4_t*)(h_out + (long long)r * s_h + c) = norm8<DT>(xs[i], wv[i], rs);
     }
 }
 
@@ -148,8 +154,13 @@ __global__ void __launch_bounds__(256) splitk_reduce_norm_kernel(const float* __
     const float* slab = ws + ((long long)b * KS * M + m) * N;           // slice k of this row: slab + k * M * N
     unsigned short* cr = C + (long long)b * sCb + (long long)m * sCm;
     const unsigned short* wr = w + (long long)b * sw;
-    u32x4_t xs[4];
+    u32x4_t xs[4], wv[4];
     float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                       // (the norm weights with the first loads, not after the barrier)
+        const int c = threadIdx.x * 8 + 2048 * i;
+        wv[i] = c < N ? *(const u32x4_t*)(wr + c) : u32x4_t{0u, 0u, 0u, 0u};
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = threadIdx.x * 8 + 2048 * i;
@@ -192,7 +203,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_norm_kernel(const float* __
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = threadIdx.x * 8 + 2048 * i;
-        if (c < N) *(u32x4_t*)(hr + c) = norm8<DT>(xs[i], *(const u32x4_t*)(wr + c), rs);
+        if (c < N) *(u32x4_t*)(hr + c) = norm8<DT>(xs[i], wv[i], rs);
     }
 }
 
