@@ -44,6 +44,8 @@ SIGNATURES = {
     "bd_binary_linear_decode_handoff": (_ci, [_vp, _vp, _vp, _ci, _vp, _vp, _ci, _ci, _ci, _ci, _i64, _i64, _i64, _i64, _i64, _ci,
                                               _i64, _i64, _ci, _ci, _ci, _vp, _i64, ctypes.c_float, _ci, _vp, _vp, _vp, _vp]),
     "bd_srv_cache_warm": (_ci, [_vp, _i64, _vp, _i64, _ci, _vp]),
+    "bd_srv_step_begin": (_ci, [_vp, _i64, _i64, _vp, _vp, _i64, _vp, _ci, _vp, _ci, _ci, _ci, _vp]),
+    "bd_srv_step_end": (_ci, [_vp, _i64, _ci, _vp, _vp, _i64, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _vp]),
     "bd_srv_rope_kv_append": (_ci, [_vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _i64, _ci, _ci, _ci, _vp]),
     "bd_srv_rope": (_ci, [_vp, _vp, _vp, _ci, _ci, _ci, _i64, _ci, _ci, _ci, _vp]),
     "bd_srv_decode_attention": (_ci, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _ci, _ci, _ci, _i64, _i64, _ci, _vp, _i64, _vp]),

@@ -1690,6 +1690,37 @@ extern "C" int bd_srv_rope_kv_append(void* QKV, const void* cos_t, const void* s
     return launch_status();
 }
 
+extern "C" int bd_srv_step_begin(const void* embed, int64_t sEt, int64_t sEv, const int64_t* tok, void* X, int64_t sx, void* valid, int Lc,
+                                 const int64_t* pos, int T, int V, int H, void* stream) {
+    if (T < 0 || V < 1 || H < 1 || Lc < 1) return BD_E_BAD_SHAPE;
+    if (T == 0) return BD_OK;
+    if (!embed || !tok || !X || !valid || !pos) return BD_E_NULL;
+    if (H % 8 || sEv % 8 || sEt % 8 || sx % 8 || sEv < H || sx < H || sEt < 0 || !aligned16(embed) || !aligned16(X)) return BD_E_BAD_SHAPE;
+    hipLaunchKernelGGL(step_begin_kernel, dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)embed, (long long)sEt,
+                       (long long)sEv, (const long long*)tok, (unsigned short*)X, (long long)sx, (unsigned char*)valid, Lc, (const long long*)pos, V, H);
+    return launch_status();
+}
+
+extern "C" int bd_srv_step_end(const void* logits, int64_t sl, int V, int64_t* tok, int64_t* out, int64_t s_out, int out_cap,
+                               const int64_t* stop_ids, int ns, void* stopped, int64_t* pos, int64_t* step, void* ticket, int T, int dtype,
+                               void* stream) {
+    if (T < 0 || V < 1 || ns < 0 || out_cap < 0) return BD_E_BAD_SHAPE;
+    if (dtype != BD_F16 && dtype != BD_BF16) return BD_E_BAD_DTYPE;
+    if (T == 0) return BD_OK;
+    if (!logits || !tok || !out || !stopped || !pos || !step || !ticket || (ns > 0 && !stop_ids)) return BD_E_NULL;
+    if (V % 8 || sl % 8 || sl < V || s_out < out_cap || !aligned16(logits) || ((uintptr_t)ticket & 3)) return BD_E_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == BD_BF16)
+        hipLaunchKernelGGL((step_end_kernel<DT_BF16>), dim3((unsigned)T), dim3(256), 0, st, (const unsigned short*)logits, (long long)sl, V,
+                           (long long*)tok, (long long*)out, (long long)s_out, out_cap, (const long long*)stop_ids, ns, (unsigned char*)stopped,
+                           (long long*)pos, (long long*)step, (unsigned int*)ticket, T);
+    else
+        hipLaunchKernelGGL((step_end_kernel<DT_F16>), dim3((unsigned)T), dim3(256), 0, st, (const unsigned short*)logits, (long long)sl, V,
+                           (long long*)tok, (long long*)out, (long long)s_out, out_cap, (const long long*)stop_ids, ns, (unsigned char*)stopped,
+                           (long long*)pos, (long long*)step, (unsigned int*)ticket, T);
+    return launch_status();
+}
+
 extern "C" int bd_srv_cache_warm(const void* p0, int64_t bytes0, const void* p1, int64_t bytes1, int blocks, void* stream) {
     if (bytes0 < 0 || bytes1 < 0 || blocks < 0) return BD_E_BAD_SHAPE;
     if ((bytes0 && !p0) || (bytes1 && !p1)) return BD_E_NULL;

@@ -269,6 +269,78 @@ __global__ void __launch_bounds__(256) swiglu_kernel(const unsigned short* __res
     *(u32x4_t*)(y + (long long)r * sy + c) = o;
 }
 
+// The two ends of a greedy decode step (round 6; demo/demo_backend.py:190-258 is the loop): what `valid.index_fill_(1, pos, True)` + the per-tenant
+// embedding gather do before the layers, and what argmax + the token / output / stop-flag / position updates do after the lm_head -- 2 launches
+// instead of ~13 stock ones (each ~5 us inside the replayed graph: ~60 us of a 4.5-ms step).  One block per tenant; integer work, exact.
+__global__ void __launch_bounds__(256) step_begin_kernel(const unsigned short* __restrict__ embed, long long sEt, long long sEv,
+                                                         const long long* __restrict__ tok, unsigned short* __restrict__ x, long long sx,
+                                                         unsigned char* __restrict__ valid, int Lc, const long long* __restrict__ pos, int V,
+                                                         int H) {
+    const int t = blockIdx.x;
+    long long id = tok[t];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);                           // (device data the host cannot validate: clamp into the table)
+    const unsigned short* row = embed + (long long)t * sEt + id * sEv;
+    for (int c = threadIdx.x * 8; c < H; c += 256 * 8) *(u32x4_t*)(x + (long long)t * sx + c) = *(const u32x4_t*)(row + c);
+    if (threadIdx.x == 0) {
+        const long long p = *pos;
+        if (p >= 0 && p < Lc) valid[(long long)t * Lc + p] = 1;
+    }
+}
+
+// torch.argmax's order: a NaN is the maximum, ties go to the lower index
+__device__ __forceinline__ bool argmax_better(float a, int ia, float b, int ib) {
+    const bool an = a != a, bn = b != b;
+    if (an || bn) return an && (!bn || ia < ib);
+    return a > b || (a == b && ia < ib);
+}
+template <int DT>
+__global__ void __launch_bounds__(256) step_end_kernel(const unsigned short* __restrict__ logits, long long sl, int V, long long* __restrict__ tok,
+                                                       long long* __restrict__ out, long long s_out, int out_cap,
+                                                       const long long* __restrict__ stop_ids, int ns, unsigned char* __restrict__ stopped,
+                                                       long long* pos, long long* step, unsigned int* ticket, int T) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const int t = blockIdx.x;
+    const unsigned short* row = logits + (long long)t * sl;
+    float best = -__builtin_inff();
+    int bidx = 0x7fffffff;
+    for (int c = threadIdx.x * 8; c < V; c += 256 * 8) {
+        const u32x4_t v = *(const u32x4_t*)(row + c);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const float lo = half_bits_to_f32<DT>(v[d] & 0xffffu), hi = half_bits_to_f32<DT>(v[d] >> 16);
+            if (argmax_better(lo, c + 2 * d, best, bidx)) { best = lo; bidx = c + 2 * d; }
+            if (argmax_better(hi, c + 2 * d + 1, best, bidx)) { best = hi; bidx = c + 2 * d + 1; }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bidx, off, 64);
+        if (argmax_better(ov, oi, best, bidx)) { best = ov; bidx = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = bidx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (argmax_better(bv[w], bi[w], best, bidx)) { best = bv[w]; bidx = bi[w]; }
+        const long long nxt = bidx, s = *step;
+        tok[t] = nxt;
+        if (s >= 0 && s < out_cap) out[(long long)t * s_out + s] = nxt;
+        unsigned char st = stopped[t];
+        for (int j = 0; j < ns; ++j) st |= (stop_ids[(long long)t * ns + j] == nxt) ? 1 : 0;
+        stopped[t] = st;
+        // the last tenant's block advances the shared position / step counters: every block has read them before its ticket
+        __threadfence();
+        if (atomicAdd(ticket, 1u) == (unsigned)(T - 1)) {
+            *ticket = 0u;
+            *pos += 1;
+            *step += 1;
+        }
+    }
+}
+
 // In-place rotary embedding of [rows, heads * 128] (a q or k projection output before the head transpose), HF rotate-half form with
 // the sign folded into `sin`: out[d] = round16(round16(x[d] * cos[d]) + x[d +- 64] * sin[d])  -- the rounding points of the stock
 // composition `torch.addcmul(x * cos, rot, sin)`, which costs five passes (cat, mul, addcmul + two temporaries) instead of one.

@@ -242,6 +242,8 @@ class TenantDecoder(nn.Module):
         self.fast_glue = True       # decode steps use the HIP glue kernels (serving_ops); False = stock torch ops everywhere
         self.swiglu_epilogue = False  # prefill: SwiGLU inside the gate|up GEMM (256-row tiles from 256 rows per tenant, pair tiles for <= 64-row
                                       # prompts): measured slower than GEMM + one pass both times (6 x 64 rows: gate|up 162 -> 186 us against a 9-us pass)
+        self.step_kernels = True      # decode step: mask extension + embedding gather, and argmax + token / output / stop / position updates, as
+                                      # one HIP launch each instead of ~13 stock ops (round 6)
         self.short_prompt_fusions = True   # multi-tenant prefill of short prompts (round 6): RoPE + KV-cache append in one launch; <= 64 rows per
                                            # tenant: the norms ride on the split-k reduce launches of o / down
         self.hip_prefill_attention = True      # prefill: RoPE + flash-style attention kernels instead of torch SDPA over a [L, Lc] mask
@@ -420,6 +422,8 @@ class TenantDecoder(nn.Module):
                 cv[:, :, :S] = v4.transpose(1, 2)
         else:
             q, k, v = layer.qkv.split(qkv)
+            if cos is None:                                                     # (forward() skips the gather when it expects the HIP attention)
+                cos, sin = self.cos[pos_idx], self.sin[pos_idx]
             q = _rope(q.view(T, S, heads, hd).transpose(1, 2), cos, sin)
             k = _rope(k.view(T, S, kvh, hd).transpose(1, 2), cos, sin)
             v = v.view(T, S, kvh, hd).transpose(1, 2)
@@ -468,13 +472,18 @@ class TenantDecoder(nn.Module):
         return x, d_hand, None
 
     @torch.no_grad()
-    def forward(self, ids, pos_idx, cache, attn_mask):
+    def forward(self, ids, pos_idx, cache, attn_mask, x=None):
         """ids [T, S]; pos_idx [S] (device, positions of these tokens in the cache); attn_mask [T, 1, S, L] bool.
-        Returns the logits of the LAST position, [T, vocab]."""
+        Returns the logits of the LAST position, [T, vocab].  x: the embedded tokens when the caller already has them (step_begin)."""
         T, S = ids.shape
-        cos, sin = self.cos[pos_idx], self.sin[pos_idx]
-        t_idx = torch.arange(T, device=ids.device).view(T, 1)
-        x = self.embed[t_idx, ids]                                            # per-tenant embedding: one gather
+        _, _, _, heads, kvh, _ = self.cfg
+        # (the rows of the rotary tables are gathered only for the stock-op attention paths: the HIP kernels index the tables themselves)
+        hip_attn = self.fast_glue and ((S == 1 and ops.decode_attention_supported(heads, kvh, self.hd)) or
+                                       (S > 1 and cache.get("kv_start") is not None and self.hd == 128 and S % 64 == 0))
+        cos, sin = (None, None) if hip_attn else (self.cos[pos_idx], self.sin[pos_idx])
+        if x is None:
+            t_idx = torch.arange(T, device=ids.device).view(T, 1)
+            x = self.embed[t_idx, ids]                                        # per-tenant embedding: one gather
         ssq_valid = False                                                     # (the embedding rows have no producer launch: layer 0 norms itself)
         h_in = None
         for li, layer in enumerate(self.layers):
@@ -522,9 +531,20 @@ class TenantDecoder(nn.Module):
     def _decode_step(self, st):
         """one greedy step on static buffers: st['tok'] [T,1] -> logits -> argmax -> st['tok']; position / masks advance on device"""
         cache = st["cache"]
-        cache["valid"].index_fill_(1, st["pos"], True)
-        mask = cache["valid"][:, None, None, :]
-        logits = self.forward(st["tok"], st["pos"], cache, mask)
+        if self.fast_glue and self.step_kernels and self.embed.shape[-1] % 8 == 0 and self.lm_head.shape[-2] % 8 == 0:
+            # the two ends of the step as ONE launch each (serving_ops.step_begin / step_end): mask extension + embedding, then argmax + the
+            # token / output / stop-flag / position updates
+            if "ticket" not in st:
+                st["ticket"] = torch.zeros(1, dtype=torch.int32, device=self.dev)      # (first call = outside any graph capture)
+            x = ops.step_begin(self.embed, st["tok"], cache["valid"], st["pos"])
+            logits = self.forward(st["tok"], st["pos"], cache, cache["valid"][:, None, None, :], x=x)
+            if logits.stride(1) == 1 and logits.stride(0) % 8 == 0 and logits.data_ptr() % 16 == 0:
+                ops.step_end(logits, st["tok"], st["out"], st["step"], st["pos"], st["stop_ids"], st["stopped"], st["ticket"])
+                return
+        else:
+            cache["valid"].index_fill_(1, st["pos"], True)
+            mask = cache["valid"][:, None, None, :]
+            logits = self.forward(st["tok"], st["pos"], cache, mask)
         nxt = torch.argmax(logits, dim=-1)
         st["tok"].copy_(nxt[:, None])
         st["out"].index_copy_(1, st["step"], nxt[:, None])
@@ -550,7 +570,7 @@ class TenantDecoder(nn.Module):
         # Stale keys of an earlier request are masked by cache["valid"].
         width = max(self.MIN_STOP_WIDTH, 1 << max(nstop - 1, 0).bit_length())
         key = (width, self.fast_glue, self.fuse_glue, self.fuse_qkv_norm, self.fuse_gateup_norm, self.norm_handoff, FusedDeltaLinear.use_tiled,
-               self.prefetch_o)
+               self.prefetch_o, self.step_kernels)
         if self._kv_cache is None:
             self._kv_cache = self.new_cache()
         slot = self._static.pop(key, None)

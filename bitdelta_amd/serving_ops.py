@@ -147,6 +147,38 @@ def rope_(x, cos, sin, heads, seq, pos0=0):
     return x
 
 
+def step_begin(embed, tok, valid, pos):
+    """First launch of a greedy decode step: x[t] = embed[t, tok[t]] -> [T, 1, H], and valid[t, pos] = True (what `valid.index_fill_(1, pos, True)`
+    and the per-tenant embedding gather do).  embed [T, V, H] (or [V, H]: one shared table), tok [T, 1] long, valid [T, Lc] bool, pos [1] long."""
+    require_gpu(embed, tok, valid, pos)
+    shared = embed.dim() == 2
+    V, H = embed.shape[-2], embed.shape[-1]
+    T = tok.shape[0]
+    assert tok.dtype == torch.long and tok.is_contiguous() and tok.numel() == T and pos.dtype == torch.long and pos.numel() == 1
+    assert valid.dtype == torch.bool and valid.is_contiguous() and valid.shape[0] == T and (shared or embed.shape[0] == T)
+    assert embed.stride(-1) == 1 and H % 8 == 0
+    x = torch.empty((T, 1, H), device=embed.device, dtype=embed.dtype)
+    with torch.cuda.device(embed.device):
+        check(lib().bd_srv_step_begin(ptr(embed), 0 if shared else embed.stride(0), embed.stride(-2), ptr(tok), ptr(x), H, ptr(valid), valid.shape[1],
+                                      ptr(pos), T, V, H, stream_ptr()), "srv_step_begin")
+    return x
+
+
+def step_end(logits, tok, out, step, pos, stop_ids, stopped, ticket):
+    """Last launch of a greedy decode step: nxt = argmax(logits, -1) (torch's order); tok[:, 0] = nxt; out[:, step] = nxt; stopped |= (nxt[:, None] ==
+    stop_ids).any(1); pos += 1; step += 1 -- the five stock ops of the loop in one launch.  logits [T, V] 16-bit, ticket: a zeroed int32 word."""
+    require_gpu(logits, tok, out, step, pos, stop_ids, stopped, ticket)
+    T, V = logits.shape
+    assert logits.stride(1) == 1 and V % 8 == 0 and tok.dtype == torch.long and tok.is_contiguous() and tok.numel() == T
+    assert out.dtype == torch.long and out.shape[0] == T and out.stride(1) == 1 and stop_ids.dtype == torch.long and stop_ids.is_contiguous()
+    assert stop_ids.shape[0] == T and stopped.dtype == torch.bool and stopped.is_contiguous() and stopped.numel() == T
+    assert step.dtype == torch.long and pos.dtype == torch.long and step.numel() == 1 and pos.numel() == 1
+    assert ticket.dtype == torch.int32 and ticket.numel() == 1
+    with torch.cuda.device(logits.device):
+        check(lib().bd_srv_step_end(ptr(logits), logits.stride(0), V, ptr(tok), ptr(out), out.stride(0), out.shape[1], ptr(stop_ids), stop_ids.shape[1],
+                                    ptr(stopped), ptr(pos), ptr(step), ptr(ticket), T, DTYPE_CODE[logits.dtype], stream_ptr()), "srv_step_end")
+
+
 def rope_kv_append_(qkv, cos, sin, kcache, vcache, heads, kvh, pos0=0):
     """Prefill from position pos0: rope_ on the q and k heads of the fused projection output qkv [T, S, (heads + 2 kvh) * 128] (in place) and, in the
     same launch, the rotated k rows and the v rows into the caches [T, kvh, Lc, 128] at positions pos0 .. pos0 + S - 1 (what

@@ -218,6 +218,19 @@ int bd_srv_rope(void* X, const void* cos_t, const void* sin_t, int rows, int hea
  * the HF attention module the reference's Linears sit in; demo/demo_backend.py:297-315 prefills through it).  pos0 + S <= Lc. */
 int bd_srv_rope_kv_append(void* QKV, const void* cos_t, const void* sin_t, void* kcache, void* vcache, int T, int S, int H, int KVH,
                           int head_dim, int64_t sx, int Lc, int pos0, int dtype, void* stream);
+/* bd_srv_step_begin / bd_srv_step_end (round 6): the two ends of ONE greedy decode step of the serving loop (demo/demo_backend.py:190-258: HF's
+ * generate loop over the tenant batch -- embedding lookup of the last tokens, attention-mask extension, argmax of the last logits, stop-token check).
+ * step_begin: X[t] = embed[t][tok[t]] (embed [T, V, H] 16-bit, tenant stride sEt -- 0 = one shared table -- row stride sEv; X [T, H], row stride sx)
+ *   and valid[t, *pos] = 1 (valid [T, Lc] bytes: the key mask bd_srv_decode_attention reads).
+ * step_end: nxt[t] = argmax(logits[t, :V]) with torch.argmax's order (a NaN is the maximum, ties go to the lower index); tok[t] = nxt[t];
+ *   out[t, *step] = nxt[t] when *step < out_cap (out [T, >= out_cap] int64, row stride s_out); stopped[t] |= nxt[t] in stop_ids[t, :ns]; then
+ *   *pos += 1 and *step += 1, once (the last block to finish; `ticket` = a zero-initialised 4-byte device word the call leaves at zero).
+ * tok / pos / step / out / stop_ids are int64 (torch.long), valid / stopped bytes (torch.bool): the state the loop keeps on the device so that the
+ * step replays inside a hipGraph.  V % 8 == 0, H % 8 == 0.  Integer work: exact. */
+int bd_srv_step_begin(const void* embed, int64_t sEt, int64_t sEv, const int64_t* tok, void* X, int64_t sx, void* valid, int Lc,
+                      const int64_t* pos, int T, int V, int H, void* stream);
+int bd_srv_step_end(const void* logits, int64_t sl, int V, int64_t* tok, int64_t* out, int64_t s_out, int out_cap,
+                    const int64_t* stop_ids, int ns, void* stopped, int64_t* pos, int64_t* step, void* ticket, int T, int dtype, void* stream);
 /* bd_srv_cache_warm (round 6): reads [p0, p0 + bytes0) and [p1, p1 + bytes1) (16-byte aligned; whole 16-byte chunks) and discards the values:
  * a weight-prefetch launch for a hipGraph side branch (the serving loop forks it next to the decode attention launch so that the o projection's
  * weight and sign words sit in the Infinity Cache when it starts).  blocks = 0: one 256-thread block per CU.  No reference counterpart (the

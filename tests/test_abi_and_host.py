@@ -152,6 +152,16 @@ def test_round6_entries_validate_their_arguments_before_any_device_work():
     assert call(M=1) == BAD_SHAPE and call(M=16) == BAD_SHAPE                                          # decode rows: the hand-off entry's business
     assert call(N=8200) == BAD_SHAPE and call(N=16384) == BAD_SHAPE                                    # wider than the norm kernels' rows
     assert call(sYm=4100) == BAD_SHAPE and call(sYb=64 * 4096 + 8) == BAD_SHAPE                        # ragged / gapped residual rows
+    sb, se = L.bd_srv_step_begin, L.bd_srv_step_end
+    assert sb(base, 0, 4096, base, base, 4096, base, 64, base, 0, 32000, 4096, None) == 0               # no tenants
+    assert sb(None, 0, 4096, base, base, 4096, base, 64, base, 2, 32000, 4096, None) == NULL
+    assert sb(base, 0, 4096, base, base, 4096, base, 64, base, 2, 32000, 4100, None) == BAD_SHAPE       # H % 8
+    assert sb(base, 0, 4000, base, base, 4096, base, 64, base, 2, 32000, 4096, None) == BAD_SHAPE       # table rows shorter than H
+    assert se(base, 32000, 32000, base, base, 16, 16, base, 1, base, base, base, base, 0, 1, None) == 0
+    assert se(base, 32000, 32000, base, base, 16, 16, base, 1, base, base, base, None, 2, 1, None) == NULL      # no ticket word
+    assert se(base, 32000, 32004, base, base, 16, 16, base, 1, base, base, base, base, 2, 1, None) == BAD_SHAPE   # V % 8
+    assert se(base, 32000, 32000, base, base, 8, 16, base, 1, base, base, base, base, 2, 1, None) == BAD_SHAPE    # out rows shorter than out_cap
+    assert se(base, 32000, 32000, base, base, 16, 16, base, 1, base, base, base, base, 2, 2, None) == BAD_DTYPE
 
 
 def test_product_never_imports_the_oracle():

@@ -1324,3 +1324,75 @@ def test_short_prompt_prefill_fusions_change_no_bit(bd, epi):
         assert torch.equal(ka, kb_)
     for va, vb in zip(a[2], b[2]):
         assert torch.equal(va, vb)
+
+
+# ------------------------------------------------------------------------------------------------ the two ends of a decode step (round 6)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T,V,H,shared", [(6, 32000, 4096, False), (1, 512, 256, False), (4, 32008, 2048, True), (12, 1000, 64, False)])
+def test_step_begin_and_step_end_do_what_the_stock_ops_do(bd, dtype, T, V, H, shared):
+    """bd_srv_step_begin == `valid.index_fill_(1, pos, True)` + the per-tenant embedding gather; bd_srv_step_end == argmax (torch's order: first
+    maximum, NaN wins) + `tok.copy_` + `out.index_copy_` + the stop-flag update + `pos += 1; step += 1` -- exact, over several steps in a row,
+    with ties, NaNs and stop tokens in the logits"""
+    from bitdelta_amd import serving_ops as ops
+    g = torch.Generator(device="cuda").manual_seed(T + V + H)
+    embed = (torch.randn(V, H, device="cuda", generator=g) if shared else torch.randn(T, V, H, device="cuda", generator=g)).to(dtype)
+    Lc, ns, cap = 40, 3, 9
+    tok = torch.randint(0, V, (T, 1), device="cuda", generator=g)
+    valid = torch.zeros(T, Lc, dtype=torch.bool, device="cuda")
+    valid[:, :5] = True
+    pos, step = torch.tensor([5], device="cuda"), torch.tensor([1], device="cuda")
+    out = torch.zeros(T, cap, dtype=torch.long, device="cuda")
+    stopped = torch.zeros(T, dtype=torch.bool, device="cuda")
+    ticket = torch.zeros(1, dtype=torch.int32, device="cuda")
+    r = {k: v.clone() for k, v in dict(tok=tok, valid=valid, pos=pos, step=step, out=out, stopped=stopped).items()}
+    stop_ids = torch.full((T, ns), -1, dtype=torch.long, device="cuda")
+    for it in range(cap + 2):                                    # runs past the end of `out`: the surplus steps must not write
+        x = ops.step_begin(embed, tok, valid, pos)
+        r["valid"].index_fill_(1, r["pos"], True)
+        x_ref = (embed[r["tok"][:, 0]] if shared else embed[torch.arange(T, device="cuda"), r["tok"][:, 0]])[:, None, :]
+        assert torch.equal(x, x_ref) and torch.equal(valid, r["valid"])
+        logits = torch.randn(T, V, device="cuda", generator=g).to(dtype)
+        if it == 1:                                              # ties: the maximum appears several times (first index wins)
+            logits[:, [7, 3, V - 1]] = 100.0
+        if it == 2:                                              # NaN beats everything, the first NaN wins
+            logits[:, [V - 5, 11]] = float("nan")
+            logits[0, 2] = float("inf")
+        if it == 3:                                              # negative zero ties positive zero; all-equal rows
+            logits.fill_(0.0)
+            logits[:, 1] = -0.0
+        if it == 4:                                              # this step's winner is a stop token of tenants 0 and T - 1
+            logits[:, 123 % V] = 50.0
+            stop_ids[0, 1] = 123 % V
+            stop_ids[T - 1, 2] = 123 % V
+        ops.step_end(logits, tok, out, step, pos, stop_ids, stopped, ticket)
+        nxt = torch.argmax(logits, dim=-1)
+        r["tok"].copy_(nxt[:, None])
+        if int(r["step"]) < cap:
+            r["out"].index_copy_(1, r["step"], nxt[:, None])
+        r["stopped"] |= (nxt[:, None] == stop_ids).any(dim=1)
+        r["pos"] += 1
+        r["step"] += 1
+        for k, v in dict(tok=tok, pos=pos, step=step, out=out, stopped=stopped).items():
+            assert torch.equal(v, r[k]), (it, k, v, r[k])
+        assert int(ticket) == 0
+    assert bool(stopped[0]) and bool(stopped[T - 1]) and (T <= 2 or not bool(stopped[1]))
+
+
+@pytest.mark.parametrize("name,T,dtype", [("tiny128", 4, torch.float16), ("mistral-1layer", 6, torch.bfloat16)])
+def test_decode_loop_with_step_kernels_generates_the_same_tokens(bd, name, T, dtype):
+    """TenantDecoder.generate with the step kernels (graph replay and eager) == the same loop with the stock ops at both ends of the step: every
+    token, the step count, the stop behaviour"""
+    from bitdelta_amd.serving_loop import TenantDecoder
+    dec = TenantDecoder.synthetic(name, T, "cuda", dtype=dtype, seed=31, max_len=192, shared_heads=True)
+    g = torch.Generator().manual_seed(9)
+    prompts = [torch.randint(1, 500, (n,), generator=g).tolist() for n in (9, 64, 33, 70, 5, 12)[:T]]
+    dec.step_kernels = False
+    ref, n_ref = dec.generate(prompts, max_new_tokens=12, use_graph=True)
+    stops = [[int(ref[t, 5])] if t % 2 == 0 else [] for t in range(T)]        # a stop token that tenants 0, 2, ... really produce at step 5
+    ref_s, n_ref_s = dec.generate(prompts, max_new_tokens=12, stop_token_ids=[s if s else [int(ref[t, 7])] for t, s in enumerate(stops)], use_graph=True)
+    for use_graph in (True, False):
+        dec.step_kernels = True
+        got, n = dec.generate(prompts, max_new_tokens=12, use_graph=use_graph)
+        assert n == n_ref and torch.equal(got, ref)
+        got_s, n_s = dec.generate(prompts, max_new_tokens=12, stop_token_ids=[s if s else [int(ref[t, 7])] for t, s in enumerate(stops)], use_graph=use_graph)
+        assert n_s == n_ref_s and torch.equal(got_s, ref_s) and n_s < 12

@@ -3,7 +3,7 @@
 
     python tools/ab_decode_step.py --tenants 6 --arms base:0 fg_off:256 fg_all:512 pf:0:prefetch
 
-An arm is name:stream_tuning_flags[:prefetch].  Each arm is captured as its own graph (dispatch decisions are taken at capture time);
+An arm is name:stream_tuning_flags[:prefetch|nostep].  Each arm is captured as its own graph (dispatch decisions are taken at capture time);
 the arms are then timed alternately, `--rounds` rounds of `--steps` replays each; min and median per arm are printed.
 Replaces the one-off tools/gpu_r4*.sh / gpu_r5*.sh scripts of earlier rounds for this kind of question."""
 import argparse
@@ -53,6 +53,7 @@ def main():
         parts = arm.split(":")
         name, flags = parts[0], int(parts[1]) if len(parts) > 1 else 0
         dec.prefetch_o = len(parts) > 2 and "prefetch" in parts[2]
+        dec.step_kernels = not (len(parts) > 2 and "nostep" in parts[2])          # (stock torch ops at both ends of the step)
         L.bd_set_stream_tuning(flags)
         restore()
         runners[name] = dec._graph_runner(st)
@@ -64,6 +65,7 @@ def main():
         toks[name] = st["out"][:, 1:9].cpu().clone()
     L.bd_set_stream_tuning(0)
     dec.prefetch_o = False
+    dec.step_kernels = True
     ms = {n: [] for n in runners}
     for n, run in runners.items():          # warm-up
         restore()
