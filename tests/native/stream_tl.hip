@@ -10,6 +10,9 @@
 #include "bd_gemv_stream.h"
 using namespace bd;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
+#ifndef TL_NS2
+#define TL_NS2 4          // prefetch depth of the per-stage-load form (form 2: down)
+#endif
 #ifndef TL_NS
 #define TL_NS 2
 #endif
@@ -41,7 +44,7 @@ int main(int argc, char** argv) {
         kern = gemv_stream_kernel<DT_F16, 6, true, TL_NS, 4, 1, 2, 1, 3, 0, 1, 1>;
         sp.ssq_in = ssq; cpb = 16; sp.xs_off = STREAM_FG_XS_OFF; lds = sp.xs_off + (size_t)T * sp.xrow; grid = N / 16;
     } else {                    // down: per-stage activation loads, residual epilogue, hand-off producer
-        kern = gemv_stream_kernel<DT_F16, 6, true, 4, 4, 1, 2, 1, 0, 0, 1, 0>;
+        kern = gemv_stream_kernel<DT_F16, 6, true, TL_NS2, 4, 1, 2, 1, 0, 0, 1, 0>;
         g.accumulate = 1; sp.ssq_out = ssq; sp.xw_out = XW; sp.nw_next = NWT; sp.sNwNext = N; cpb = (cpb + 15) & ~15;
         lds = STREAM_LDS_BYTES; grid = (N + cpb - 1) / cpb;
     }
