@@ -135,3 +135,56 @@ def test_prefill_attention_random_geometries():
         err = (out - ref).abs().max().item()
         tol = 4e-2 if dtype == torch.bfloat16 else 5e-3
         assert err <= tol, (case, B, S, H, KVH, causal, dtype, err)
+
+
+# ---- round 6 glue kernels: exact integer / copy semantics on random geometry
+@settings(max_examples=30, deadline=None)
+@given(T=st.integers(1, 7), S=st.integers(1, 40), KVH=st.sampled_from([1, 2, 4]), G=st.sampled_from([1, 2, 4]), pad=st.integers(0, 24),
+       dtype=st.sampled_from([torch.bfloat16, torch.float16]), seed=st.integers(0, 2 ** 16), data=st.data())
+def test_rope_kv_append_equals_rope_plus_cache_copies_on_random_geometry(bd, T, S, KVH, G, pad, dtype, seed, data):
+    from bitdelta_amd import serving_ops as ops
+    H = KVH * G
+    Lc = S + data.draw(st.integers(0, 30))
+    pos0 = data.draw(st.integers(0, Lc - S))
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    W = (H + 2 * KVH) * 128
+    full = torch.randn(T, S, W + 8 * pad, device="cuda", generator=g).to(dtype)
+    qkv = full[..., :W]
+    f = torch.outer(torch.arange(Lc, device="cuda", dtype=torch.float32), 1.0 / (10000.0 ** (torch.arange(0, 128, 2, device="cuda") / 128.0)))
+    emb = torch.cat([f, f], -1)
+    cos = emb.cos().to(dtype).contiguous()
+    sin = (emb.sin() * torch.cat([-torch.ones(64, device="cuda"), torch.ones(64, device="cuda")])).to(dtype).contiguous()
+    kc = torch.randn(T, KVH, Lc, 128, device="cuda", generator=g).to(dtype)
+    vc = torch.randn(T, KVH, Lc, 128, device="cuda", generator=g).to(dtype)
+    ref_full, kc_ref, vc_ref = full.clone(), kc.clone(), vc.clone()
+    ref = ref_full[..., :W]
+    ops.rope_(ref[..., :(H + KVH) * 128], cos, sin, H + KVH, S, pos0)
+    kc_ref[:, :, pos0:pos0 + S] = ref[..., H * 128:(H + KVH) * 128].reshape(T, S, KVH, 128).transpose(1, 2)
+    vc_ref[:, :, pos0:pos0 + S] = ref[..., (H + KVH) * 128:].reshape(T, S, KVH, 128).transpose(1, 2)
+    ops.rope_kv_append_(qkv, cos, sin, kc, vc, H, KVH, pos0)
+    assert torch.equal(full, ref_full) and torch.equal(kc, kc_ref) and torch.equal(vc, vc_ref)
+
+
+@settings(max_examples=40, deadline=None)
+@given(T=st.integers(1, 9), v8=st.integers(1, 700), dtype=st.sampled_from([torch.bfloat16, torch.float16]), seed=st.integers(0, 2 ** 16),
+       plateau=st.booleans(), nans=st.integers(0, 3), pad=st.integers(0, 3))
+def test_step_end_argmax_matches_torch_on_random_logits(bd, T, v8, dtype, seed, plateau, nans, pad):
+    """the argmax of bd_srv_step_end == torch.argmax on coarse (many exact ties), plateau and NaN-bearing logits of any width V % 8 == 0, rows padded"""
+    from bitdelta_amd import serving_ops as ops
+    V = 8 * v8
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    full = (torch.randn(T, V + 8 * pad, device="cuda", generator=g) * 3).round().to(dtype)      # integers in a small range: ties everywhere
+    logits = full[:, :V]
+    if plateau:
+        logits[:, V // 3:] = logits.max()
+    for i in range(nans):
+        logits[i % T, int(torch.randint(0, V, (1,), generator=torch.Generator().manual_seed(seed + i)))] = float("nan")
+    tok = torch.zeros(T, 1, dtype=torch.long, device="cuda")
+    out = torch.zeros(T, 4, dtype=torch.long, device="cuda")
+    step, pos = torch.tensor([2], device="cuda"), torch.tensor([17], device="cuda")
+    stop_ids = torch.full((T, 1), -1, dtype=torch.long, device="cuda")
+    stopped = torch.zeros(T, dtype=torch.bool, device="cuda")
+    ticket = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.step_end(logits, tok, out, step, pos, stop_ids, stopped, ticket)
+    ref = torch.argmax(logits, dim=-1)
+    assert torch.equal(tok[:, 0], ref) and torch.equal(out[:, 2], ref) and int(step) == 3 and int(pos) == 18 and int(ticket) == 0 and not stopped.any()
