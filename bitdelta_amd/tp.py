@@ -363,11 +363,15 @@ class TPDecoderLayer(nn.Module):
                                               qkv[..., nq + nk:].view(B, S, self.kv_loc, hd))):
             # whole-prompt causal attention straight on the three slices of the fused projection output (as serving_loop does): in-place
             # RoPE of the q and k heads in one launch, flash-style kernel over S keys -- no [S, Lc] mask, no SDPA over the cache length
-            ops.rope_(qkv[..., :nq + nk], cos, sin, self.h_loc + self.kv_loc, S, 0)
             k4, v4 = qkv[..., nq:nq + nk].view(B, S, self.kv_loc, hd), qkv[..., nq + nk:].view(B, S, self.kv_loc, hd)
-            a = ops.prefill_attention(qkv[..., :nq].view(B, S, self.h_loc, hd), k4, v4, causal=True)
-            ck[:, :, :S] = k4.transpose(1, 2)
-            cv[:, :, :S] = v4.transpose(1, 2)
+            if ck.is_contiguous() and cv.is_contiguous() and ck.shape[0] == B:
+                ops.rope_kv_append_(qkv, cos, sin, ck, cv, self.h_loc, self.kv_loc, 0)      # RoPE + both cache writes: one launch (round 6)
+                a = ops.prefill_attention(qkv[..., :nq].view(B, S, self.h_loc, hd), k4, v4, causal=True)
+            else:
+                ops.rope_(qkv[..., :nq + nk], cos, sin, self.h_loc + self.kv_loc, S, 0)
+                a = ops.prefill_attention(qkv[..., :nq].view(B, S, self.h_loc, hd), k4, v4, causal=True)
+                ck[:, :, :S] = k4.transpose(1, 2)
+                cv[:, :, :S] = v4.transpose(1, 2)
         else:
             from .serving_loop import _rope
             q, k, v = self.qkv.split(qkv)
