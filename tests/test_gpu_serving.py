@@ -1396,3 +1396,24 @@ def test_decode_loop_with_step_kernels_generates_the_same_tokens(bd, name, T, dt
         assert n == n_ref and torch.equal(got, ref)
         got_s, n_s = dec.generate(prompts, max_new_tokens=12, stop_token_ids=[s if s else [int(ref[t, 7])] for t, s in enumerate(stops)], use_graph=use_graph)
         assert n_s == n_ref_s and torch.equal(got_s, ref_s) and n_s < 12
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_residual_norm_with_scale_groups_shared_mask_and_shared_norm_weight(bd, dtype):
+    """bd_binary_linear_residual_norm off the serving loop's beaten path: a fused projection with several scale groups (alpha [T, G]), ONE mask shared
+    by all entries (mask batch 1), an odd number of entries -- still bit-identical to residual Linear + RMSNorm"""
+    from bitdelta_amd import serving_ops as ops
+    from bitdelta_amd.binary_gemm_kernel import binary_linear_residual_norm
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for (T, M, N, K, G, shared) in [(5, 48, 4096, 4096, 4, False), (3, 64, 2048, 1024, 2, True), (2, 33, 1024, 512, 1, True)]:
+        x = torch.randn(T, M, K, device="cuda", generator=g).to(dtype)
+        w, mask = _mt_linear(1 if shared else T, N, K, dtype, g)
+        alpha = torch.rand(1 if shared else T, G, device="cuda", generator=g) * 1e-3 + 2e-4
+        resid = torch.randn(T, M, N, device="cuda", generator=g).to(dtype)
+        nw = (1 + 0.1 * torch.randn(T, N, device="cuda", generator=g)).to(dtype)
+        r_ref = resid.clone()
+        bd.binary_linear(x, w, mask, alpha, groups=G, residual=r_ref)
+        h_ref = ops.rmsnorm_tenant(r_ref, nw, 1e-5)
+        r = resid.clone()
+        _, h = binary_linear_residual_norm(x, w, mask, alpha, r, nw, 1e-5, groups=G)
+        assert torch.equal(r, r_ref) and torch.equal(h, h_ref), (T, M, N, K, G, shared)
